@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+    MPLBACKEND=Agg python tests/golden/make_golden.py
+
+Imports luisdiaz1997/GPzoo from /root/reference (read-only, never copied, never
+shipped), evaluates every working (GP class x kernel class) cell of SURVEY.md
+§8a's compatibility matrix on small seeded inputs in fp64 and fp32, and stores
+inputs + outputs as .npz next to this script.  The fixtures are data only.
+
+Stored per case: inputs (X, y, Z, groups, sigma, lengthscale, a, embedding, mu,
+Lu_raw, jitter, noise_sd) and reference outputs (Kxx, Kzx, Kzz_jit, chol, mean,
+scale, Lu, kl, elbo).  The reference has no tests of its own, so these pin the
+oracle (tests/test_oracle_golden.py) and the HIP path (tests/test_hip_golden.py)
+to torch 2.10.0's CPU arithmetic run through the reference's code.
+"""
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.path.insert(0, "/root/reference")
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import distributions
+
+import gpzoo.gp as rgp          # noqa: E402  (the reference)
+import gpzoo.kernels as rk      # noqa: E402
+import gpzoo.likelihoods as rl  # noqa: E402
+from gpzoo.utilities import whitened_KL  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def inv_softplus(v):
+    return float(np.log(np.expm1(v)))
+
+
+def gen(seed, *shape, dist="randn"):
+    g = torch.Generator().manual_seed(seed)
+    f = torch.randn if dist == "randn" else torch.rand
+    return f(*shape, generator=g, dtype=torch.float64)
+
+
+def make_inputs(seed, N, M, d, L, n_groups=0, span=10.0):
+    X = (gen(seed, N, d, dist="rand") - 0.5) * 2 * span
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(seed + 1))
+    Z = X[perm[:M]].clone() + 0.05 * gen(seed + 2, M, d)
+    shape_mu = (L, M) if L else (M,)
+    shape_Lu = (L, M, M) if L else (M, M)
+    mu = 0.5 * gen(seed + 3, *shape_mu)
+    Lu = 0.05 * gen(seed + 4, *shape_Lu)
+    Lu = Lu + torch.diag_embed(-0.3 + 0.1 * gen(seed + 5, *shape_mu)) - torch.diag_embed(torch.diagonal(Lu, dim1=-2, dim2=-1))
+    shape_y = (L, N) if L else (N,)
+    y = torch.sin(X[:, 0] / 3.0).expand(shape_y) + 0.1 * gen(seed + 6, *shape_y)
+    out = dict(X=X, Z=Z, mu=mu, Lu_raw=Lu, y=y)
+    if n_groups:
+        g = torch.Generator().manual_seed(seed + 7)
+        out["gX"] = torch.randint(0, n_groups, (N,), generator=g)
+        out["gZ"] = torch.randint(0, n_groups, (M,), generator=g)
+    return out
+
+
+def run_case(name, gp_cls, kern, inp, dtype, jitter, noise_sd, whitened, mggp):
+    """Evaluate the reference model and collect everything the parity tests use."""
+    M, d = inp["Z"].shape
+    kw = dict(kernel=kern, dim=d, M=M, jitter=jitter)
+    if mggp:
+        kw["n_groups"] = int(kern.embedding.shape[0])
+    gp = gp_cls(**kw)
+    gp.Z = nn.Parameter(inp["Z"].clone())
+    gp.mu = nn.Parameter(inp["mu"].clone())
+    gp.Lu = nn.Parameter(inp["Lu_raw"].clone())
+    if mggp:
+        gp.groupsZ = nn.Parameter(inp["gZ"].clone(), requires_grad=False)
+    model = rl.ExactLikelihood(gp, noise=inv_softplus(noise_sd))
+    model = model.double() if dtype == torch.float64 else model.float()
+    if mggp and not isinstance(kern.embedding, nn.Parameter):
+        kern.embedding = kern.embedding.to(dtype)  # plain tensor attr: .double() does not move it
+    X = inp["X"].to(dtype)
+    y = inp["y"].to(dtype)
+    fkw = dict(groupsX=inp["gX"]) if mggp else {}
+    with torch.no_grad():
+        pY, qF, qU, pU = model(X=X, E=1, **fkw)
+        # intermediate matrices through the same kernel object
+        if mggp:
+            Kzx = kern(gp.Z, X, gp.groupsZ, inp["gX"])
+            Kzz = kern(gp.Z, gp.Z, gp.groupsZ, gp.groupsZ).contiguous()
+            Kxx = kern(X, X, inp["gX"], inp["gX"], diag=True)
+        else:
+            Kzx = kern(gp.Z, X)
+            Kzz = kern(gp.Z, gp.Z).contiguous()
+            Kxx = kern(X, X, diag=True)
+        Kzz_jit = Kzz.clone()
+        Kzz_jit.diagonal(dim1=-2, dim2=-1).add_(jitter)
+        chol = torch.linalg.cholesky(Kzz_jit)
+        s = torch.nn.functional.softplus(model.noise)
+        if whitened:
+            if qU.mean.dim() == 1:
+                kl = whitened_KL(qU.mean, qU.scale_tril)
+            else:  # whitened_KL is 2-D only: apply per latent as the notebooks do
+                kl = torch.stack([whitened_KL(qU.mean[l], qU.scale_tril[l]) for l in range(qU.mean.shape[0])])
+        else:
+            kl = distributions.kl_divergence(qU, pU)
+        elbo = pY.log_prob(y).double().sum() - (qF.scale.double() ** 2).sum() / (2 * s.double() ** 2) - kl.double().sum()
+    out = {k: v.to(dtype).numpy() if v.is_floating_point() else v.numpy() for k, v in inp.items()}
+    out.update(
+        sigma=kern.sigma.detach().numpy(), lengthscale=kern.lengthscale.detach().numpy(),
+        jitter=np.float64(jitter), noise_sd=np.float64(float(s)),
+        Kxx=Kxx.numpy(), Kzx=Kzx.numpy(), Kzz_jit=Kzz_jit.numpy(), chol=chol.numpy(),
+        mean=qF.mean.numpy(), scale=qF.scale.numpy(), Lu=qU.scale_tril.numpy(),
+        kl=kl.numpy(), elbo=np.float64(float(elbo)),
+    )
+    if mggp:
+        out["embedding"] = kern.embedding.detach().numpy()
+        out["group_diff"] = kern.group_diff_param.detach().numpy()
+        out["input_dim"] = np.int64(kern.input_dim)
+    return out
+
+
+def per_latent(vals, shape3=False):
+    t = torch.tensor(vals, dtype=torch.float64)
+    return t.reshape(-1, 1, 1) if shape3 else t
+
+
+def build_kernel(kind, L):
+    sig = [1.0, 0.8, 1.3][:max(L, 1)]
+    ell = [2.5, 4.0, 6.0][:max(L, 1)]
+    a = [0.7, 0.4, 1.1][:max(L, 1)]
+    if kind == "rbf":
+        return rk.RBF(sigma=1.2, lengthscale=3.0)
+    if kind == "nsf_rbf":
+        k = rk.NSF_RBF(L=L)
+        k.sigma = nn.Parameter(per_latent(sig, True)); k.lengthscale = nn.Parameter(per_latent(ell, True))
+        return k
+    if kind == "matern32":
+        k = rk.batched_Matern32()
+        k.sigma = nn.Parameter(per_latent(sig)); k.lengthscale = nn.Parameter(per_latent(ell))
+        return k
+    if kind == "mggp_rbf":
+        return rk.MGGP_RBF(sigma=1.1, lengthscale=3.5, group_diff_param=0.6, n_groups=3)
+    if kind == "mggp_nsf_rbf":
+        k = rk.MGGP_NSF_RBF(n_groups=3, L=L)
+        k.sigma = nn.Parameter(per_latent(sig, True)); k.lengthscale = nn.Parameter(per_latent(ell, True))
+        k.group_diff_param = nn.Parameter(per_latent(a, True))
+        return k
+    raise ValueError(kind)
+
+
+CASES = [
+    # name, gp class, kernel kind, L (0 = single GP), whitened, mggp, jitter
+    ("wsvgp_rbf", "WSVGP", "rbf", 0, True, False, 1e-2),
+    ("wsvgp_nsf_rbf", "WSVGP", "nsf_rbf", 3, True, False, 1e-2),
+    ("wsvgp_matern32", "WSVGP", "matern32", 3, True, False, 1e-2),
+    ("svgp_rbf", "SVGP", "rbf", 0, False, False, 1e-2),
+    ("svgp_nsf_rbf", "SVGP", "nsf_rbf", 3, False, False, 1e-2),
+    ("svgp_matern32", "SVGP", "matern32", 3, False, False, 1e-2),
+    ("mggp_wsvgp_mggp_rbf", "MGGP_WSVGP", "mggp_rbf", 0, True, True, 1e-2),
+    ("mggp_wsvgp_mggp_nsf_rbf", "MGGP_WSVGP", "mggp_nsf_rbf", 3, True, True, 1e-2),
+    ("mggp_svgp_mggp_rbf", "MGGP_SVGP", "mggp_rbf", 0, False, True, 1e-2),
+    ("mggp_svgp_mggp_nsf_rbf", "MGGP_SVGP", "mggp_nsf_rbf", 3, False, True, 1e-2),
+]
+
+
+def kernel_only_cases():
+    """Kernel matrices of the vmap kernels whose `diag` branch is broken at HEAD
+    (SURVEY §8a a3/a7): the full-matrix branch works and is pinned here."""
+    out = {}
+    inp = make_inputs(77, 96, 24, 2, 3, n_groups=3)
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        X, Z = inp["X"].to(dtype), inp["Z"].to(dtype)
+        k = rk.batched_RBF()
+        k.sigma = nn.Parameter(torch.tensor([1.0, 0.8, 1.3], dtype=dtype))
+        k.lengthscale = nn.Parameter(torch.tensor([2.5, 4.0, 6.0], dtype=dtype))
+        ks = rk.batched_RBF(sigma=1.2, lengthscale=3.0).to(dtype)
+        km = rk.batched_MGGP_RBF(sigma=1.1, lengthscale=3.5, group_diff_param=-0.6, n_groups=3).to(dtype)
+        kms = rk.batched_Matern32(sigma=0.9, lengthscale=2.0).to(dtype)
+        with torch.no_grad():
+            out[f"{tag}_batched_rbf_vec"] = k(Z, X).numpy()
+            out[f"{tag}_batched_rbf_scalar"] = ks(Z, X).numpy()
+            out[f"{tag}_batched_mggp_rbf_scalar"] = km(Z, X, inp["gZ"], inp["gX"]).numpy()
+            out[f"{tag}_matern32_scalar"] = kms(Z, X).numpy()
+            out[f"{tag}_matern32_zz"] = kms(Z, Z).numpy()
+        out[f"{tag}_X"], out[f"{tag}_Z"] = X.numpy(), Z.numpy()
+        out[f"{tag}_embedding"] = km.embedding.detach().numpy()
+    out["gX"], out["gZ"] = inp["gX"].numpy(), inp["gZ"].numpy()
+    return out
+
+
+def cfg1_case():
+    """BASELINE.json configs[0]: 1-D regression, N=1000, M=64, single latent,
+    RBF, fp64, un-whitened SVGP + ExactLikelihood (inputs per SURVEY §8d)."""
+    from gpzoo_amd.synthetic import make_config  # the build's own generator
+    c = make_config(1)
+    kern = rk.RBF(sigma=1.0, lengthscale=1.0)
+    inp = dict(X=c["X"], Z=c["Z"], mu=c["mu"], Lu_raw=c["Lu_raw"], y=c["y"])
+    return run_case("cfg1", rgp.SVGP, kern, inp, torch.float64, c["jitter"], c["noise_sd"], False, False)
+
+
+def main():
+    torch.manual_seed(0)
+    for i, (name, gpc, kind, L, whitened, mggp, jitter) in enumerate(CASES):
+        for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            inp = make_inputs(100 + 10 * i, N=160, M=36, d=2, L=L, n_groups=3 if mggp else 0)
+            kern = build_kernel(kind, L)
+            out = run_case(name, getattr(rgp, gpc), kern, inp, dtype, jitter, 0.5, whitened, mggp)
+            out["kind"] = np.array(kind); out["whitened"] = np.array(whitened)
+            np.savez_compressed(os.path.join(HERE, f"{name}_{tag}.npz"), **out)
+            print(f"{name}_{tag}: elbo={float(out['elbo']):.10f}")
+    np.savez_compressed(os.path.join(HERE, "kernels_only.npz"), **kernel_only_cases())
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    out = cfg1_case()
+    out["kind"] = np.array("rbf"); out["whitened"] = np.array(False)
+    np.savez_compressed(os.path.join(HERE, "cfg1_f64.npz"), **out)
+    print(f"cfg1_f64: elbo={float(out['elbo']):.10f}")
+
+
+if __name__ == "__main__":
+    main()

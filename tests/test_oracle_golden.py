@@ -1,0 +1,73 @@
+"""CPU: the oracle reproduces every tensor the reference produced (tests/golden)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases
+from helpers import load_case, oracle_kwargs
+from oracle import svgp_oracle as O
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_oracle_matches_reference(name):
+    c = load_case(name)
+    dt = c["X"].dtype
+    tight = dict(rtol=1e-10, atol=1e-12) if dt == torch.float64 else dict(rtol=2e-5, atol=2e-6)
+    kw = oracle_kwargs(c)
+    kkw = dict(embedding=kw.get("embedding"), group_diff=kw.get("group_diff"), input_dim=kw.get("input_dim", 2))
+    Kzx = O.kernel_matrix(c["kind"], c["Z"], c["X"], c["sigma"], c["lengthscale"],
+                          gA=kw.get("gZ"), gB=kw.get("gX"), **kkw)
+    Kzz = O.kernel_matrix(c["kind"], c["Z"], c["Z"], c["sigma"], c["lengthscale"],
+                          gA=kw.get("gZ"), gB=kw.get("gZ"), **kkw).contiguous()
+    O.add_jitter_(Kzz, c["jitter"])
+    Kxx = O.kernel_diag(c["sigma"], c["X"].shape[0])
+    torch.testing.assert_close(Kzx, c["Kzx"], **tight)
+    torch.testing.assert_close(Kzz, c["Kzz_jit"], **tight)
+    torch.testing.assert_close(Kxx.reshape(c["Kxx"].shape), c["Kxx"], **tight)
+    clamp = 5e-2 if name.startswith("mggp_svgp") else 1e-6
+    if c["whitened"]:
+        mean, scale, Lu, chol = O.wsvgp_moments(Kxx, Kzx, Kzz, c["mu"], c["Lu_raw"])
+        kl = O.whitened_kl(c["mu"], Lu)
+    else:
+        mean, scale, Lu, chol = O.svgp_moments(Kxx, Kzx, Kzz, c["mu"], c["Lu_raw"], clamp)
+        kl = O.mvn_kl(c["mu"], Lu, chol)
+    loose = tight if dt == torch.float64 else dict(rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(chol, c["chol"], **tight)
+    torch.testing.assert_close(Lu, c["Lu"], **tight)
+    torch.testing.assert_close(mean, c["mean"], **loose)
+    torch.testing.assert_close(scale, c["scale"], **loose)
+    torch.testing.assert_close(kl.reshape(c["kl"].shape), c["kl"], **loose)
+    elbo = O.gaussian_elbo(c["y"], mean, scale, c["noise_sd"], kl)
+    assert float(elbo) == pytest.approx(c["elbo"], rel=1e-10 if dt == torch.float64 else 1e-5)
+    e2, _, _ = O.elbo_eval(c["kind"], c["whitened"], c["X"], c["y"], c["Z"], c["sigma"], c["lengthscale"],
+                           c["mu"], c["Lu_raw"], c["jitter"], c["noise_sd"], clamp_min=clamp, **kw)
+    assert float(e2) == pytest.approx(float(elbo), rel=1e-12)
+
+
+def test_oracle_vmap_kernels():
+    z = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "kernels_only.npz"))
+    gX, gZ = torch.from_numpy(z["gX"]), torch.from_numpy(z["gZ"])
+    for tag, dt, tol in (("f64", torch.float64, 1e-11), ("f32", torch.float32, 2e-5)):
+        X, Z = torch.from_numpy(z[f"{tag}_X"]), torch.from_numpy(z[f"{tag}_Z"])
+        emb = torch.from_numpy(z[f"{tag}_embedding"])
+        # scalar kernel params were built as fp32 python floats and then cast (Module.to)
+        t = lambda *v: (torch.tensor(v, dtype=dt) if len(v) > 1 else torch.tensor(v[0]).to(dt))
+        K = O.kernel_matrix("batched_rbf", Z, X, t(1.0, 0.8, 1.3), t(2.5, 4.0, 6.0))
+        torch.testing.assert_close(K, torch.from_numpy(z[f"{tag}_batched_rbf_vec"]), rtol=tol, atol=tol)
+        K = O.kernel_matrix("batched_rbf", Z, X, t(1.2), t(3.0))
+        torch.testing.assert_close(K, torch.from_numpy(z[f"{tag}_batched_rbf_scalar"]), rtol=tol, atol=tol)
+        K = O.kernel_matrix("batched_mggp_rbf", Z, X, t(1.1), t(3.5), gA=gZ, gB=gX, embedding=emb,
+                            group_diff=t(-0.6))
+        torch.testing.assert_close(K, torch.from_numpy(z[f"{tag}_batched_mggp_rbf_scalar"]), rtol=tol, atol=tol)
+        K = O.kernel_matrix("matern32", Z, X, t(0.9), t(2.0))
+        torch.testing.assert_close(K, torch.from_numpy(z[f"{tag}_matern32_scalar"]), rtol=tol, atol=tol)
+        K = O.kernel_matrix("matern32", Z, Z, t(0.9), t(2.0))
+        torch.testing.assert_close(K, torch.from_numpy(z[f"{tag}_matern32_zz"]), rtol=tol, atol=tol)
+
+
+def test_embedding_default_distances():
+    """Default group distances ones - eye => r^2 = 1 between groups, 0 within."""
+    G = 4
+    emb = O.embed_group_distances(torch.ones(G, G) - torch.eye(G))
+    d2 = O.sqdist_direct(emb, emb)
+    torch.testing.assert_close(d2, (torch.ones(G, G) - torch.eye(G)), rtol=1e-4, atol=1e-4)
