@@ -1,0 +1,87 @@
+"""ctypes binding of libgpzoo_hip.so (the C ABI declared in include/gpzoo_hip.h).
+
+The library is the product path: there is no CPU or torch fallback.  If the
+shared object is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgpzoo_hip.so")
+
+GPZ_F32, GPZ_F64 = 0, 1
+KERNEL_RBF, KERNEL_MATERN32, KERNEL_MGGP_RBF = 0, 1, 2
+PROF_SLOTS = ("kfill", "stage1", "stage2", "potrf_trailing", "potrf_all", "trtri", "finalize", "_unused")
+
+
+class KernelDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("n_latent", C.c_int32), ("dtype", C.c_int32), ("n_groups", C.c_int32),
+        ("sigma", C.c_void_p), ("lengthscale", C.c_void_p), ("group_a", C.c_void_p), ("group_r2", C.c_void_p),
+        ("group_pow", C.c_double),
+    ]
+
+
+class SvgpProblem(C.Structure):
+    _fields_ = [
+        ("k", KernelDesc),
+        ("dtype", C.c_int32), ("whitened", C.c_int32), ("d", C.c_int32), ("reserved", C.c_int32),
+        ("N", C.c_int64), ("M", C.c_int64),
+        ("X", C.c_void_p), ("Z", C.c_void_p), ("gX", C.c_void_p), ("gZ", C.c_void_p),
+        ("mu", C.c_void_p), ("Lu_raw", C.c_void_p),
+        ("jitter", C.c_double), ("var_clamp_min", C.c_double),
+        ("y", C.c_void_p), ("noise_sd", C.c_double),
+        ("mean", C.c_void_p), ("scale", C.c_void_p), ("Lu", C.c_void_p), ("chol", C.c_void_p),
+        ("kl", C.c_void_p), ("loglik", C.c_void_p), ("elbo", C.c_void_p), ("info", C.c_void_p),
+    ]
+
+
+_SIGNATURES = {
+    "gpz_version": (C.c_int, []),
+    "gpz_last_error": (C.c_char_p, []),
+    "gpz_kfill": (C.c_int, [C.POINTER(KernelDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_int32,
+                            C.c_void_p]),
+    "gpz_potrf_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "gpz_potrf_batched": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
+    "gpz_trsm_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "gpz_trsm_lln_batched": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                       C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gpz_svgp_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
+    "gpz_svgp_forward": (C.c_int, [C.POINTER(SvgpProblem), C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gpz_profile_enable": (C.c_int, [C.c_int32]),
+    "gpz_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (fails loudly: there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m gpzoo_amd.build` (hipcc, gfx950). "
+            "gpzoo_amd has no CPU/torch fallback for the SVGP hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().gpz_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

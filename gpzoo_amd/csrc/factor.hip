@@ -1,0 +1,345 @@
+// factor.hip -- batched Cholesky (blocked, right-looking) and triangular inverse.
+//
+// Replaces torch.linalg.cholesky (gp.py:213, 270, 360) and, through the explicit
+// inverse, torch.linalg.solve_triangular / torch.cholesky_solve (gp.py:218, 276,
+// 365).  Everything here is fp64 ("factor precision"): the M x M work is ~1% of an
+// evaluation, and an fp64 L^{-1} rounded once keeps the fp32 path's error at
+// fp32 rounding of the big products instead of cond(Kzz) * eps32.
+//
+// Per 128-wide panel k:
+//   1. potf2_inv_kernel  one workgroup per matrix: diagonal block in LDS, column
+//                        sweeps with workgroup-level rank-1 updates; also emits the
+//                        inverse of the block (used by the panel solve and trtri).
+//   2. panel             L[i][k] = A[i][k] * inv(L[k][k])^T          (MFMA GEMM, NT)
+//   3. trailing          A[i][j] -= L[i][k] * L[j][k]^T, i >= j > k  (MFMA SYRK/GEMM)
+// Triangular inverse by recursive doubling: with the diagonal blocks inverted,
+// inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]] is applied level by level,
+// two MFMA GEMMs per level batched over all pairs and latents.
+#include "common.h"
+#include "gemm.h"
+
+#include <vector>
+
+namespace gpz {
+
+constexpr int NB = 128;        // panel width == GEMM tile
+constexpr int P2 = NB + 1;     // LDS pitch (doubles)
+
+// Factor the diagonal block (bk, bk) of every matrix in place, write zeros above
+// its diagonal, and write the block's inverse (full 128x128, zeros above) to Dinv.
+__global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int64_t stride,
+                                                       int bk, double* __restrict__ Dinv, int64_t dinv_stride,
+                                                       int32_t* __restrict__ info, int64_t m_real) {
+  extern __shared__ __attribute__((aligned(16))) double S[];  // [128][129]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  double* Ab = A + (int64_t)b * stride + (int64_t)bk * NB * (lda + 1);
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 7, j = e & 127;
+    S[i * P2 + j] = (j <= i) ? Ab[(int64_t)i * lda + j] : 0.0;
+  }
+  const int ti = tid >> 4, tk = tid & 15;
+  // ---- Cholesky: right-looking column sweep ----
+  for (int j = 0; j < NB; ++j) {
+    __syncthreads();
+    double d = S[j * P2 + j];
+    const bool bad = !(d > 0.0);
+    if (bad) {
+      if (tid == 0 && (int64_t)bk * NB + j < m_real) atomicCAS(&info[b], 0, bk * NB + j + 1);
+      d = 1.0;
+    }
+    const double rs = 1.0 / sqrt(d);
+    if (tid < NB - 1 - j) S[(j + 1 + tid) * P2 + j] *= rs;
+    __syncthreads();
+    if (tid == 0) S[j * P2 + j] = d * rs;
+    for (int i = j + 1 + ti; i < NB; i += 16) {
+      const double lij = S[i * P2 + j];
+      for (int k = j + 1 + tk; k <= i; k += 16) S[i * P2 + k] -= lij * S[k * P2 + j];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 7, j = e & 127;
+    Ab[(int64_t)i * lda + j] = (j <= i) ? S[i * P2 + j] : 0.0;
+  }
+  // ---- inverse: X[i][c] (i >= c) kept transposed above the diagonal at S[c][i+1] ----
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int c = e >> 7, i = e & 127;
+    if (i >= c) S[c * P2 + i + 1] = (i == c) ? 1.0 : 0.0;
+  }
+  for (int k = 0; k < NB; ++k) {
+    __syncthreads();
+    const double rk = 1.0 / S[k * P2 + k];
+    if (tid <= k) S[tid * P2 + k + 1] *= rk;          // row k of X is final
+    __syncthreads();
+    for (int i = k + 1 + ti; i < NB; i += 16) {
+      const double lik = S[i * P2 + k];
+      for (int c = tk; c <= k; c += 16) S[c * P2 + i + 1] -= lik * S[c * P2 + k + 1];
+    }
+  }
+  __syncthreads();
+  double* Db = Dinv + (int64_t)b * dinv_stride + (int64_t)bk * NB * NB;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 7, c = e & 127;
+    Db[e] = (c <= i) ? S[c * P2 + i + 1] : 0.0;
+  }
+}
+
+// Copies the inverted diagonal blocks into the diagonal of Linv (rest zeroed by memset).
+__global__ void scatter_diag_kernel(const double* __restrict__ Dinv, int64_t dinv_stride, double* __restrict__ Linv,
+                                    int64_t ld, int64_t stride, int nblk) {
+  const int b = blockIdx.y, k = blockIdx.x;
+  const double* src = Dinv + (int64_t)b * dinv_stride + (int64_t)k * NB * NB;
+  double* dst = Linv + (int64_t)b * stride + (int64_t)k * NB * (ld + 1);
+  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) dst[(int64_t)(e >> 7) * ld + (e & 127)] = src[e];
+}
+
+static bool g_potf2_attr_set = false;
+
+// In-place Cholesky of `batch` padded (Mp,Mp) fp64 matrices; Dinv receives the inverse of
+// every diagonal 128-block: (batch, Mp/128, 128, 128).
+int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
+                 int32_t* info, hipStream_t s) {
+  GPZ_REQUIRE(Mp % NB == 0 && Mp > 0, "potrf: padded order %lld is not a multiple of %d", (long long)Mp, NB);
+  const int nblk = (int)(Mp / NB);
+  const int64_t dstride = (int64_t)nblk * NB * NB;
+  const size_t lds = (size_t)NB * P2 * sizeof(double);
+  if (!g_potf2_attr_set) {
+    GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    g_potf2_attr_set = true;
+  }
+  GPZ_HIP_OK(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, s));
+  prof_begin(PROF_POTRF_ALL, s);
+  for (int k = 0; k < nblk; ++k) {
+    hipLaunchKernelGGL(potf2_inv_kernel, dim3((unsigned)batch), dim3(256), lds, s, A, lda, stride, k, Dinv, dstride,
+                       info, m_real);
+    GPZ_LAUNCH_OK();
+    const int rem = nblk - k - 1;
+    if (rem == 0) break;
+    // panel: rows below the diagonal block, in place
+    GemmParams<double> g;
+    g.A = A + (int64_t)(k + 1) * NB * lda + (int64_t)k * NB; g.lda = lda; g.sA0 = stride;
+    g.B = Dinv + (int64_t)k * NB * NB; g.ldb = NB; g.sB0 = dstride;
+    g.C = const_cast<double*>(g.A); g.ldc = lda; g.sC0 = stride;
+    g.nb0 = (int)batch; g.mt = rem; g.nt = 1; g.K = NB; g.flags = GF_B_TRANS;
+    if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
+    // trailing update: A22 -= L21 L21^T (lower tiles only)
+    GemmParams<double> t;
+    t.A = g.A; t.lda = lda; t.sA0 = stride;
+    t.B = g.A; t.ldb = lda; t.sB0 = stride;
+    t.C = A + (int64_t)(k + 1) * NB * (lda + 1); t.ldc = lda; t.sC0 = stride;
+    t.nb0 = (int)batch; t.mt = rem; t.nt = rem; t.K = NB; t.flags = GF_B_TRANS | GF_TILES_LOWER;
+    t.alpha = -1.0; t.beta = 1.0;
+    prof_begin(PROF_POTRF_TRAIL, s);
+    if (int rc = gemm_launch(t, EPI_STORE, s)) return rc;
+    prof_end(PROF_POTRF_TRAIL, s);
+  }
+  prof_end(PROF_POTRF_ALL, s);
+  return 0;
+}
+
+// Linv = inverse of the lower-triangular factor held in Lc (padded), by recursive
+// doubling over the 128-blocks.  T is scratch of batch * Mp * Mp / 2 doubles.
+int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* Dinv, double* Linv, int64_t Mp,
+                 int64_t batch, double* T, hipStream_t s) {
+  const int nblk = (int)(Mp / NB);
+  const int64_t dstride = (int64_t)nblk * NB * NB;
+  const int64_t stride = Mp * Mp;
+  prof_begin(PROF_TRTRI, s);
+  GPZ_HIP_OK(hipMemsetAsync(Linv, 0, sizeof(double) * stride * batch, s));
+  hipLaunchKernelGGL(scatter_diag_kernel, dim3(nblk, (unsigned)batch), dim3(256), 0, s, Dinv, dstride, Linv, Mp, stride,
+                     nblk);
+  GPZ_LAUNCH_OK();
+  // segments: boundaries of the already-inverted diagonal blocks, in units of NB
+  std::vector<int> seg(nblk + 1);
+  for (int i = 0; i <= nblk; ++i) seg[i] = i;
+  const int64_t tstride = stride / 2;
+  while (seg.size() > 2) {
+    const int npairs = (int)(seg.size() - 1) / 2;
+    // uniform pairs are batched in one launch; a ragged last pair goes alone
+    int p = 0;
+    while (p < npairs) {
+      const int a = seg[2 * p + 1] - seg[2 * p], c = seg[2 * p + 2] - seg[2 * p + 1];
+      int run = 1;
+      while (p + run < npairs && seg[2 * (p + run) + 1] - seg[2 * (p + run)] == a &&
+             seg[2 * (p + run) + 2] - seg[2 * (p + run) + 1] == c &&
+             seg[2 * (p + run)] - seg[2 * (p + run - 1)] == a + c)
+        ++run;
+      const int64_t r0 = (int64_t)seg[2 * p] * NB, r1 = (int64_t)seg[2 * p + 1] * NB;
+      const int64_t pair_step = (int64_t)(a + c) * NB;
+      // T = C * Ainv    (c x a) = (c x a)(a x a lower)
+      GemmParams<double> g1;
+      g1.A = Lc + r1 * ldl + r0; g1.lda = ldl; g1.sA0 = stride_l; g1.sA1 = pair_step * (ldl + 1);
+      g1.B = Linv + r0 * Mp + r0; g1.ldb = Mp; g1.sB0 = stride; g1.sB1 = pair_step * (Mp + 1);
+      g1.C = T; g1.ldc = (int64_t)a * NB; g1.sC0 = tstride; g1.sC1 = (int64_t)a * NB * c * NB;
+      g1.nb0 = (int)batch; g1.nb1 = run; g1.mt = c; g1.nt = a; g1.K = a * NB; g1.flags = GF_B_LOWER;
+      if (int rc = gemm_launch(g1, EPI_STORE, s)) return rc;
+      // X = -Binv * T   (c x a) = (c x c lower)(c x a)
+      GemmParams<double> g2;
+      g2.A = Linv + r1 * Mp + r1; g2.lda = Mp; g2.sA0 = stride; g2.sA1 = pair_step * (Mp + 1);
+      g2.B = T; g2.ldb = g1.ldc; g2.sB0 = tstride; g2.sB1 = g1.sC1;
+      g2.C = Linv + r1 * Mp + r0; g2.ldc = Mp; g2.sC0 = stride; g2.sC1 = pair_step * (Mp + 1);
+      g2.nb0 = (int)batch; g2.nb1 = run; g2.mt = c; g2.nt = a; g2.K = c * NB; g2.flags = GF_A_LOWER;
+      g2.alpha = -1.0;
+      if (int rc = gemm_launch(g2, EPI_STORE, s)) return rc;
+      p += run;
+    }
+    std::vector<int> nseg;
+    for (size_t i = 0; i + 2 < seg.size(); i += 2) nseg.push_back(seg[i]);
+    if ((seg.size() - 1) % 2 == 1) nseg.push_back(seg[seg.size() - 2]);
+    nseg.push_back(seg.back());
+    seg.swap(nseg);
+  }
+  prof_end(PROF_TRTRI, s);
+  return 0;
+}
+
+// ---- ragged <-> padded copies for the public entry points ----
+__global__ void pad_copy_in_kernel(const double* __restrict__ src, int64_t ld, int64_t stride, int64_t m,
+                                   double* __restrict__ dst, int64_t mp, int lower_identity) {
+  const int64_t b = blockIdx.z;
+  const int64_t i = blockIdx.y;
+  for (int64_t j = threadIdx.x + (int64_t)blockIdx.x * blockDim.x; j < mp; j += (int64_t)blockDim.x * gridDim.x) {
+    double v = (i < m && j < m) ? src[b * stride + i * ld + j] : ((lower_identity && i == j) ? 1.0 : 0.0);
+    dst[b * mp * mp + i * mp + j] = v;
+  }
+}
+
+__global__ void pad_copy_out_kernel(const double* __restrict__ src, int64_t mp, double* __restrict__ dst, int64_t ld,
+                                    int64_t stride, int64_t m) {
+  const int64_t b = blockIdx.z;
+  const int64_t i = blockIdx.y;
+  for (int64_t j = threadIdx.x + (int64_t)blockIdx.x * blockDim.x; j < m; j += (int64_t)blockDim.x * gridDim.x)
+    dst[b * stride + i * ld + j] = (j <= i) ? src[b * mp * mp + i * mp + j] : 0.0;  // zeros above the diagonal
+}
+
+}  // namespace gpz
+
+using namespace gpz;
+
+extern "C" size_t gpz_potrf_workspace_bytes(int64_t M, int64_t batch) {
+  const int64_t Mp = pad_up(M);
+  Carver c(nullptr);
+  c.take<double>(batch * Mp * Mp);              // padded copy
+  c.take<double>(batch * (Mp / NB) * NB * NB);  // Dinv
+  return c.used();
+}
+
+extern "C" int gpz_potrf_batched(double* A, int64_t M, int64_t lda, int64_t stride_a, int64_t batch, int32_t* info,
+                                 void* ws, size_t ws_bytes, void* stream) {
+  GPZ_REQUIRE(A && info && ws, "gpz_potrf_batched: null pointer");
+  GPZ_REQUIRE(M >= 1 && lda >= M && batch >= 1, "gpz_potrf_batched: bad extents");
+  GPZ_REQUIRE(ws_bytes >= gpz_potrf_workspace_bytes(M, batch), "gpz_potrf_batched: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t Mp = pad_up(M);
+  Carver c(ws);
+  double* Ap = c.take<double>(batch * Mp * Mp);
+  double* Dinv = c.take<double>(batch * (Mp / NB) * NB * NB);
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp, (unsigned)batch);
+  hipLaunchKernelGGL(pad_copy_in_kernel, grid, dim3(256), 0, s, A, lda, stride_a, M, Ap, Mp, 1);
+  GPZ_LAUNCH_OK();
+  if (int rc = potrf_padded(Ap, Mp, Mp, Mp * Mp, batch, M, Dinv, info, s)) return rc;
+  dim3 grid2((unsigned)((M + 255) / 256), (unsigned)M, (unsigned)batch);
+  hipLaunchKernelGGL(pad_copy_out_kernel, grid2, dim3(256), 0, s, Ap, Mp, A, lda, stride_a, M);
+  GPZ_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" size_t gpz_trsm_workspace_bytes(int64_t M, int64_t N, int64_t batch) {
+  const int64_t Mp = pad_up(M), Np = pad_up(N);
+  Carver c(nullptr);
+  c.take<double>(batch * Mp * Mp);              // padded factor
+  c.take<double>(batch * (Mp / NB) * NB * NB);  // Dinv
+  c.take<double>(batch * Mp * Mp);              // Linv
+  c.take<double>(batch * Mp * Mp / 2);          // T
+  c.take<double>(batch * Mp * Np);              // padded B
+  c.take<double>(batch * Mp * Np);              // padded X
+  return c.used();
+}
+
+namespace gpz {
+// Inverts the diagonal 128-blocks of an already-factored lower-triangular matrix.
+__global__ __launch_bounds__(256) void trinv_diag_kernel(const double* __restrict__ Lc, int64_t ld, int64_t stride,
+                                                        double* __restrict__ Dinv, int64_t dinv_stride) {
+  extern __shared__ __attribute__((aligned(16))) double S[];
+  const int tid = threadIdx.x, b = blockIdx.y, bk = blockIdx.x;
+  const double* Lb = Lc + (int64_t)b * stride + (int64_t)bk * NB * (ld + 1);
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 7, j = e & 127;
+    if (j <= i) S[i * P2 + j] = Lb[(int64_t)i * ld + j];
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int c = e >> 7, i = e & 127;
+    if (i >= c) S[c * P2 + i + 1] = (i == c) ? 1.0 : 0.0;
+  }
+  const int ti = tid >> 4, tk = tid & 15;
+  for (int k = 0; k < NB; ++k) {
+    __syncthreads();
+    const double rk = 1.0 / S[k * P2 + k];
+    if (tid <= k) S[tid * P2 + k + 1] *= rk;
+    __syncthreads();
+    for (int i = k + 1 + ti; i < NB; i += 16) {
+      const double lik = S[i * P2 + k];
+      for (int c = tk; c <= k; c += 16) S[c * P2 + i + 1] -= lik * S[c * P2 + k + 1];
+    }
+  }
+  __syncthreads();
+  double* Db = Dinv + (int64_t)b * dinv_stride + (int64_t)bk * NB * NB;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 7, c = e & 127;
+    Db[e] = (c <= i) ? S[c * P2 + i + 1] : 0.0;
+  }
+}
+static bool g_trinv_attr_set = false;
+}  // namespace gpz
+
+extern "C" int gpz_trsm_lln_batched(const double* Lc, int64_t ldl, int64_t stride_l, double* B, int64_t ldb,
+                                    int64_t stride_b, int64_t M, int64_t N, int64_t batch, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  GPZ_REQUIRE(Lc && B && ws, "gpz_trsm_lln_batched: null pointer");
+  GPZ_REQUIRE(M >= 1 && N >= 1 && batch >= 1 && ldl >= M && ldb >= N, "gpz_trsm_lln_batched: bad extents");
+  GPZ_REQUIRE(ws_bytes >= gpz_trsm_workspace_bytes(M, N, batch), "gpz_trsm_lln_batched: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t Mp = pad_up(M), Np = pad_up(N);
+  const int nblk = (int)(Mp / NB);
+  Carver c(ws);
+  double* Lp = c.take<double>(batch * Mp * Mp);
+  double* Dinv = c.take<double>(batch * nblk * NB * NB);
+  double* Linv = c.take<double>(batch * Mp * Mp);
+  double* T = c.take<double>(batch * Mp * Mp / 2);
+  double* Bp = c.take<double>(batch * Mp * Np);
+  double* Xp = c.take<double>(batch * Mp * Np);
+  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp, (unsigned)batch);
+  hipLaunchKernelGGL(pad_copy_in_kernel, grid, dim3(256), 0, s, Lc, ldl, stride_l, M, Lp, Mp, 1);
+  GPZ_LAUNCH_OK();
+  const size_t lds = (size_t)NB * P2 * sizeof(double);
+  if (!g_trinv_attr_set) {
+    GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(trinv_diag_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    g_trinv_attr_set = true;
+  }
+  hipLaunchKernelGGL(trinv_diag_kernel, dim3(nblk, (unsigned)batch), dim3(256), lds, s, Lp, Mp, Mp * Mp, Dinv,
+                     (int64_t)nblk * NB * NB);
+  GPZ_LAUNCH_OK();
+  if (int rc = trtri_padded(Lp, Mp, Mp * Mp, Dinv, Linv, Mp, batch, T, s)) return rc;
+  // padded right-hand side (rows >= M and columns >= N are zero)
+  GPZ_HIP_OK(hipMemsetAsync(Bp, 0, sizeof(double) * batch * Mp * Np, s));
+  GPZ_HIP_OK(hipMemcpy2DAsync(Bp, Np * sizeof(double), B, ldb * sizeof(double), N * sizeof(double), M,
+                              hipMemcpyDeviceToDevice, s));
+  for (int64_t b = 1; b < batch; ++b)
+    GPZ_HIP_OK(hipMemcpy2DAsync(Bp + b * Mp * Np, Np * sizeof(double), B + b * stride_b, ldb * sizeof(double),
+                                N * sizeof(double), M, hipMemcpyDeviceToDevice, s));
+  GemmParams<double> g;
+  g.A = Linv; g.lda = Mp; g.sA0 = Mp * Mp;
+  g.B = Bp; g.ldb = Np; g.sB0 = Mp * Np;
+  g.C = Xp; g.ldc = Np; g.sC0 = Mp * Np;
+  g.nb0 = (int)batch; g.mt = nblk; g.nt = (int)(Np / NB); g.K = (int)Mp; g.flags = GF_A_LOWER;
+  if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
+  for (int64_t b = 0; b < batch; ++b)
+    GPZ_HIP_OK(hipMemcpy2DAsync(B + b * stride_b, ldb * sizeof(double), Xp + b * Mp * Np, Np * sizeof(double),
+                                N * sizeof(double), M, hipMemcpyDeviceToDevice, s));
+  return 0;
+}

@@ -1,0 +1,262 @@
+// gemm.hip -- 128x128-tile batched GEMM on the CDNA4 matrix cores.
+//
+// fp32: v_mfma_f32_16x16x4_f32, fp64: v_mfma_f64_16x16x4_f64 (exact IEEE FMA
+// chains, so results are deterministic and match a plain fp32/fp64 reference to
+// rounding).  256 threads = 4 waves in a 2x2 grid, 64x64 outputs per wave held
+// in 16 accumulator tiles.  A and (transposed) B tiles are staged [row][k] in LDS
+// and fetched with one 16-byte ds_read per lane covering VEC consecutive k; the
+// non-transposed B tile is staged [k][n].  Because the MFMA sums its four k
+// slots, lane group q may own k = VEC*q .. VEC*q+VEC-1 as long as A and B agree,
+// which is what makes the wide read legal.  Global->LDS staging is double
+// buffered through registers with one barrier per k-tile.
+//
+// Triangular structure (L^{-1} and Lu^T are triangular, SYRK only needs the lower
+// tiles) is expressed as a per-tile k-range in units of the 128-block, so no
+// flop is spent on known-zero blocks.
+#include "gemm.h"
+
+namespace gpz {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  using acc_t = f32x4;
+  using vec_t = f32x4;  // 16 bytes
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of the 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg
+  static __device__ __forceinline__ int crow(int q, int g) { return 4 * q + g; }
+};
+template <> struct Mma<double> {
+  using acc_t = f64x4;
+  using vec_t = f64x2;
+  static constexpr int VEC = 2;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // f64 is the exception: row = (lane >> 4) + 4 * reg
+  static __device__ __forceinline__ int crow(int q, int g) { return q + 4 * g; }
+};
+
+template <typename T, bool BT, int EPI>
+__global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams<T> p) {
+  using M = Mma<T>;
+  using vec_t = typename M::vec_t;
+  using acc_t = typename M::acc_t;
+  constexpr int VEC = M::VEC;
+  constexpr int BK = 4 * VEC;               // 16 (f32) / 8 (f64): 64 bytes of k per row
+  constexpr int LDR = BK + 2 * VEC;         // [row][k] tiles: 96-byte rows, conflict-free 16-B reads
+  constexpr int LDN = 128 + (VEC == 4 ? 4 : 8);  // [k][n] tile row (elements)
+  constexpr int A_ELEMS = 128 * LDR;
+  constexpr int B_ELEMS = BT ? 128 * LDR : BK * LDN;
+  __shared__ __attribute__((aligned(16))) T smem[2 * (A_ELEMS + B_ELEMS)];
+  auto sA = [&](int buf) -> T* { return smem + buf * (A_ELEMS + B_ELEMS); };
+  auto sB = [&](int buf) -> T* { return smem + buf * (A_ELEMS + B_ELEMS) + A_ELEMS; };
+
+  // ---------------- tile decode ----------------
+  int b0, b1, ti, tj;
+  {
+    const int bid = blockIdx.x;
+    if (p.flags & GF_GROUP_COLS) {
+      const int x = bid & 7, s = bid >> 3;
+      const int grp = (s / p.mt) * 8 + x, ii = s % p.mt;
+      if (grp >= p.nb0 * p.nt) return;
+      b0 = grp / p.nt; tj = grp - b0 * p.nt; b1 = 0;
+      ti = (p.flags & GF_A_LOWER) ? p.mt - 1 - ii : ii;   // longest k-range first
+    } else {
+      const int per = (p.flags & GF_TILES_LOWER) ? p.mt * (p.mt + 1) / 2 : p.mt * p.nt;
+      const int b = bid / per;
+      int t = bid - b * per;
+      b0 = b / p.nb1; b1 = b - b0 * p.nb1;
+      if (p.flags & GF_TILES_LOWER) {
+        int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        while (i * (i + 1) / 2 > t) --i;
+        ti = i; tj = t - i * (i + 1) / 2;
+      } else {
+        ti = t / p.nt; tj = t - ti * p.nt;
+      }
+    }
+  }
+  int k_begin = 0, k_end = p.K;
+  if (p.flags & GF_A_LOWER) k_end = min(k_end, (ti + 1) * 128);
+  if (p.flags & GF_A_UPPER) k_begin = max(k_begin, ti * 128);
+  if (p.flags & GF_B_LOWER) k_begin = max(k_begin, tj * 128);
+  if (p.flags & GF_B_UPPER) k_end = min(k_end, (tj + 1) * 128);
+
+  const T* Ag = p.A + b0 * p.sA0 + b1 * p.sA1 + (int64_t)ti * 128 * p.lda;
+  const T* Bg = p.B + b0 * p.sB0 + b1 * p.sB1 + (BT ? (int64_t)tj * 128 * p.ldb : (int64_t)tj * 128);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, q = lane >> 4;
+
+  // ---------------- staging maps (16 bytes per thread per load) ----------------
+  // [row][k] tiles (A, and B when BT): 4 vectors per row, 64 rows per pass, 2 passes
+  const int ra_row = tid >> 2, ra_vc = (tid & 3) * VEC;
+  // [k][n] tile: 128/VEC vectors per row
+  constexpr int NV = 128 / VEC;               // 32 / 64 threads per row
+  constexpr int BROWS = 256 / NV;             // 8 / 4 rows per pass
+  const int rb_row = tid / NV, rb_vc = (tid % NV) * VEC;
+
+  vec_t ga[2], gb[2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      ga[h] = *reinterpret_cast<const vec_t*>(Ag + (int64_t)(ra_row + 64 * h) * p.lda + k0 + ra_vc);
+    if (BT) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        gb[h] = *reinterpret_cast<const vec_t*>(Bg + (int64_t)(ra_row + 64 * h) * p.ldb + k0 + ra_vc);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        gb[h] = *reinterpret_cast<const vec_t*>(Bg + (int64_t)(k0 + rb_row + BROWS * h) * p.ldb + rb_vc);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      *reinterpret_cast<vec_t*>(sA(buf) + (ra_row + 64 * h) * LDR + ra_vc) = ga[h];
+    if (BT) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<vec_t*>(sB(buf) + (ra_row + 64 * h) * LDR + ra_vc) = gb[h];
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<vec_t*>(sB(buf) + (rb_row + BROWS * h) * LDN + rb_vc) = gb[h];
+    }
+  };
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = acc_t{0, 0, 0, 0};
+
+  const int nk = (k_end - k_begin) / BK;
+  if (nk > 0) {
+    gload(k_begin);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) gload(k_begin + (t + 1) * BK);
+    // fragments: lane (r, q) owns k = VEC*q + j, j < VEC
+    vec_t fa[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      fa[mi] = *reinterpret_cast<const vec_t*>(sA(buf) + (wm * 64 + mi * 16 + r) * LDR + q * VEC);
+    if (BT) {
+      vec_t fb[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        fb[ni] = *reinterpret_cast<const vec_t*>(sB(buf) + (wn * 64 + ni * 16 + r) * LDR + q * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni][j], acc[mi][ni]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        T fb[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fb[ni] = sB(buf)[(q * VEC + j) * LDN + wn * 64 + ni * 16 + r];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni], acc[mi][ni]);
+      }
+    }
+    if (t + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const int64_t crow0 = (int64_t)ti * 128 + wm * 64;
+  const int64_t ccol0 = (int64_t)tj * 128 + wn * 64;
+  if (EPI != EPI_STATS) {
+    T* Cg = p.C + b0 * p.sC0 + b1 * p.sC1;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          T* dst = Cg + (crow0 + mi * 16 + M::crow(q, g)) * p.ldc + ccol0 + ni * 16 + r;
+          T v = p.alpha * acc[mi][ni][g];
+          if (p.beta != (T)0) v += p.beta * *dst;
+          *dst = v;
+        }
+  }
+  if (EPI != EPI_STORE) {
+    // column sums over this block's 128 rows: registers -> lane groups -> the two wm waves
+    T* red = smem;  // [2 stats][2 wm][128 cols]; all tile reads are behind the loop's last barrier
+    const T* mu = (EPI == EPI_STORE_STATS) ? p.mu + b0 * p.sMu + crow0 : nullptr;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      T ssq = 0, smu = 0;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const T v = p.alpha * acc[mi][ni][g];
+          ssq = fma(v, v, ssq);
+          if (EPI == EPI_STORE_STATS) smu = fma(mu[mi * 16 + M::crow(q, g)], v, smu);
+        }
+      ssq += __shfl_xor(ssq, 16); ssq += __shfl_xor(ssq, 32);
+      if (EPI == EPI_STORE_STATS) { smu += __shfl_xor(smu, 16); smu += __shfl_xor(smu, 32); }
+      if (q == 0) {
+        red[wm * 128 + wn * 64 + ni * 16 + r] = ssq;
+        if (EPI == EPI_STORE_STATS) red[256 + wm * 128 + wn * 64 + ni * 16 + r] = smu;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int64_t o = ((int64_t)b0 * p.mt + ti) * p.ncols + (int64_t)tj * 128 + tid;
+      p.ps_sq[o] = red[tid] + red[128 + tid];
+      if (EPI == EPI_STORE_STATS) p.ps_mu[o] = red[256 + tid] + red[384 + tid];
+    }
+  }
+}
+
+template <typename T>
+int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
+  GPZ_REQUIRE(p.mt > 0 && p.nt > 0 && p.nb0 > 0 && p.nb1 > 0, "gemm: empty problem");
+  GPZ_REQUIRE(p.K % 128 == 0, "gemm: K=%d is not a multiple of 128", p.K);
+  GPZ_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "gemm: leading dimensions must be multiples of 4");
+  int64_t nblocks;
+  if (p.flags & GF_GROUP_COLS) {
+    GPZ_REQUIRE(p.nb1 == 1 && !(p.flags & GF_TILES_LOWER), "gemm: GROUP_COLS needs a flat batch and a full tile grid");
+    const int64_t groups = (int64_t)p.nb0 * p.nt;
+    nblocks = (groups + 7) / 8 * 8 * p.mt;
+  } else {
+    const int64_t per = (p.flags & GF_TILES_LOWER) ? (int64_t)p.mt * (p.mt + 1) / 2 : (int64_t)p.mt * p.nt;
+    nblocks = per * p.nb0 * p.nb1;
+  }
+  GPZ_REQUIRE(nblocks < (1ll << 31), "gemm: grid too large");
+  const bool bt = (p.flags & GF_B_TRANS) != 0;
+  dim3 grid((unsigned)nblocks), block(256);
+#define GPZ_GEMM(BT, EPI) hipLaunchKernelGGL((gemm128_kernel<T, BT, EPI>), grid, block, 0, s, p)
+  if (epilogue == EPI_STORE) { if (bt) GPZ_GEMM(true, EPI_STORE); else GPZ_GEMM(false, EPI_STORE); }
+  else if (epilogue == EPI_STORE_STATS) { GPZ_REQUIRE(!bt, "gemm: stats epilogues are NN only"); GPZ_GEMM(false, EPI_STORE_STATS); }
+  else { GPZ_REQUIRE(!bt, "gemm: stats epilogues are NN only"); GPZ_GEMM(false, EPI_STATS); }
+#undef GPZ_GEMM
+  GPZ_LAUNCH_OK();
+  return 0;
+}
+
+template int gemm_launch<float>(const GemmParams<float>&, int, hipStream_t);
+template int gemm_launch<double>(const GemmParams<double>&, int, hipStream_t);
+
+}  // namespace gpz

@@ -1,0 +1,468 @@
+// svgp.hip -- one SVGP / WSVGP forward pass + closed-form Gaussian ELBO.
+//
+// Replaces WSVGP.forward (gp.py:260-306), SVGP.forward (gp.py:183-232 with
+// svgp_forward utilities.py:382-397), the MGGP variants (gp.py:341-399),
+// whitened_KL (utilities.py:27-36), kl_divergence(qU, pU) (utilities.py:481) and
+// the ELBO assembly of mggp_test_exact.ipynb:157-159.
+//
+// With Linv = chol(Kzz + jitter I)^{-1} (fp64, factor.hip) both variants reduce to
+//   Wt   = Linv  Kzx                       (lower-triangular x dense, MFMA)
+//   P    = LuE^T Wt                        (upper-triangular x dense, MFMA)
+//   mean = muE^T Wt,  s1 = colsum(Wt^2),  s2 = colsum(P^2)
+// whitened   (gp.py:276-296): LuE = Lu,       muE = mu,      var = max(s^2 - s1, 0) + s2
+// un-whitened (gp.py:218-228): LuE = Linv Lu, muE = Linv mu, var = max(s^2 - s1 + s2, clamp)
+// because W = Kxz Kzz^{-1} = Wt^T Linv, so W mu = Wt^T (Linv mu), diag(W Kzz W^T) =
+// colsum(Wt^2) and diag(W S W^T) = colsum(((Linv Lu)^T Wt)^2).
+// N is processed in chunks so Kzx / Wt only ever exist one chunk at a time; P is
+// never stored.  All reductions are slab-based (no atomics): bitwise reproducible.
+#include "common.h"
+#include "gemm.h"
+
+namespace gpz {
+
+int kfill_padded(const gpz_kernel_desc* k, const void* A, int64_t nA, int64_t pA, const void* B, int64_t nB,
+                 int64_t pB, int d, const int64_t* gA, const int64_t* gB, void* K, int64_t ldk, int64_t stride,
+                 double jitter, int pad_identity, int out_dtype, hipStream_t s);
+int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
+                 int32_t* info, hipStream_t s);
+int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* Dinv, double* Linv, int64_t Mp,
+                 int64_t batch, double* T, hipStream_t s);
+
+constexpr int NB = 128;
+constexpr int RED_BLOCKS = 64;  // per-latent partial slots of the M x M reductions
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  // fixed-shape tree: lanes -> waves -> block (deterministic)
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;  // valid on thread 0
+}
+
+// Constrained scale_tril of q(U) from the raw parameter (gp.py:220/278: strict lower
+// triangle kept, diagonal exponentiated), emitted in up to three forms:
+//   LuT   (L,Mp,Mp) TG  transposed (upper triangular), zero padded      [whitened: the stage-2 operand]
+//   LuD   (L,Mp,Mp) f64 as is (lower triangular), zero padded           [un-whitened: input to Linv * Lu]
+//   LuOut (L,M,M)   TIO for MultivariateNormal(scale_tril=...)
+// and per-block partial sums of ||Lu||_F^2 and of the raw diagonal (= log diag Lu).
+template <typename T>
+__global__ __launch_bounds__(256) void lu_prepare_kernel(const T* __restrict__ raw, int64_t M, int64_t Mp,
+                                                        T* __restrict__ LuT, double* __restrict__ LuD,
+                                                        T* __restrict__ LuOut, double* __restrict__ part) {
+  __shared__ double tile[32][33];
+  __shared__ double sh[8];
+  const int l = blockIdx.z;
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double fro = 0.0, ld = 0.0;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t i = i0 + rr, j = j0 + tx;
+    double v = 0.0;
+    if (i < M && j < M && j <= i) {
+      const double x = (double)raw[(int64_t)l * M * M + i * M + j];
+      if (i == j) { v = exp(x); ld += x; } else v = x;
+      fro += v * v;
+    }
+    tile[rr][tx] = v;
+    if (LuOut && i < M && j < M) LuOut[(int64_t)l * M * M + i * M + j] = (T)v;
+    if (LuD && i < Mp && j < Mp) LuD[(int64_t)l * Mp * Mp + i * Mp + j] = v;
+  }
+  __syncthreads();
+  if (LuT)
+    for (int rr = ty; rr < 32; rr += 8) {
+      const int64_t jt = j0 + rr, it = i0 + tx;  // LuT[j][i] = Lu[i][j]
+      if (jt < Mp && it < Mp) LuT[(int64_t)l * Mp * Mp + jt * Mp + it] = (T)tile[tx][rr];
+    }
+  const double f = block_sum(fro, sh);
+  const double g = block_sum(ld, sh);
+  if (threadIdx.x == 0) {
+    const int64_t nb = (int64_t)gridDim.x * gridDim.y, b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    part[((int64_t)l * 2 + 0) * nb + b] = f;
+    part[((int64_t)l * 2 + 1) * nb + b] = g;
+  }
+}
+
+// dst (L,Mp,Mp) T = transpose(src (L,Mp,Mp) f64), plus per-block partial ||src||_F^2.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const double* __restrict__ src, int64_t Mp,
+                                                            T* __restrict__ dst, double* __restrict__ part) {
+  __shared__ double tile[32][33];
+  __shared__ double sh[8];
+  const int l = blockIdx.z;
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double fro = 0.0;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const double v = src[(int64_t)l * Mp * Mp + (i0 + rr) * Mp + j0 + tx];
+    tile[rr][tx] = v;
+    fro += v * v;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8)
+    dst[(int64_t)l * Mp * Mp + (j0 + rr) * Mp + i0 + tx] = (T)tile[tx][rr];
+  const double f = block_sum(fro, sh);
+  if (threadIdx.x == 0) {
+    const int64_t nb = (int64_t)gridDim.x * gridDim.y, b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    part[(int64_t)l * nb + b] = f;
+  }
+}
+
+template <typename T>
+__global__ void cast_kernel(const double* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (T)src[i];
+}
+
+// Cholesky factor out: (L,Mp,Mp) f64 -> (L,M,M) T with zeros above the diagonal; and
+// sum of log diag per latent (one block per latent along y == 0 row).
+template <typename T>
+__global__ __launch_bounds__(256) void chol_out_kernel(const double* __restrict__ Lc, int64_t Mp, int64_t M,
+                                                      T* __restrict__ out, double* __restrict__ logdiag) {
+  __shared__ double sh[8];
+  const int l = blockIdx.y;
+  const double* src = Lc + (int64_t)l * Mp * Mp;
+  if (out) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < M * M; e += (int64_t)gridDim.x * 256) {
+      const int64_t i = e / M, j = e - i * M;
+      out[(int64_t)l * M * M + e] = (j <= i) ? (T)src[i * Mp + j] : (T)0;
+    }
+  }
+  if (blockIdx.x == 0) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < M; i += 256) s += log(src[i * (Mp + 1)]);
+    const double t = block_sum(s, sh);
+    if (threadIdx.x == 0) logdiag[l] = t;
+  }
+}
+
+// muE: whitened -> mu itself; un-whitened -> Linv * mu (fp64 GEMV, one block per 64 rows).
+// Writes the padded GEMM-precision vector and per-block partial ||muE||^2.
+template <typename T>
+__global__ __launch_bounds__(256) void mu_prepare_kernel(const T* __restrict__ mu, int64_t M, int64_t Mp,
+                                                        const double* __restrict__ Linv, T* __restrict__ muE,
+                                                        double* __restrict__ part) {
+  __shared__ double sh[8];
+  __shared__ double rowacc[64];
+  const int l = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  double sq = 0.0;
+  if (!Linv) {
+    if (threadIdx.x < 64) {
+      const int64_t i = r0 + threadIdx.x;
+      const double v = (i < M) ? (double)mu[(int64_t)l * M + i] : 0.0;
+      muE[(int64_t)l * Mp + i] = (T)v;
+      sq = v * v;
+    }
+  } else {
+    // 4 threads per row, each strides over k; Linv is lower triangular: k <= i
+    const int rr = threadIdx.x >> 2, part4 = threadIdx.x & 3;
+    const int64_t i = r0 + rr;
+    double acc = 0.0;
+    const double* Lrow = Linv + (int64_t)l * Mp * Mp + i * Mp;
+    const int64_t kmax = (i < M) ? i : -1;
+    for (int64_t k = part4; k <= kmax; k += 4) acc += Lrow[k] * (double)mu[(int64_t)l * M + k];
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (part4 == 0) rowacc[rr] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const double v = rowacc[threadIdx.x];
+      muE[(int64_t)l * Mp + r0 + threadIdx.x] = (T)v;
+      sq = v * v;
+    }
+  }
+  const double t = block_sum(sq, sh);
+  if (threadIdx.x == 0) part[(int64_t)l * gridDim.x + blockIdx.x] = t;
+}
+
+// q(F) moments and likelihood terms for one chunk of columns.
+template <typename T>
+struct FinalizeArgs {
+  const T* ps1; const T* pm1; const T* ps2;  // [L][mt][nc]
+  const T* sigma;                            // (L,)
+  const T* y;                                // (L,N) or null
+  T* mean; T* scale;                         // (L,N) or null
+  double* part;                              // [L][nfb_total]
+  int64_t N, n0, nc, nfb_total, fb0;
+  int mt, whitened;
+  double clamp_min, noise_sd;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs<T> a) {
+  __shared__ double sh[8];
+  const int l = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = a.n0 + c;
+  double term = 0.0;
+  if (c < a.nc && n < a.N) {
+    T s1 = 0, m1 = 0, s2 = 0;
+    for (int i = 0; i < a.mt; ++i) {
+      const int64_t o = ((int64_t)l * a.mt + i) * a.nc + c;
+      s1 += a.ps1[o]; m1 += a.pm1[o]; s2 += a.ps2[o];
+    }
+    const T sg = a.sigma[l];
+    T var;
+    if (a.whitened) {
+      var = sg * sg - s1;
+      var = (var > (T)0 ? var : (T)0) + s2;          // gp.py:286-288
+    } else {
+      var = sg * sg - s1 + s2;                        // utilities.py:395
+      var = var > (T)a.clamp_min ? var : (T)a.clamp_min;  // gp.py:228 / :378
+    }
+    if (a.mean) a.mean[(int64_t)l * a.N + n] = m1;
+    if (a.scale) a.scale[(int64_t)l * a.N + n] = sqrt(var);
+    if (a.y) {
+      const double s2n = a.noise_sd * a.noise_sd;
+      const double r = (double)a.y[(int64_t)l * a.N + n] - (double)m1;
+      term = -0.5 * log(6.283185307179586476925 * s2n) - (r * r + (double)var) / (2.0 * s2n);
+    }
+  }
+  const double t = block_sum(term, sh);
+  if (threadIdx.x == 0) a.part[(int64_t)l * a.nfb_total + a.fb0 + blockIdx.x] = t;
+}
+
+// Final per-latent sums and the scalar ELBO (single block; fixed summation order).
+struct ReduceArgs {
+  const double* ll_part; int64_t nfb;          // [L][nfb]
+  const double* lu_part; int64_t nlu;          // [L][2][nlu]: frob^2, sum raw diag
+  const double* fro_part; int64_t nfro;        // [L][nfro] (un-whitened: ||Linv Lu||_F^2) or null
+  const double* mu_part; int64_t nmu;          // [L][nmu]
+  const double* chol_logdiag;                  // (L,)
+  double* kl; double* loglik; double* elbo;
+  int L, whitened; int64_t M;
+  int has_y;
+};
+
+__global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
+  __shared__ double sh[8];
+  double total = 0.0;
+  for (int l = 0; l < a.L; ++l) {
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < a.nfb; i += 256) v += a.ll_part[(int64_t)l * a.nfb + i];
+    const double ll = block_sum(v, sh);
+    v = 0.0;
+    for (int64_t i = threadIdx.x; i < a.nlu; i += 256) v += a.lu_part[((int64_t)l * 2) * a.nlu + i];
+    double fro = block_sum(v, sh);
+    v = 0.0;
+    for (int64_t i = threadIdx.x; i < a.nlu; i += 256) v += a.lu_part[((int64_t)l * 2 + 1) * a.nlu + i];
+    const double logdiag_q = block_sum(v, sh);
+    if (a.fro_part) {
+      v = 0.0;
+      for (int64_t i = threadIdx.x; i < a.nfro; i += 256) v += a.fro_part[(int64_t)l * a.nfro + i];
+      fro = block_sum(v, sh);
+    }
+    v = 0.0;
+    for (int64_t i = threadIdx.x; i < a.nmu; i += 256) v += a.mu_part[(int64_t)l * a.nmu + i];
+    const double mu2 = block_sum(v, sh);
+    if (threadIdx.x == 0) {
+      double kl;
+      if (a.whitened) kl = 0.5 * (-2.0 * logdiag_q + fro + mu2 - (double)a.M);          // utilities.py:34
+      else kl = a.chol_logdiag[l] - logdiag_q + 0.5 * (fro + mu2 - (double)a.M);          // MVN||MVN closed form
+      if (a.kl) a.kl[l] = kl;
+      if (a.loglik) a.loglik[l] = ll;
+      total += (a.has_y ? ll : 0.0) - kl;
+    }
+  }
+  if (threadIdx.x == 0 && a.elbo) *a.elbo = total;
+}
+
+struct Plan {
+  int64_t L, N, M, Mp, nblk, nc, nchunks, nfb_chunk, nfb_total, nlu, nmu;
+  bool f32;
+};
+
+static Plan make_plan(const gpz_svgp_problem* p, int64_t chunk) {
+  Plan pl;
+  pl.L = p->k.n_latent; pl.N = p->N; pl.M = p->M; pl.Mp = pad_up(p->M); pl.nblk = pl.Mp / NB;
+  pl.f32 = p->dtype == GPZ_F32;
+  const int64_t esz = pl.f32 ? 4 : 8;
+  if (chunk <= 0) {
+    // auto: Kzx + Wt chunk buffers of ~6 GiB, at least 2048 columns
+    chunk = (int64_t)(6.0 * (1ull << 30) / (2.0 * pl.L * pl.Mp * esz));
+    if (chunk < 2048) chunk = 2048;
+  }
+  chunk = pad_up(chunk > pl.N ? pl.N : chunk);
+  pl.nc = chunk;
+  pl.nchunks = (pl.N + chunk - 1) / chunk;
+  pl.nfb_chunk = (chunk + 255) / 256;
+  pl.nfb_total = pl.nfb_chunk * pl.nchunks;
+  pl.nlu = (pl.Mp / 32) * (pl.Mp / 32);
+  pl.nmu = pl.Mp / 64;
+  return pl;
+}
+
+template <typename T>
+struct Buffers {
+  double *Kzz, *Dinv, *Linv, *Tmp, *LuD, *LuW;
+  T *LinvG, *LuT, *muE, *Kc, *Wc, *ps1, *pm1, *ps2;
+  double *ll_part, *lu_part, *fro_part, *mu_part, *chol_logdiag;
+  size_t bytes;
+};
+
+template <typename T>
+static Buffers<T> carve(const Plan& pl, bool whitened, void* ws) {
+  Buffers<T> b;
+  Carver c(ws);
+  const int64_t mm = pl.L * pl.Mp * pl.Mp;
+  b.Kzz = c.take<double>(mm);
+  b.Dinv = c.take<double>(pl.L * pl.nblk * NB * NB);
+  b.Linv = c.take<double>(mm);
+  b.Tmp = c.take<double>(mm / 2);
+  b.LuD = whitened ? nullptr : c.take<double>(mm);
+  b.LuW = whitened ? nullptr : c.take<double>(mm);
+  b.LinvG = sizeof(T) == 8 ? reinterpret_cast<T*>(b.Linv) : c.take<T>(mm);
+  b.LuT = c.take<T>(mm);
+  b.muE = c.take<T>(pl.L * pl.Mp);
+  b.Kc = c.take<T>(pl.L * pl.Mp * pl.nc);
+  b.Wc = c.take<T>(pl.L * pl.Mp * pl.nc);
+  b.ps1 = c.take<T>(pl.L * pl.nblk * pl.nc);
+  b.pm1 = c.take<T>(pl.L * pl.nblk * pl.nc);
+  b.ps2 = c.take<T>(pl.L * pl.nblk * pl.nc);
+  b.ll_part = c.take<double>(pl.L * pl.nfb_total);
+  b.lu_part = c.take<double>(pl.L * 2 * pl.nlu);
+  b.fro_part = whitened ? nullptr : c.take<double>(pl.L * pl.nlu);
+  b.mu_part = c.take<double>(pl.L * pl.nmu);
+  b.chol_logdiag = c.take<double>(pl.L);
+  b.bytes = c.used();
+  return b;
+}
+
+template <typename T>
+static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes, hipStream_t s) {
+  const Plan pl = make_plan(p, chunk);
+  const bool wh = p->whitened != 0;
+  Buffers<T> b = carve<T>(pl, wh, ws);
+  GPZ_REQUIRE(ws_bytes >= b.bytes, "gpz_svgp_forward: workspace too small (%zu < %zu)", ws_bytes, b.bytes);
+  const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, N = pl.N, mm = Mp * Mp;
+  const int L32 = (int)L;
+
+  // 1. Kzz + jitter I (fp64, identity padded), Cholesky, inverse
+  if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, p->gZ, p->gZ, b.Kzz, Mp, mm, p->jitter, 1,
+                            GPZ_F64, s))
+    return rc;
+  if (int rc = potrf_padded(b.Kzz, Mp, Mp, mm, L, M, b.Dinv, p->info, s)) return rc;
+  hipLaunchKernelGGL((chol_out_kernel<T>), dim3(p->chol ? 64 : 1, L32), dim3(256), 0, s, b.Kzz, Mp, M,
+                     static_cast<T*>(p->chol), b.chol_logdiag);
+  GPZ_LAUNCH_OK();
+  if (int rc = trtri_padded(b.Kzz, Mp, mm, b.Dinv, b.Linv, Mp, L, b.Tmp, s)) return rc;
+  if (sizeof(T) == 4) {
+    hipLaunchKernelGGL((cast_kernel<T>), dim3(2048), dim3(256), 0, s, b.Linv, b.LinvG, L * mm);
+    GPZ_LAUNCH_OK();
+  }
+
+  // 2. q(U) parameters in the form the two products need
+  const dim3 g32((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32);
+  if (wh) {
+    hipLaunchKernelGGL((lu_prepare_kernel<T>), g32, dim3(256), 0, s, static_cast<const T*>(p->Lu_raw), M, Mp, b.LuT,
+                       (double*)nullptr, static_cast<T*>(p->Lu), b.lu_part);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL((mu_prepare_kernel<T>), dim3((unsigned)pl.nmu, L32), dim3(256), 0, s,
+                       static_cast<const T*>(p->mu), M, Mp, (const double*)nullptr, b.muE, b.mu_part);
+    GPZ_LAUNCH_OK();
+  } else {
+    hipLaunchKernelGGL((lu_prepare_kernel<T>), g32, dim3(256), 0, s, static_cast<const T*>(p->Lu_raw), M, Mp,
+                       (T*)nullptr, b.LuD, static_cast<T*>(p->Lu), b.lu_part);
+    GPZ_LAUNCH_OK();
+    GemmParams<double> g;  // LuW = Linv * Lu  (lower x lower -> lower)
+    g.A = b.Linv; g.lda = Mp; g.sA0 = mm;
+    g.B = b.LuD; g.ldb = Mp; g.sB0 = mm;
+    g.C = b.LuW; g.ldc = Mp; g.sC0 = mm;
+    g.nb0 = L32; g.mt = g.nt = (int)pl.nblk; g.K = (int)Mp; g.flags = GF_A_LOWER | GF_B_LOWER | GF_TILES_LOWER;
+    GPZ_HIP_OK(hipMemsetAsync(b.LuW, 0, sizeof(double) * L * mm, s));
+    if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
+    hipLaunchKernelGGL((transpose_cast_kernel<T>), g32, dim3(256), 0, s, b.LuW, Mp, b.LuT, b.fro_part);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL((mu_prepare_kernel<T>), dim3((unsigned)pl.nmu, L32), dim3(256), 0, s,
+                       static_cast<const T*>(p->mu), M, Mp, b.Linv, b.muE, b.mu_part);
+    GPZ_LAUNCH_OK();
+  }
+
+  // 3. chunks of columns
+  const int64_t esz = sizeof(T);
+  for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
+    const int64_t n0 = ci * pl.nc;
+    const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
+    const int64_t ncp = pad_up(nreal);  // columns computed this chunk
+    const int nt = (int)(ncp / NB);
+    prof_begin(PROF_KFILL, s);
+    if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
+                              p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
+                              pl.f32 ? GPZ_F32 : GPZ_F64, s))
+      return rc;
+    prof_end(PROF_KFILL, s);
+    GemmParams<T> g1;  // Wt = Linv * Kzx, with colsum(Wt^2) and muE^T Wt
+    g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
+    g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
+    g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
+    g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
+    g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
+    prof_begin(PROF_STAGE1, s);
+    if (int rc = gemm_launch(g1, EPI_STORE_STATS, s)) return rc;
+    prof_end(PROF_STAGE1, s);
+    GemmParams<T> g2;  // colsum((LuE^T Wt)^2)
+    g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+    g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+    g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+    g2.ps_sq = b.ps2; g2.ncols = ncp;
+    prof_begin(PROF_STAGE2, s);
+    if (int rc = gemm_launch(g2, EPI_STATS, s)) return rc;
+    prof_end(PROF_STAGE2, s);
+    FinalizeArgs<T> f;
+    f.ps1 = b.ps1; f.pm1 = b.pm1; f.ps2 = b.ps2; f.sigma = static_cast<const T*>(p->k.sigma);
+    f.y = static_cast<const T*>(p->y); f.mean = static_cast<T*>(p->mean); f.scale = static_cast<T*>(p->scale);
+    f.part = b.ll_part; f.N = N; f.n0 = n0; f.nc = ncp; f.nfb_total = pl.nfb_total; f.fb0 = ci * pl.nfb_chunk;
+    f.mt = (int)pl.nblk; f.whitened = wh; f.clamp_min = p->var_clamp_min; f.noise_sd = p->noise_sd;
+    prof_begin(PROF_FINAL, s);
+    // blocks beyond this chunk's columns still write a zero partial so the slab is fully defined
+    hipLaunchKernelGGL((finalize_kernel<T>), dim3((unsigned)pl.nfb_chunk, L32), dim3(256), 0, s, f);
+    GPZ_LAUNCH_OK();
+    prof_end(PROF_FINAL, s);
+  }
+
+  // 4. per-latent KL / log-likelihood and the scalar ELBO
+  ReduceArgs r;
+  r.ll_part = b.ll_part; r.nfb = pl.nfb_total; r.lu_part = b.lu_part; r.nlu = pl.nlu;
+  r.fro_part = b.fro_part; r.nfro = pl.nlu; r.mu_part = b.mu_part; r.nmu = pl.nmu;
+  r.chol_logdiag = b.chol_logdiag; r.kl = p->kl; r.loglik = p->loglik; r.elbo = p->elbo;
+  r.L = L32; r.whitened = wh; r.M = M; r.has_y = p->y != nullptr;
+  hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, s, r);
+  GPZ_LAUNCH_OK();
+  return 0;
+}
+
+static int check_problem(const gpz_svgp_problem* p) {
+  GPZ_REQUIRE(p, "gpz_svgp: null problem");
+  GPZ_REQUIRE(p->dtype == GPZ_F32 || p->dtype == GPZ_F64, "gpz_svgp: bad dtype %d", p->dtype);
+  GPZ_REQUIRE(p->k.dtype == p->dtype, "gpz_svgp: kernel dtype %d != problem dtype %d", p->k.dtype, p->dtype);
+  GPZ_REQUIRE(p->k.n_latent >= 1 && p->N >= 1 && p->M >= 1, "gpz_svgp: bad extents L=%d N=%lld M=%lld",
+              p->k.n_latent, (long long)p->N, (long long)p->M);
+  GPZ_REQUIRE(p->X && p->Z && p->mu && p->Lu_raw && p->info, "gpz_svgp: null input pointer");
+  GPZ_REQUIRE(p->d >= 1 && p->d <= 4, "gpz_svgp: input dimension %d unsupported", p->d);
+  if (p->y) GPZ_REQUIRE(p->noise_sd > 0.0, "gpz_svgp: noise_sd must be positive");
+  return 0;
+}
+
+}  // namespace gpz
+
+using namespace gpz;
+
+extern "C" size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk) {
+  if (check_problem(p)) return 0;
+  const Plan pl = make_plan(p, chunk);
+  return p->dtype == GPZ_F32 ? carve<float>(pl, p->whitened != 0, nullptr).bytes
+                             : carve<double>(pl, p->whitened != 0, nullptr).bytes;
+}
+
+extern "C" int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  GPZ_REQUIRE(ws, "gpz_svgp_forward: null workspace");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return p->dtype == GPZ_F32 ? svgp_forward_t<float>(p, chunk, ws, ws_bytes, s)
+                             : svgp_forward_t<double>(p, chunk, ws, ws_bytes, s);
+}

@@ -1,0 +1,230 @@
+"""Tensor-level entry points: torch CUDA tensors in, HIP kernels underneath.
+
+PyTorch is used for storage, streams and (in ``parallel.py``) torch.distributed
+only; every numeric step of the hot path runs in libgpzoo_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GPZ_F32, GPZ_F64, KernelDesc, SvgpProblem
+
+
+@dataclass
+class KernelSpec:
+    """Flattened hyper-parameters of one gpzoo kernel object (see kernels.py)."""
+    kind: int
+    sigma: torch.Tensor            # (L,)
+    lengthscale: torch.Tensor      # (L,)
+    batched: bool                  # False: scalar parameters -> results drop the latent axis
+    group_a: Optional[torch.Tensor] = None   # (L,) effective multiplier of r^2_group
+    group_r2: Optional[torch.Tensor] = None  # (G,G)
+    group_pow: float = 1.0
+
+    @property
+    def L(self) -> int:
+        return int(self.sigma.numel())
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return GPZ_F32
+    if t.dtype == torch.float64:
+        return GPZ_F64
+    raise TypeError(f"gpzoo_amd supports float32/float64 tensors, got {t.dtype}")
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gpzoo_amd computes on the GPU only (HIP kernels, no CPU fallback): "
+                               "move the model and inputs to a cuda device")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_workspaces: dict = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        _workspaces.pop(device, None)
+        ws = None
+        ws = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+def _desc(spec: KernelSpec, dtype: torch.dtype, keep: list) -> KernelDesc:
+    def prep(t):
+        if t is None:
+            return None
+        t = t.detach().to(dtype).contiguous()
+        keep.append(t)
+        return t
+    sig, ell = prep(spec.sigma.reshape(-1)), prep(spec.lengthscale.reshape(-1))
+    ga, gr2 = prep(spec.group_a), prep(spec.group_r2)
+    d = KernelDesc()
+    d.kind, d.n_latent, d.dtype = spec.kind, spec.L, _dt(sig)
+    d.n_groups = 0 if gr2 is None else int(gr2.shape[0])
+    d.sigma, d.lengthscale = sig.data_ptr(), ell.data_ptr()
+    d.group_a = None if ga is None else ga.data_ptr()
+    d.group_r2 = None if gr2 is None else gr2.data_ptr()
+    d.group_pow = float(spec.group_pow)
+    return d
+
+
+def kfill(spec: KernelSpec, A: torch.Tensor, B: torch.Tensor, gA=None, gB=None, jitter: float = 0.0,
+          out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """K[l,i,j] = k_l(A_i, B_j): (L,nA,nB), or (nA,nB) for scalar-parameter kernels."""
+    _need_cuda(A, B, spec.sigma)
+    lib = _lib.load()
+    keep: list = []
+    A = A.detach().contiguous()
+    B = B.detach().to(A.dtype).contiguous()
+    if A.dim() != 2 or B.dim() != 2 or A.shape[1] != B.shape[1]:
+        raise ValueError(f"expected (n,d) inputs with equal d, got {tuple(A.shape)} and {tuple(B.shape)}")
+    d = _desc(spec, A.dtype, keep)
+    if spec.kind == _lib.KERNEL_MGGP_RBF:
+        gA = gA.detach().to(device=A.device, dtype=torch.int64).contiguous()
+        gB = gB.detach().to(device=A.device, dtype=torch.int64).contiguous()
+    else:
+        gA = gB = None
+    odt = A.dtype if out_dtype is None else out_dtype
+    nA, nB = A.shape[0], B.shape[0]
+    K = torch.empty((spec.L, nA, nB), dtype=odt, device=A.device)
+    rc = lib.gpz_kfill(C.byref(d), _ptr(A), nA, _ptr(B), nB, A.shape[1], _ptr(gA), _ptr(gB), _ptr(K), nB,
+                       nA * nB, float(jitter), _dt(K), _stream())
+    _lib.check(rc, "gpz_kfill")
+    return K if spec.batched else K[0]
+
+
+def _raise_not_pd(info: torch.Tensor, what: str):
+    bad = torch.nonzero(info)
+    b = int(bad[0, 0])
+    k = int(info[b])
+    prefix = f"(Batch element {b}): " if info.numel() > 1 else ""
+    raise torch.linalg.LinAlgError(
+        f"{what}: {prefix}The factorization could not be completed because the input is not "
+        f"positive-definite (the leading minor of order {k} is not positive-definite).")
+
+
+def cholesky(A: torch.Tensor) -> torch.Tensor:
+    """Lower Cholesky factor of (M,M) or (L,M,M); raises torch.linalg.LinAlgError
+    when a matrix is not positive-definite (what gp.py:213/270/360 callers see)."""
+    _need_cuda(A)
+    lib = _lib.load()
+    dt = A.dtype
+    M = A.shape[-1]
+    W = A.detach().to(torch.float64).reshape(-1, M, M).contiguous().clone()
+    batch = W.shape[0]
+    info = torch.empty(batch, dtype=torch.int32, device=A.device)
+    nbytes = lib.gpz_potrf_workspace_bytes(M, batch)
+    ws = _workspace(A.device, nbytes)
+    rc = lib.gpz_potrf_batched(_ptr(W), M, M, M * M, batch, _ptr(info), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "gpz_potrf_batched")
+    if bool(info.any()):
+        _raise_not_pd(info, "linalg.cholesky")
+    return W.to(dt).reshape(A.shape)
+
+
+def solve_triangular_lower(Lc: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """Lc^{-1} B for lower-triangular (.., M, M) and (.., M, N)."""
+    _need_cuda(Lc, B)
+    lib = _lib.load()
+    dt = B.dtype
+    M, N = B.shape[-2], B.shape[-1]
+    Lw = Lc.detach().to(torch.float64).reshape(-1, M, M).contiguous()
+    Bw = B.detach().to(torch.float64).reshape(-1, M, N).contiguous().clone()
+    batch = Bw.shape[0]
+    nbytes = lib.gpz_trsm_workspace_bytes(M, N, batch)
+    ws = _workspace(B.device, nbytes)
+    rc = lib.gpz_trsm_lln_batched(_ptr(Lw), M, M * M, _ptr(Bw), N, M * N, M, N, batch, _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "gpz_trsm_lln_batched")
+    return Bw.to(dt).reshape(B.shape)
+
+
+def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, *, gX=None, gZ=None,
+                 y=None, noise_sd: Optional[float] = None, clamp_min: float = 1e-6, chunk: int = 0,
+                 want_moments: bool = True, want_Lu: bool = True, want_chol: bool = False,
+                 check_info: bool = True) -> dict:
+    """One fused forward pass (gpz_svgp_forward).  Returns a dict with mean, scale
+    (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars."""
+    _need_cuda(X, Z, mu, Lu_raw)
+    lib = _lib.load()
+    dt = X.dtype
+    keep: list = []
+    X = X.detach().contiguous()
+    Z = Z.detach().to(dt).contiguous()
+    L = spec.L
+    M, N, dim = Z.shape[0], X.shape[0], X.shape[1]
+    mu = mu.detach().to(dt).reshape(L, M).contiguous()
+    Lu_raw = Lu_raw.detach().to(dt).reshape(L, M, M).contiguous()
+    dev = X.device
+    p = SvgpProblem()
+    p.k = _desc(spec, dt, keep)
+    p.dtype, p.whitened, p.d = _dt(X), int(whitened), dim
+    p.N, p.M = N, M
+    p.X, p.Z, p.mu, p.Lu_raw = X.data_ptr(), Z.data_ptr(), mu.data_ptr(), Lu_raw.data_ptr()
+    if spec.kind == _lib.KERNEL_MGGP_RBF:
+        gX = gX.detach().to(device=dev, dtype=torch.int64).contiguous()
+        gZ = gZ.detach().to(device=dev, dtype=torch.int64).contiguous()
+        p.gX, p.gZ = gX.data_ptr(), gZ.data_ptr()
+    p.jitter, p.var_clamp_min = float(jitter), float(clamp_min)
+    out = {}
+    if y is not None:
+        y = y.detach().to(dt).reshape(L, N).contiguous()
+        p.y, p.noise_sd = y.data_ptr(), float(noise_sd)
+    if want_moments:
+        out["mean"] = torch.empty((L, N), dtype=dt, device=dev)
+        out["scale"] = torch.empty((L, N), dtype=dt, device=dev)
+        p.mean, p.scale = out["mean"].data_ptr(), out["scale"].data_ptr()
+    if want_Lu:
+        out["Lu"] = torch.empty((L, M, M), dtype=dt, device=dev)
+        p.Lu = out["Lu"].data_ptr()
+    if want_chol:
+        out["chol"] = torch.empty((L, M, M), dtype=dt, device=dev)
+        p.chol = out["chol"].data_ptr()
+    scal = torch.zeros(2 * L + 1, dtype=torch.float64, device=dev)
+    info = torch.empty(L, dtype=torch.int32, device=dev)
+    p.kl, p.loglik, p.elbo = scal.data_ptr(), scal.data_ptr() + 8 * L, scal.data_ptr() + 16 * L
+    p.info = info.data_ptr()
+    nbytes = lib.gpz_svgp_workspace_bytes(C.byref(p), int(chunk))
+    if nbytes == 0:
+        _lib.check(-1, "gpz_svgp_workspace_bytes")
+    ws = _workspace(dev, nbytes)
+    rc = lib.gpz_svgp_forward(C.byref(p), int(chunk), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "gpz_svgp_forward")
+    if check_info and bool(info.any()):
+        _raise_not_pd(info, "linalg.cholesky")
+    out["kl"], out["loglik"], out["elbo"] = scal[:L], scal[L:2 * L], scal[2 * L]
+    out["info"] = info
+    return out
+
+
+def profile_enable(on: bool = True):
+    _lib.check(_lib.load().gpz_profile_enable(int(on)), "gpz_profile_enable")
+
+
+def profile_read() -> dict:
+    n = len(_lib.PROF_SLOTS)
+    ms = (C.c_double * n)()
+    cnt = (C.c_int32 * n)()
+    _lib.check(_lib.load().gpz_profile_read(ms, cnt, n), "gpz_profile_read")
+    return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.PROF_SLOTS) if not name.startswith("_")}

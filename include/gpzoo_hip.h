@@ -1,0 +1,141 @@
+/* gpzoo_hip.h -- C ABI of libgpzoo_hip.so (MI355X / gfx950).
+ *
+ * The reference (luisdiaz1997/GPzoo) is pure Python/torch and has no FFI of its
+ * own; this ABI is what a maintainer binds (ctypes stub in INTEGRATION.md) to
+ * replace the torch ops on the SVGP/NSF hot path.  Each entry point cites the
+ * reference lines whose arithmetic it replaces (paths under /root/reference).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the
+ *    caller unless marked "host"; the library never allocates user-visible
+ *    memory; scratch comes from a caller workspace sized by *_workspace_bytes.
+ *  - all launches are asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - return 0 on success, negative on bad arguments / launch errors
+ *    (gpz_last_error() holds the message, per thread).
+ *  - dtype: GPZ_F32 = 0, GPZ_F64 = 1.  Matrices are row-major, batched over a
+ *    leading latent axis L with an explicit batch stride (in elements).
+ *  - non-PD input to a factorisation: LAPACK-style info[b] = k > 0 written to
+ *    device memory (order of the first non-positive leading minor); the Python
+ *    wrapper turns it into torch.linalg.LinAlgError like gp.py:213/270/360.
+ */
+#ifndef GPZOO_HIP_H
+#define GPZOO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPZ_VERSION 100
+
+enum { GPZ_F32 = 0, GPZ_F64 = 1 };
+
+/* covariance families: every kernel class of gpzoo/kernels.py maps to one */
+enum {
+  GPZ_KERNEL_RBF = 0,      /* RBF, NSF_RBF, batched_RBF      kernels.py:34-59,106-155  */
+  GPZ_KERNEL_MATERN32 = 1, /* batched_Matern32               kernels.py:6-30           */
+  GPZ_KERNEL_MGGP_RBF = 2  /* MGGP_RBF, MGGP_NSF_RBF, batched_MGGP_RBF  kernels.py:62-104,158-228 */
+};
+
+/* Hyper-parameters of one covariance family for L independent latents.
+ * sigma / lengthscale / group_a: device arrays of L values of dtype `dtype`.
+ * group_a is the EFFECTIVE multiplier of the squared group distance
+ * (a, a^2 or |a| depending on the class: kernels.py:187 / :222 / :87), NULL
+ * unless kind == GPZ_KERNEL_MGGP_RBF.  group_r2 is the (G,G) table of squared
+ * distances between group embeddings (dtype `dtype`); group_pow = p/2, the
+ * exponent of the denominator (kernels.py:189, :224, :89). */
+typedef struct gpz_kernel_desc {
+  int32_t kind;
+  int32_t n_latent;
+  int32_t dtype;
+  int32_t n_groups;
+  const void* sigma;
+  const void* lengthscale;
+  const void* group_a;
+  const void* group_r2;
+  double group_pow;
+} gpz_kernel_desc;
+
+int gpz_version(void);
+const char* gpz_last_error(void);
+
+/* K[l][i][j] = k_l(A_i, B_j) (+ jitter where i == j if jitter != 0).
+ * Replaces kernel.forward(X, Z) -- kernels.py:29-30, 57-58, 98-104, 118-130,
+ * 146-155, 176-191, 211-228 -- and add_jitter (utilities.py:407-418) fused.
+ * A (nA,d), B (nB,d) of k->dtype; gA/gB int64 group ids (MGGP only, else NULL).
+ * K has dtype out_dtype, row stride ldk, latent stride stride_k (elements).
+ * Distances are evaluated by direct differencing in the output precision. */
+int gpz_kfill(const gpz_kernel_desc* k, const void* A, int64_t nA, const void* B, int64_t nB,
+              int32_t d, const int64_t* gA, const int64_t* gB, void* K, int64_t ldk,
+              int64_t stride_k, double jitter, int32_t out_dtype, void* stream);
+
+/* In-place lower Cholesky of `batch` (M,M) matrices (fp64), zeros written above
+ * the diagonal; info[b] as described above.  Replaces torch.linalg.cholesky at
+ * gp.py:213, 270, 360.  Blocked right-looking: LDS-resident diagonal panel,
+ * MFMA (v_mfma_f64_16x16x4_f64) panel solve and trailing SYRK/GEMM update. */
+size_t gpz_potrf_workspace_bytes(int64_t M, int64_t batch);
+int gpz_potrf_batched(double* A, int64_t M, int64_t lda, int64_t stride_a, int64_t batch,
+                      int32_t* info, void* ws, size_t ws_bytes, void* stream);
+
+/* X = Lc^{-1} B for `batch` lower-triangular (M,M) factors and (M,N) right-hand
+ * sides (fp64), X written over B.  Replaces torch.linalg.solve_triangular at
+ * gp.py:276 (and each half of cholesky_solve at gp.py:218, 365). */
+size_t gpz_trsm_workspace_bytes(int64_t M, int64_t N, int64_t batch);
+int gpz_trsm_lln_batched(const double* Lc, int64_t ldl, int64_t stride_l, double* B, int64_t ldb,
+                         int64_t stride_b, int64_t M, int64_t N, int64_t batch, void* ws,
+                         size_t ws_bytes, void* stream);
+
+/* One evaluation of the SVGP / WSVGP forward pass and (optionally) the
+ * closed-form Gaussian ELBO, batched over L latents and tiled over N:
+ *   Kzz(+jitter) -> Cholesky -> L^{-1} -> per N-chunk { Kzx fill, Wt = L^{-1} Kzx,
+ *   Lu^T Wt, column reductions } -> q(F) mean / scale, KL per latent, ELBO.
+ * Replaces WSVGP.forward gp.py:260-306, SVGP.forward gp.py:183-232 (+
+ * svgp_forward utilities.py:382-397), MGGP_* gp.py:341-399, whitened_KL
+ * utilities.py:27-36, kl_divergence(qU,pU) at utilities.py:481, and the ELBO
+ * assembly of mggp_test_exact.ipynb:157-159.
+ * dtype = storage/GEMM type of X, Z, mu, Lu_raw, y, mean, scale (k.dtype must
+ * match).  Kzz, its Cholesky factor and inverse are carried in fp64 in both modes.
+ */
+typedef struct gpz_svgp_problem {
+  gpz_kernel_desc k;
+  int32_t dtype;
+  int32_t whitened;      /* 1: WSVGP (gp.py:260), 0: SVGP (gp.py:183) */
+  int32_t d;             /* input dimension */
+  int32_t reserved;
+  int64_t N, M;
+  const void* X;         /* (N,d) */
+  const void* Z;         /* (M,d) */
+  const int64_t* gX;     /* (N,) MGGP only */
+  const int64_t* gZ;     /* (M,) MGGP only */
+  const void* mu;        /* (L,M) */
+  const void* Lu_raw;    /* (L,M,M) unconstrained: diag is exponentiated */
+  double jitter;
+  double var_clamp_min;  /* un-whitened only: clamp(cov, min) gp.py:228 (1e-6) / :378 (5e-2) */
+  const void* y;         /* (L,N) targets or NULL: no likelihood terms */
+  double noise_sd;       /* softplus(noise) of likelihoods.py:33 */
+  /* outputs (any may be NULL) */
+  void* mean;            /* (L,N) dtype */
+  void* scale;           /* (L,N) dtype: sqrt of the predictive variance */
+  void* Lu;              /* (L,M,M) dtype: constrained scale_tril of q(U) */
+  void* chol;            /* (L,M,M) dtype: Cholesky factor of Kzz + jitter I */
+  double* kl;            /* (L,) */
+  double* loglik;        /* (L,) sum_n log N(y; mean, s^2) - var / (2 s^2) */
+  double* elbo;          /* (1,) sum_l loglik - kl */
+  int32_t* info;         /* (L,) potrf info */
+} gpz_svgp_problem;
+
+size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
+int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* Timing hooks used by bench.py: HIP events recorded on `stream` around the
+ * dominant kernels of the last gpz_svgp_forward call (roofline.achieved). */
+int gpz_profile_enable(int32_t on);
+int gpz_profile_read(double* ms_out, int32_t* counts_out, int32_t n_slots); /* host arrays */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPZOO_HIP_H */

@@ -36,3 +36,26 @@ def oracle_kwargs(c):
 def rtol_for(dtype):
     """north_star tolerances: 1e-5 rtol fp64, 1e-3 rtol fp32."""
     return 1e-5 if dtype == torch.float64 else 1e-3
+
+
+def spec_from_case(c, device):
+    """KernelSpec for a golden case (mirrors what gpzoo_amd.kernels classes build)."""
+    from gpzoo_amd import _lib
+    from gpzoo_amd.ops import KernelSpec
+    kind = c["kind"]
+    sig, ell = c["sigma"].to(device), c["lengthscale"].to(device)
+    batched = sig.dim() > 0
+    if kind in ("rbf", "nsf_rbf", "batched_rbf"):
+        return KernelSpec(_lib.KERNEL_RBF, sig.reshape(-1), ell.reshape(-1), batched)
+    if kind == "matern32":
+        return KernelSpec(_lib.KERNEL_MATERN32, sig.reshape(-1), ell.reshape(-1), batched)
+    emb = c["embedding"].to(device)
+    r2 = ((emb[:, None, :] - emb[None, :, :]) ** 2).sum(-1)
+    a = c["group_diff"].to(device).reshape(-1)
+    if kind == "mggp_rbf":
+        ga, pw = a, c.get("input_dim", 2) / 2
+    elif kind == "mggp_nsf_rbf":
+        ga, pw = a ** 2, c.get("input_dim", 2) / 2
+    else:
+        ga, pw = a.abs(), c["X"].shape[1] / 2
+    return KernelSpec(_lib.KERNEL_MGGP_RBF, sig.reshape(-1), ell.reshape(-1), batched, ga, r2, pw)

@@ -1,0 +1,44 @@
+"""GPU: batched Cholesky / triangular solve against torch fp64 on the same inputs,
+at sizes that exercise several panels, ragged (non multiple of 128) orders and the
+non-positive-definite error path."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def spd(batch, M, seed, jitter=0.5):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(batch, M, M + 8, generator=g, dtype=torch.float64)
+    return A @ A.transpose(-1, -2) / M + jitter * torch.eye(M, dtype=torch.float64)
+
+
+@pytest.mark.parametrize("M,batch", [(1, 2), (36, 3), (128, 2), (200, 2), (384, 3), (700, 2), (1024, 1)])
+def test_cholesky_matches_lapack(M, batch):
+    from gpzoo_amd import ops
+    A = spd(batch, M, 7 + M)
+    ref = torch.linalg.cholesky(A)
+    got = ops.cholesky(A.cuda()).cpu()
+    torch.testing.assert_close(got, ref, rtol=1e-9, atol=1e-11)
+    assert torch.equal(got.triu(1), torch.zeros_like(got))  # zeros above the diagonal
+
+
+@pytest.mark.parametrize("M,N,batch", [(36, 50, 2), (256, 130, 2), (640, 300, 1)])
+def test_trsm_matches_lapack(M, N, batch):
+    from gpzoo_amd import ops
+    Lc = torch.linalg.cholesky(spd(batch, M, 11 + M))
+    B = torch.randn(batch, M, N, generator=torch.Generator().manual_seed(M + N), dtype=torch.float64)
+    ref = torch.linalg.solve_triangular(Lc, B, upper=False)
+    got = ops.solve_triangular_lower(Lc.cuda(), B.cuda()).cpu()
+    torch.testing.assert_close(got, ref, rtol=1e-8, atol=1e-10)
+
+
+def test_not_positive_definite_raises():
+    """gp.py:213/270/360 callers see torch.linalg.LinAlgError with the failing minor."""
+    from gpzoo_amd import ops
+    A = spd(3, 200, 5)
+    A[1, 150, 150] = -1.0  # leading minor of order 151 fails in batch element 1
+    with pytest.raises(torch.linalg.LinAlgError, match=r"Batch element 1.*minor of order 151"):
+        ops.cholesky(A.cuda())
+    with pytest.raises(torch.linalg.LinAlgError):
+        torch.linalg.cholesky(A)
