@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""ELBO-evaluation benchmark of the SVGP/WSVGP hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one closed-form Gaussian ELBO evaluation on the
+Slide-seq-shaped synthetic workload of BASELINE.json configs[2]: N=200k spots,
+M=2048 inducing points, L=32 latent GPs per GPU, Matern-3/2, fp32.  With N GPUs
+each rank owns 32 latents of a 32*N-latent model (configs[3] at N=8): weak
+scaling, no data-path collective, one RCCL all-reduce of the fp64 ELBO scalar.
+`value` counts L=32-latent ELBO evaluations per second over all ranks, inputs
+resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {"f32": 157.3, "f64": 78.6}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md; f64 = datasheet)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based): 2, 3 or 5")
+    ap.add_argument("--N", type=int, default=None)
+    ap.add_argument("--M", type=int, default=None)
+    ap.add_argument("--L", type=int, default=None, help="latents per GPU")
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="spots in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_id: int, c: dict, sample: int) -> dict:
+    """Time the CPU oracle (a torch-CPU port of the reference's op sequence) on a
+    bounded sample: all latents and inducing points, the first `sample` spots --
+    the reference's own minibatch usage (utilities.py:605-609)."""
+    from oracle import svgp_oracle as O
+    n = min(sample, c["X"].shape[0])
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    kw = {}
+    if "gX" in c:
+        kw = dict(gX=c["gX"][:n], gZ=c["gZ"], embedding=O.embed_group_distances(
+            torch.ones(c["n_groups"], c["n_groups"]) - torch.eye(c["n_groups"])).to(c["X"].dtype),
+            group_diff=c["group_diff"])
+    t0 = time.perf_counter()
+    Kzz = O.kernel_matrix(c["kind"], c["Z"], c["Z"], c["sigma"], c["lengthscale"], gA=kw.get("gZ"), gB=kw.get("gZ"),
+                          embedding=kw.get("embedding"), group_diff=kw.get("group_diff")).contiguous()
+    O.add_jitter_(Kzz, c["jitter"])
+    torch.linalg.cholesky(Kzz)
+    t_chol = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    e, _, _ = O.elbo_eval(c["kind"], c["whitened"], c["X"][:n], c["y"][..., :n], c["Z"], c["sigma"], c["lengthscale"],
+                          c["mu"], c["Lu_raw"], c["jitter"], c["noise_sd"], **kw)
+    t_eval = time.perf_counter() - t0
+    N = c["X"].shape[0]
+    t_chunk = max(t_eval - t_chol, 1e-9)
+    full = t_chol + math.ceil(N / n) * t_chunk
+    return {"value": 1.0 / full, "unit": "ELBO evals/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/svgp_oracle.py (torch CPU, {threads} threads) on the first {n} of {N} spots, all "
+                      f"{c['mu'].shape[0] if c['mu'].dim() > 1 else 1} latents, M={c['Z'].shape[0]}: {t_eval:.2f} s per "
+                      f"chunk-eval incl. {t_chol:.2f} s Kzz+Cholesky; extrapolated to full N as "
+                      f"1/(t_chol + ceil(N/n) * t_chunk)",
+            "sample_elbo": float(e)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gpzoo_amd import ops
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import CONFIGS, make_config
+
+    cfg_id = a.config
+    Lper = a.L if a.L is not None else CONFIGS[cfg_id]["L"]
+    Ltot = Lper * world
+    lat = range(rank * Lper, (rank + 1) * Lper)
+    c = make_config(4 if (cfg_id == 3 and world > 1) else cfg_id, N=a.N, M=a.M, L=Ltot, latents=lat)
+    dt = c["dtype"]
+    dname = "f32" if dt == torch.float32 else "f64"
+    g = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
+    spec, extra = spec_for_config(g, dev)
+    N, M = c["X"].shape[0], c["Z"].shape[0]
+
+    def step():
+        out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
+                               y=g["y"], noise_sd=c["noise_sd"], chunk=a.chunk, want_Lu=False, **extra)
+        e = out["elbo"].clone()
+        if world > 1:
+            dist.all_reduce(e)
+        return e
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        elbo = step()
+    fence()
+    dt_s = time.perf_counter() - t0
+    prof = ops.profile_read()
+    ops.profile_enable(False)
+    tmax = torch.tensor([dt_s], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    t = float(tmax)
+    elbo = float(elbo)
+
+    if rank == 0:
+        Mp = (M + 127) // 128 * 128
+        ms1, n1 = prof["stage1"]
+        ms2, n2 = prof["stage2"]
+        # dominant kernel: Wt = Linv * Kzx (gemm128_kernel<T,false,EPI_STORE_STATS>), one launch per N-chunk.
+        # algorithmic flops = L * M^2 * N per evaluation (SURVEY §8d TRSM count), spread over its launches.
+        flops1 = Lper * float(M) * M * N * a.steps
+        ach1 = flops1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx)" % dname,
+                "achieved": ach1, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach1 / PEAK[dname],
+                "traffic": None, "launches": n1, "avg_launch_ms": ms1 / max(n1, 1)}
+        kms, kn = prof["kfill"]
+        esz = 4 if dname == "f32" else 8
+        kbytes = (Lper * float(Mp) * N * esz) * a.steps
+        sub = {
+            "kuf_fill": {"bound": "hbm", "achieved_GBps": kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0, "peak_GBps": 8000.0,
+                         "ms_per_eval": kms / a.steps},
+            "stage2_LuT_Wt": {"bound": "mfma", "achieved_TFLOPs": flops1 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0,
+                              "peak_TFLOPs": PEAK[dname], "ms_per_eval": ms2 / a.steps},
+            "stage1_ms_per_eval": ms1 / a.steps,
+            "potrf_ms_per_eval": prof["potrf_all"][0] / a.steps,
+            "potrf_trailing": {"bound": "mfma", "dtype": "f64",
+                               "achieved_TFLOPs": (Lper * float(Mp) ** 3 / 3.0) * a.steps / (prof["potrf_trailing"][0] * 1e-3) / 1e12
+                               if prof["potrf_trailing"][0] > 0 else 0.0, "peak_TFLOPs": PEAK["f64"],
+                               "ms_per_eval": prof["potrf_trailing"][0] / a.steps},
+            "trtri_ms_per_eval": prof["trtri"][0] / a.steps,
+            "finalize_ms_per_eval": prof["finalize"][0] / a.steps,
+        }
+        res = {
+            "metric": "ELBO evals/sec (L=32-latent evaluations, all GPUs) at M=%d inducing, N=%d, L=%d per GPU" % (M, N, Lper),
+            "value": a.steps * world / t, "unit": "ELBO evals/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dname, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: %s, N=%d spots, M=%d, L=%d latents/GPU x %d GPU(s), %s, %s"
+                                   % (cfg_id - 1, "Slide-seq-shaped synthetic" if cfg_id >= 3 else "2-D synthetic spatial",
+                                      N, M, Lper, world, c["kind"], dname),
+                       "whitened": bool(c["whitened"]), "chunk": a.chunk, "factor_dtype": "f64"},
+            "elbo": elbo, "roofline": roof, "kernels": sub,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(cfg_id, c, a.cpu_sample)
+        elif not a.no_cpu_baseline:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

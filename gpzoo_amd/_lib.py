@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgpzoo_hip.so")
 
 GPZ_F32, GPZ_F64 = 0, 1
-KERNEL_RBF, KERNEL_MATERN32, KERNEL_MGGP_RBF = 0, 1, 2
+KERNEL_RBF, KERNEL_MATERN32, KERNEL_MGGP_RBF, KERNEL_DISTANCE = 0, 1, 2, 3
 PROF_SLOTS = ("kfill", "stage1", "stage2", "potrf_trailing", "potrf_all", "trtri", "finalize", "_unused")
 
 

@@ -41,7 +41,7 @@ __device__ __forceinline__ double fast_exp(double x) { return exp(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
 
-// KIND: 0 RBF, 1 Matern-3/2, 2 MGGP RBF.  VECST: aligned 16-byte stores allowed.
+// KIND: 0 RBF, 1 Matern-3/2, 2 MGGP RBF, 3 plain distance.  VECST: aligned 16-byte stores allowed.
 template <typename Tin, typename To, int KIND, bool VECST>
 __global__ __launch_bounds__(KF_TX* KF_TY) void kfill_kernel(KfillArgs a) {
   constexpr int VEC = VecOf<To>::N;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(KF_TX* KF_TY) void kfill_kernel(KfillArgs a) {
     for (int v = 0; v < VEC; ++v) {
       To acc = 0;
       for (int k = 0; k < d; ++k) { const To df = ax[k] - bx[v][k]; acc = fma(df, df, acc); }
-      d2[v] = (KIND == 1) ? fast_sqrt(acc) : acc;
+      d2[v] = (KIND == 1 || KIND == 3) ? fast_sqrt(acc) : acc;
     }
     To* Krow = static_cast<To*>(a.K) + i * a.ldk + j0;
     for (int l = 0; l < L; ++l) {
@@ -121,6 +121,8 @@ __global__ __launch_bounds__(KF_TX* KF_TY) void kfill_kernel(KfillArgs a) {
         } else if (KIND == 1) {
           const To t = cf * d2[v];
           val = amp * ((To)1 + t) * fast_exp(-t);
+        } else if (KIND == 3) {
+          val = d2[v];
         } else {
           const int t = 2 * ((l * G + gai) * G + gb[v]);
           val = s_tab[t + 1] * fast_exp(s_tab[t] * d2[v]);
@@ -173,6 +175,7 @@ static int launch_kfill(const gpz_kernel_desc* k, KfillArgs a, hipStream_t s) {
     switch (k->kind) {
       case GPZ_KERNEL_RBF: GPZ_KF(0); break;
       case GPZ_KERNEL_MATERN32: GPZ_KF(1); break;
+      case GPZ_KERNEL_DISTANCE: GPZ_KF(3); break;
       default: GPZ_KF(2); break;
     }
 #undef GPZ_KF
@@ -187,7 +190,7 @@ int kfill_padded(const gpz_kernel_desc* k, const void* A, int64_t nA, int64_t pA
                  double jitter, int pad_identity, int out_dtype, hipStream_t s) {
   GPZ_REQUIRE(k && A && B && K, "gpz_kfill: null pointer");
   GPZ_REQUIRE(d >= 1 && d <= 4, "gpz_kfill: input dimension %d unsupported (1..4)", d);
-  GPZ_REQUIRE(k->kind >= 0 && k->kind <= 2, "gpz_kfill: unknown kernel kind %d", k->kind);
+  GPZ_REQUIRE(k->kind >= 0 && k->kind <= 3, "gpz_kfill: unknown kernel kind %d", k->kind);
   GPZ_REQUIRE(k->n_latent >= 1, "gpz_kfill: n_latent must be >= 1");
   GPZ_REQUIRE(k->dtype == GPZ_F32 || k->dtype == GPZ_F64, "gpz_kfill: bad dtype");
   GPZ_REQUIRE(!(k->dtype == GPZ_F64 && out_dtype == GPZ_F32), "gpz_kfill: fp64 inputs need fp64 output");

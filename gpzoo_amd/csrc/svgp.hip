@@ -29,7 +29,6 @@ int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* 
                  int64_t batch, double* T, hipStream_t s);
 
 constexpr int NB = 128;
-constexpr int RED_BLOCKS = 64;  // per-latent partial slots of the M x M reductions
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
   // fixed-shape tree: lanes -> waves -> block (deterministic)

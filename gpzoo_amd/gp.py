@@ -1,0 +1,148 @@
+"""Sparse variational GP modules with the gpzoo.gp class API on the HIP hot path.
+
+``SVGP`` / ``WSVGP`` / ``MGGP_SVGP`` / ``MGGP_WSVGP`` keep the reference's
+constructor signatures, attribute names (``kernel, jitter, Z, Lu, mu, groupsZ,
+constraint`` -- the state_dict keys) and return contract
+``(qF: Normal, qU: MultivariateNormal, pU: MultivariateNormal | None)``; shapes
+of ``mu`` / ``Lu`` / ``Z`` are read at call time because notebooks replace those
+parameters after construction.  ``forward`` is ONE call into
+``gpz_svgp_forward`` (csrc/svgp.hip): covariance fill, Cholesky, the triangular
+solves and the q(F) reductions never round-trip through torch ops, and neither
+Kzx nor W is materialised for more than one N-chunk.
+
+Forward only (SURVEY.md §8f "next" #1): returned tensors carry no autograd graph.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch import distributions
+from torch.distributions import constraints
+
+from . import ops
+from .kernels import kernel_spec
+
+
+class _FusedGP(nn.Module):
+    _whitened = True
+    _clamp_min = 1e-6
+    _mggp = False
+
+    def _init_common(self, kernel, dim, M, jitter):
+        self.kernel = kernel
+        self.jitter = jitter
+        self.Z = nn.Parameter(torch.randn((M, dim)))
+        self.Lu = nn.Parameter(torch.randn((M, M)))
+        self.mu = nn.Parameter(torch.zeros((M,)))
+        self.constraint = constraints.lower_cholesky
+
+    # -- the reference's small helpers ------------------------------------
+    def kernel_forward(self, X, Z, **args):
+        return self.kernel(X, Z, **args)
+
+    def forward_kernels(self, X, **args):
+        """(Kxx diag, Kzx, Kzz) as separate matrices -- API parity with gp.py:252-258 /
+        :392-399; ``forward`` itself never materialises them."""
+        if self._mggp:
+            gX = args['groupsX']
+            return (self.kernel(X, X, gX, gX, diag=True), self.kernel(self.Z, X, self.groupsZ, gX),
+                    self.kernel(self.Z, self.Z, self.groupsZ, self.groupsZ).contiguous())
+        return (self.kernel(X, X, diag=True), self.kernel(self.Z, X), self.kernel(self.Z, self.Z).contiguous())
+
+    # -- fused evaluation --------------------------------------------------
+    def _latents(self) -> int:
+        return 1 if self.mu.dim() == 1 else int(self.mu.shape[0])
+
+    def _evaluate(self, X, groupsX=None, y=None, noise_sd=None, want_moments=True, want_Lu=True,
+                  want_chol=False, chunk=0):
+        spec = kernel_spec(self.kernel, X, self._latents())
+        if spec.L != self._latents():
+            raise ValueError(f"kernel defines {spec.L} latent GPs but mu has shape {tuple(self.mu.shape)}")
+        gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
+        return spec, ops.svgp_forward(spec, X, self.Z, self.mu, self.Lu, float(self.jitter), self._whitened,
+                                      y=y, noise_sd=noise_sd, clamp_min=self._clamp_min, chunk=chunk,
+                                      want_moments=want_moments, want_Lu=want_Lu, want_chol=want_chol, **gk)
+
+    def _distributions(self, out):
+        single = self.mu.dim() == 1
+        pick = (lambda t: t[0]) if single else (lambda t: t)
+        qF = distributions.Normal(pick(out["mean"]), pick(out["scale"]))
+        qU = distributions.MultivariateNormal(self.mu, scale_tril=pick(out["Lu"]))
+        pU = None
+        if not self._whitened:
+            pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(out["chol"]))
+        return qF, qU, pU
+
+    def _forward(self, X, groupsX=None, verbose=False):
+        if verbose:
+            print('gpz_svgp_forward: kernels, cholesky, solves and moments in one fused pass')
+        _, out = self._evaluate(X, groupsX, want_chol=not self._whitened)
+        return self._distributions(out)
+
+    def elbo(self, X, y, noise_sd, groupsX=None, chunk=0):
+        """Closed-form Gaussian ELBO (mggp_test_exact.ipynb:157-159 / utilities.py:479-481
+        with an exact likelihood): fp64 device scalar, plus per-latent KL and log-lik terms."""
+        _, out = self._evaluate(X, groupsX, y=y, noise_sd=float(noise_sd), want_moments=False, want_Lu=False,
+                                chunk=chunk)
+        return out["elbo"], out["kl"], out["loglik"]
+
+
+class WSVGP(_FusedGP):
+    """Whitened SVGP; reference gp.py:235-322."""
+    _whitened = True
+
+    def __init__(self, kernel, dim=1, M=50, jitter=1e-4):
+        super().__init__()
+        self._init_common(kernel, dim, M, jitter)
+
+    def forward(self, X, verbose=False, **args):
+        return self._forward(X, args.get('groupsX'), verbose)
+
+    def forward_precomputed(self, W, **args):
+        """q(F) from a caller-supplied W (L,N,M) (gp.py:308-322)."""
+        out = ops.wsvgp_precomputed(W, self.kernel.sigma, self.mu, self.Lu)
+        return self._distributions(out)
+
+
+class SVGP(_FusedGP):
+    """Un-whitened SVGP; reference gp.py:149-232 (pU = N(0, Kzz) is returned for the MVN-MVN KL)."""
+    _whitened = False
+    _clamp_min = 1e-6
+
+    def __init__(self, kernel, dim=1, M=50, jitter=1e-4):
+        super().__init__()
+        self._init_common(kernel, dim, M, jitter)
+        self.precompute_distance = False
+
+    def forward_kernels(self, X, Z=None, **args):
+        return super().forward_kernels(X, **args)
+
+    def forward(self, X, verbose=False):
+        return self._forward(X, None, verbose)
+
+
+class MGGP_SVGP(_FusedGP):
+    """Multi-group un-whitened SVGP; reference gp.py:329-382 (variance clamp 5e-2, gp.py:378)."""
+    _whitened = False
+    _clamp_min = 5e-2
+    _mggp = True
+
+    def __init__(self, kernel, dim=1, M=50, jitter=1e-4, n_groups=2):
+        super().__init__()
+        self._init_common(kernel, dim, M, jitter)
+        self.groupsZ = nn.Parameter(torch.randint(0, n_groups, (M,)).type(torch.LongTensor), requires_grad=False)
+
+    def forward(self, X, groupsX, verbose=False):
+        return self._forward(X, groupsX, verbose)
+
+
+class MGGP_WSVGP(WSVGP):
+    """Multi-group whitened SVGP; reference gp.py:385-399 (groupsX is a required kwarg)."""
+    _mggp = True
+
+    def __init__(self, kernel, dim=1, M=50, n_groups=2, jitter=1e-4):
+        super().__init__(kernel, dim, M, jitter)
+        self.groupsZ = nn.Parameter(torch.randint(0, n_groups, (M,)).type(torch.LongTensor), requires_grad=False)
+
+    def forward(self, X, verbose=False, **args):
+        return self._forward(X, args['groupsX'], verbose)

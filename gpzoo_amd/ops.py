@@ -115,6 +115,12 @@ def kfill(spec: KernelSpec, A: torch.Tensor, B: torch.Tensor, gA=None, gB=None, 
     return K if spec.batched else K[0]
 
 
+def pairwise_distance(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """Euclidean distances (nA,nB) -- what RBF.forward(return_distance=True) hands back."""
+    one = torch.ones(1, dtype=A.dtype, device=A.device)
+    return kfill(KernelSpec(_lib.KERNEL_DISTANCE, one, one, False), A, B)
+
+
 def _raise_not_pd(info: torch.Tensor, what: str):
     bad = torch.nonzero(info)
     b = int(bad[0, 0])

@@ -36,7 +36,8 @@ enum { GPZ_F32 = 0, GPZ_F64 = 1 };
 enum {
   GPZ_KERNEL_RBF = 0,      /* RBF, NSF_RBF, batched_RBF      kernels.py:34-59,106-155  */
   GPZ_KERNEL_MATERN32 = 1, /* batched_Matern32               kernels.py:6-30           */
-  GPZ_KERNEL_MGGP_RBF = 2  /* MGGP_RBF, MGGP_NSF_RBF, batched_MGGP_RBF  kernels.py:62-104,158-228 */
+  GPZ_KERNEL_MGGP_RBF = 2, /* MGGP_RBF, MGGP_NSF_RBF, batched_MGGP_RBF  kernels.py:62-104,158-228 */
+  GPZ_KERNEL_DISTANCE = 3  /* plain Euclidean distance (return_distance=True, kernels.py:118,125-126) */
 };
 
 /* Hyper-parameters of one covariance family for L independent latents.
