@@ -31,6 +31,7 @@ struct GemmParams {
   int mt = 0, nt = 0;       // output tiles of 128 x 128
   int K = 0;                // contraction extent (multiple of 128 when a triangular flag is set)
   int flags = 0;
+  int super_cols = 8;       // GF_GROUP_COLS: column tiles per L2 super-tile
   T alpha = 1, beta = 0;
   // column statistics (EPI_STORE_STATS / EPI_STATS): partial sums per (outer batch, row tile, column)
   const T* mu = nullptr; int64_t sMu = 0;  // (outer batch, K) vector, padded with zeros

@@ -43,6 +43,7 @@ template <> struct Mma<double> {
   static __device__ __forceinline__ int crow(int q, int g) { return q + 4 * g; }
 };
 
+
 template <typename T, bool BT, int EPI>
 __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams<T> p) {
   using M = Mma<T>;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams<T> p) {
   using acc_t = typename M::acc_t;
   constexpr int VEC = M::VEC;
   constexpr int BK = 4 * VEC;               // 16 (f32) / 8 (f64): 64 bytes of k per row
-  constexpr int LDR = BK + 2 * VEC;         // [row][k] tiles: 96-byte rows, conflict-free 16-B reads
+  constexpr int LDR = BK + VEC;             // [row][k] tiles: 80-byte rows (2-way on 16-B reads) so 4 blocks fit a CU
   constexpr int LDN = 128 + (VEC == 4 ? 4 : 8);  // [k][n] tile row (elements)
   constexpr int A_ELEMS = 128 * LDR;
   constexpr int B_ELEMS = BT ? 128 * LDR : BK * LDN;
@@ -63,10 +64,20 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams<T> p) {
   {
     const int bid = blockIdx.x;
     if (p.flags & GF_GROUP_COLS) {
+      // Super-tiles for L2 reuse: one XCD (blocks b, b+8, ... share an XCD's L2) works through
+      // (latent, strip of SUPER_COLS column tiles) units; inside a unit, row tiles go longest
+      // k-range first and the SUPER_COLS blocks of one row tile are dispatched together, so they
+      // stream the same A panel in lock-step while the unit's B panels stay L2 resident.
+      const int SUPER_COLS = p.super_cols;
       const int x = bid & 7, s = bid >> 3;
-      const int grp = (s / p.mt) * 8 + x, ii = s % p.mt;
-      if (grp >= p.nb0 * p.nt) return;
-      b0 = grp / p.nt; tj = grp - b0 * p.nt; b1 = 0;
+      const int strips = (p.nt + SUPER_COLS - 1) / SUPER_COLS;
+      const int per_unit = p.mt * SUPER_COLS;
+      const int unit = (s / per_unit) * 8 + x, within = s % per_unit;
+      if (unit >= p.nb0 * strips) return;
+      b0 = unit / strips; b1 = 0;
+      const int ii = within / SUPER_COLS;
+      tj = (unit - b0 * strips) * SUPER_COLS + within % SUPER_COLS;
+      if (tj >= p.nt) return;
       ti = (p.flags & GF_A_LOWER) ? p.mt - 1 - ii : ii;   // longest k-range first
     } else {
       const int per = (p.flags & GF_TILES_LOWER) ? p.mt * (p.mt + 1) / 2 : p.mt * p.nt;
@@ -238,8 +249,10 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   int64_t nblocks;
   if (p.flags & GF_GROUP_COLS) {
     GPZ_REQUIRE(p.nb1 == 1 && !(p.flags & GF_TILES_LOWER), "gemm: GROUP_COLS needs a flat batch and a full tile grid");
-    const int64_t groups = (int64_t)p.nb0 * p.nt;
-    nblocks = (groups + 7) / 8 * 8 * p.mt;
+    const int sc = p.super_cols;
+    GPZ_REQUIRE(sc >= 1, "gemm: super_cols must be >= 1");
+    const int64_t units = (int64_t)p.nb0 * ((p.nt + sc - 1) / sc);
+    nblocks = (units + 7) / 8 * 8 * p.mt * sc;
   } else {
     const int64_t per = (p.flags & GF_TILES_LOWER) ? (int64_t)p.mt * (p.mt + 1) / 2 : (int64_t)p.mt * p.nt;
     nblocks = per * p.nb0 * p.nb1;

@@ -18,6 +18,8 @@
 #include "common.h"
 #include "gemm.h"
 
+#include <cstdlib>
+
 namespace gpz {
 
 int kfill_padded(const gpz_kernel_desc* k, const void* A, int64_t nA, int64_t pA, const void* B, int64_t nB,
@@ -383,6 +385,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
   }
 
   // 3. chunks of columns
+  static const int super_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 16; }();
   const int64_t esz = sizeof(T);
   for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
     const int64_t n0 = ci * pl.nc;
@@ -400,7 +403,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
     g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
     g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
-    g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
+    g1.super_cols = super_cols; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
     prof_begin(PROF_STAGE1, s);
     if (int rc = gemm_launch(g1, EPI_STORE_STATS, s)) return rc;
     prof_end(PROF_STAGE1, s);
@@ -408,7 +411,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
     g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
     g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-    g2.ps_sq = b.ps2; g2.ncols = ncp;
+    g2.super_cols = super_cols; g2.ps_sq = b.ps2; g2.ncols = ncp;
     prof_begin(PROF_STAGE2, s);
     if (int rc = gemm_launch(g2, EPI_STATS, s)) return rc;
     prof_end(PROF_STAGE2, s);
