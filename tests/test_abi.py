@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gpzoo_hip.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "gpzoo_hip.h")).read()
+    return sorted(set(re.findall(r"\b(gpz_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gpzoo_amd import _lib, build
+    build.build(force=False, verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in gpzoo_hip.h but not exported"
+    assert sorted(_lib.exported_symbols()) == names  # the ctypes table binds exactly the header
+
+
+def test_version_and_error_string():
+    from gpzoo_amd import _lib
+    lib = _lib.load()
+    assert lib.gpz_version() == 100
+    assert isinstance(lib.gpz_last_error(), bytes)
+
+
+def test_argument_errors_do_not_touch_the_gpu():
+    """Bad arguments are rejected on the host (negative return + message) before any launch."""
+    from gpzoo_amd import _lib
+    lib = _lib.load()
+    rc = lib.gpz_kfill(None, None, 4, None, 4, 2, None, None, None, 4, 16, 0.0, 0, None)
+    assert rc < 0 and b"null" in lib.gpz_last_error()
+    p = _lib.SvgpProblem()
+    p.dtype = 7
+    assert lib.gpz_svgp_workspace_bytes(ctypes.byref(p), 0) == 0
+    assert b"dtype" in lib.gpz_last_error()
+
+
+def test_struct_layout_matches_header():
+    from gpzoo_amd import _lib
+    assert ctypes.sizeof(_lib.KernelDesc) == 56
+    assert ctypes.sizeof(_lib.SvgpProblem) == 56 + 16 + 16 + 8 * 6 + 16 + 16 + 8 * 8

@@ -1,0 +1,85 @@
+"""CPU: the gpzoo.kernels / gpzoo.gp class API (constructor signatures, parameter names and
+shapes = state_dict keys, post-construction replacement) and the loud failure off-GPU."""
+import pytest
+import torch
+import torch.nn as nn
+
+
+def test_drop_in_import_names():
+    from gpzoo.gp import MGGP_SVGP, MGGP_WSVGP, SVGP, WSVGP  # noqa: F401
+    from gpzoo.kernels import (MGGP_NSF_RBF, MGGP_RBF, NSF_RBF, RBF, batched_Matern32,  # noqa: F401
+                               batched_MGGP_RBF, batched_RBF)
+    from gpzoo.likelihoods import ExactLikelihood, GaussianLikelihood  # noqa: F401
+    from gpzoo.utilities import (_embed_distance_matrix, _squared_dist, add_jitter, reshape_param,  # noqa: F401
+                                 svgp_forward, whitened_KL)
+
+
+def test_state_dict_keys_and_shapes():
+    from gpzoo.gp import MGGP_SVGP, WSVGP
+    from gpzoo.kernels import MGGP_NSF_RBF, NSF_RBF
+    m = WSVGP(NSF_RBF(sigma=1.0, lengthscale=2.0, L=5), dim=2, M=30, jitter=1e-3)
+    sd = m.state_dict()
+    assert set(sd) == {"Z", "Lu", "mu", "kernel.sigma", "kernel.lengthscale"}
+    assert sd["Z"].shape == (30, 2) and sd["Lu"].shape == (30, 30) and sd["mu"].shape == (30,)
+    assert sd["kernel.sigma"].shape == (5, 1, 1)
+    g = MGGP_SVGP(MGGP_NSF_RBF(n_groups=3, L=4), dim=2, M=20, n_groups=3)
+    sd = g.state_dict()
+    assert {"groupsZ", "kernel.group_diff_param", "kernel.embedding"} <= set(sd)
+    assert sd["groupsZ"].dtype == torch.int64 and sd["kernel.embedding"].shape == (3, 3)
+    assert g.jitter == 1e-4 and m.jitter == 1e-3
+
+
+def test_defaults_match_reference():
+    from gpzoo.gp import SVGP
+    from gpzoo.kernels import MGGP_RBF, RBF, batched_MGGP_RBF
+    k = RBF()
+    assert float(k.sigma) == 1.0 and float(k.lengthscale) == 2.0 and k.input_dim == 2
+    s = SVGP(k)
+    assert s.Z.shape == (50, 1) and s.Lu.shape == (50, 50) and float(s.mu.abs().sum()) == 0.0
+    assert MGGP_RBF(n_groups=2).embedding.shape == (2, 2)
+    assert not isinstance(MGGP_RBF().embedding, nn.Parameter)      # plain tensor, as in the reference
+    assert isinstance(batched_MGGP_RBF().embedding, nn.Parameter)
+    assert batched_MGGP_RBF().embedding.shape == (10, 10)
+
+
+def test_diag_contract():
+    from gpzoo.kernels import NSF_RBF, RBF, batched_Matern32
+    X = torch.randn(7, 2)
+    assert RBF(sigma=1.5)(X, X, diag=True).shape == (7,)
+    torch.testing.assert_close(RBF(sigma=1.5)(X, X, diag=True), torch.full((7,), 2.25))
+    assert NSF_RBF(L=3)(X, X, diag=True).shape == (3, 7)
+    k = batched_Matern32()
+    k.sigma = nn.Parameter(torch.tensor([1.0, 2.0]))
+    assert k(X, X, diag=True).shape == (2, 7)
+
+
+def test_cpu_tensors_fail_loudly():
+    """No CPU fallback: the product path refuses CPU tensors instead of silently using torch."""
+    from gpzoo.gp import WSVGP
+    from gpzoo.kernels import RBF
+    X = torch.randn(10, 2)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        RBF()(X, X)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        WSVGP(RBF(), dim=2, M=5)(X)
+
+
+def test_helpers_match_oracle():
+    from gpzoo.utilities import _embed_distance_matrix, add_jitter, whitened_KL
+    from oracle import svgp_oracle as O
+    D = torch.tensor([[0.0, 1.0, 2.0], [1.0, 0.0, 1.5], [2.0, 1.5, 0.0]])
+    torch.testing.assert_close(_embed_distance_matrix(D).abs(), O.embed_group_distances(D).abs(), rtol=1e-5, atol=1e-6)
+    K = torch.zeros(2, 4, 4)
+    assert add_jitter(K, 0.5) is K and float(K.sum()) == 4.0   # in place, returns the same tensor
+    assert add_jitter(torch.zeros(3), 1.0) is None
+    mu, Lu = torch.randn(6), torch.randn(6, 6).tril() + 3 * torch.eye(6)
+    torch.testing.assert_close(whitened_KL(mu, Lu), O.whitened_kl(mu, Lu))
+
+
+def test_shard_latents_partition():
+    from gpzoo_amd.synthetic import shard_latents
+    for L, w in ((256, 8), (32, 8), (5, 3), (3, 8)):
+        blocks = [shard_latents(L, w, r) for r in range(w)]
+        assert sum(len(b) for b in blocks) == L
+        assert [i for b in blocks for i in b] == list(range(L))
+    assert len(shard_latents(256, 8, 3)) == 32 and len(shard_latents(256, 2, 1)) == 128

@@ -1,0 +1,137 @@
+"""GPU: the gpzoo.gp / gpzoo.kernels modules (the reference's own call pattern) against the
+golden vectors: construct, replace parameters after construction, model.double(), forward."""
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import golden_cases
+from helpers import load_case, rtol_for
+
+pytestmark = pytest.mark.gpu
+
+KCLS = {"rbf": "RBF", "nsf_rbf": "NSF_RBF", "matern32": "batched_Matern32", "mggp_rbf": "MGGP_RBF",
+        "mggp_nsf_rbf": "MGGP_NSF_RBF"}
+
+
+def build(name, c):
+    import gpzoo.gp as G
+    import gpzoo.kernels as K
+    from gpzoo.likelihoods import ExactLikelihood
+    kind = c["kind"]
+    mggp = "gX" in c
+    M, d = c["Z"].shape
+    if mggp:
+        k = getattr(K, KCLS[kind])(n_groups=3, **({"L": c["sigma"].shape[0]} if kind == "mggp_nsf_rbf" else {}))
+        k.group_diff_param = nn.Parameter(c["group_diff"].clone())
+        if isinstance(k.embedding, nn.Parameter):
+            k.embedding = nn.Parameter(c["embedding"].clone(), requires_grad=False)
+        else:
+            k.embedding = c["embedding"].clone()
+    elif kind == "nsf_rbf":
+        k = K.NSF_RBF(L=c["sigma"].shape[0])
+    else:
+        k = getattr(K, KCLS[kind])()
+    k.sigma = nn.Parameter(c["sigma"].clone())
+    k.lengthscale = nn.Parameter(c["lengthscale"].clone())
+    gpname = name.rsplit("_", 1)[0]
+    if gpname.startswith("mggp_wsvgp"):
+        gp = G.MGGP_WSVGP(k, dim=d, M=M, n_groups=3, jitter=c["jitter"])
+    elif gpname.startswith("mggp_svgp"):
+        gp = G.MGGP_SVGP(k, dim=d, M=M, jitter=c["jitter"], n_groups=3)
+    elif gpname.startswith("wsvgp"):
+        gp = G.WSVGP(k, dim=d, M=M, jitter=c["jitter"])
+    else:
+        gp = G.SVGP(k, dim=d, M=M, jitter=c["jitter"])
+    gp.Z = nn.Parameter(c["Z"].clone())
+    gp.mu = nn.Parameter(c["mu"].clone())           # (M,) -> (L,M) after construction, as the notebooks do
+    gp.Lu = nn.Parameter(c["Lu_raw"].clone())
+    if mggp:
+        gp.groupsZ = nn.Parameter(c["gZ"].clone(), requires_grad=False)
+    import math
+    model = ExactLikelihood(gp, noise=math.log(math.expm1(c["noise_sd"])))
+    model = model.double() if c["X"].dtype == torch.float64 else model.float()
+    model = model.cuda()
+    if mggp and not isinstance(k.embedding, nn.Parameter):
+        k.embedding = k.embedding.cuda()
+    return model
+
+
+@pytest.mark.parametrize("name", [n for n in golden_cases() if n != "cfg1_f64"])
+def test_module_forward_matches_reference(name):
+    c = load_case(name)
+    model = build(name, c)
+    X = c["X"].cuda()
+    kw = {"groupsX": c["gX"].cuda()} if "gX" in c else {}
+    pY, qF, qU, pU = model(X=X, E=1, **kw)
+    rt = rtol_for(X.dtype)
+    assert isinstance(qF, torch.distributions.Normal) and isinstance(qU, torch.distributions.MultivariateNormal)
+    assert qF.mean.shape == c["mean"].shape
+    torch.testing.assert_close(qF.mean.cpu(), c["mean"], rtol=rt, atol=rt * 1e-1)
+    torch.testing.assert_close(qF.scale.cpu(), c["scale"], rtol=rt, atol=rt * 1e-1)
+    torch.testing.assert_close(qU.scale_tril.cpu(), c["Lu"], rtol=rt, atol=rt * 1e-2)
+    if c["whitened"]:
+        assert pU is None
+    else:
+        torch.testing.assert_close(pU.scale_tril.cpu(), c["chol"], rtol=rt, atol=rt * 1e-2)
+        kl = torch.distributions.kl_divergence(qU, pU)
+        torch.testing.assert_close(kl.cpu().reshape(c["kl"].shape), c["kl"], rtol=rt, atol=rt)
+    # the ELBO exactly as mggp_test_exact.ipynb:157-159 assembles it from the returned distributions
+    y = c["y"].cuda()
+    s = torch.nn.functional.softplus(model.noise)
+    elbo = pY.log_prob(y).double().sum() - (qF.scale.double() ** 2).sum() / (2 * s.double() ** 2)
+    elbo = elbo - torch.from_numpy(__import__("numpy").asarray(c["kl"])).double().sum().cuda()
+    assert float(elbo) == pytest.approx(c["elbo"], rel=rt)
+    assert float(model.elbo(X, y, **kw)) == pytest.approx(c["elbo"], rel=rt)   # fused closed form
+
+
+def test_forward_kernels_and_distance():
+    c = load_case("wsvgp_nsf_rbf_f64")
+    model = build("wsvgp_nsf_rbf_f64", c)
+    X = c["X"].cuda()
+    Kxx, Kzx, Kzz = model.gp.forward_kernels(X)
+    torch.testing.assert_close(Kzx.cpu(), c["Kzx"], rtol=1e-9, atol=1e-12)
+    torch.testing.assert_close(Kxx.cpu(), c["Kxx"], rtol=1e-12, atol=0)
+    assert Kzz.shape == (3, 36, 36)
+    from gpzoo.kernels import RBF
+    k = RBF(sigma=1.3, lengthscale=2.0).double().cuda()
+    K, D = k(X, c["Z"].cuda(), return_distance=True)
+    torch.testing.assert_close(D.cpu(), torch.cdist(c["X"], c["Z"]), rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(K.cpu(), (1.3 ** 2) * torch.exp(-0.5 * torch.cdist(c["X"], c["Z"]) ** 2 / 4.0),
+                               rtol=1e-6, atol=1e-9)  # sigma is a float32 python constant cast up
+
+
+def test_vmap_kernels_match_reference():
+    import numpy as np
+    import gpzoo.kernels as K
+    from helpers import GOLDEN
+    import os
+    z = np.load(os.path.join(GOLDEN, "kernels_only.npz"))
+    gX, gZ = torch.from_numpy(z["gX"]).cuda(), torch.from_numpy(z["gZ"]).cuda()
+    for tag, dt, tol in (("f64", torch.float64, 1e-9), ("f32", torch.float32, 1e-4)):
+        X, Z = torch.from_numpy(z[f"{tag}_X"]).cuda(), torch.from_numpy(z[f"{tag}_Z"]).cuda()
+        k = K.batched_RBF()
+        k.sigma = nn.Parameter(torch.tensor([1.0, 0.8, 1.3], dtype=dt))
+        k.lengthscale = nn.Parameter(torch.tensor([2.5, 4.0, 6.0], dtype=dt))
+        torch.testing.assert_close(k.cuda()(Z, X).cpu(), torch.from_numpy(z[f"{tag}_batched_rbf_vec"]), rtol=tol, atol=tol)
+        ks = K.batched_RBF(sigma=1.2, lengthscale=3.0).to(dt).cuda()
+        torch.testing.assert_close(ks(Z, X).cpu(), torch.from_numpy(z[f"{tag}_batched_rbf_scalar"]), rtol=tol, atol=tol)
+        km = K.batched_MGGP_RBF(sigma=1.1, lengthscale=3.5, group_diff_param=-0.6, n_groups=3).to(dt)
+        km.embedding = nn.Parameter(torch.from_numpy(z[f"{tag}_embedding"]), requires_grad=False)
+        torch.testing.assert_close(km.cuda()(Z, X, gZ, gX).cpu(), torch.from_numpy(z[f"{tag}_batched_mggp_rbf_scalar"]),
+                                   rtol=tol, atol=tol)
+        kk = K.batched_Matern32(sigma=0.9, lengthscale=2.0).to(dt).cuda()
+        torch.testing.assert_close(kk(Z, X).cpu(), torch.from_numpy(z[f"{tag}_matern32_scalar"]), rtol=tol, atol=tol)
+        torch.testing.assert_close(kk(Z, Z).cpu(), torch.from_numpy(z[f"{tag}_matern32_zz"]), rtol=tol, atol=tol)
+
+
+def test_not_positive_definite_forward_raises():
+    """An indefinite Kzz (negative jitter beats the off-diagonal mass): the reference raises
+    torch.linalg.LinAlgError from torch.linalg.cholesky (gp.py:270); so does the fused pass."""
+    from gpzoo.gp import WSVGP
+    from gpzoo.kernels import RBF
+    gp = WSVGP(RBF(), dim=2, M=8, jitter=-0.9).double()
+    Z = 0.3 * torch.randn(8, 2, dtype=torch.float64)
+    gp.Z = nn.Parameter(Z)
+    gp = gp.cuda()
+    with pytest.raises(torch.linalg.LinAlgError, match="not positive-definite"):
+        gp(torch.randn(20, 2, dtype=torch.float64).cuda())

@@ -1,0 +1,109 @@
+"""GPU: BASELINE.json's configurations -- scaled to what the CPU oracle finishes in seconds for
+element-wise parity, and at full size through size-independent properties (chunk invariance,
+bitwise determinism, additivity over latent shards, padding invariance)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def to_dev(c):
+    return {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
+
+
+def hip_eval(c, chunk=0, **kw):
+    from gpzoo_amd import ops
+    from gpzoo_amd.configs import spec_for_config
+    g = to_dev(c)
+    spec, extra = spec_for_config(g)
+    return ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
+                            noise_sd=c["noise_sd"], chunk=chunk, clamp_min=kw.pop("clamp_min", 1e-6), **extra, **kw)
+
+
+def oracle_eval(c):
+    from oracle import svgp_oracle as O
+    d = {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in c.items()}
+    kw = {}
+    if "gX" in c:
+        G = c["n_groups"]
+        kw = dict(gX=c["gX"], gZ=c["gZ"], embedding=O.embed_group_distances(torch.ones(G, G) - torch.eye(G)).double(),
+                  group_diff=d["group_diff"])
+    return O.elbo_eval(c["kind"], c["whitened"], d["X"], d["y"], d["Z"], d["sigma"], d["lengthscale"], d["mu"],
+                       d["Lu_raw"], c["jitter"], c["noise_sd"], **kw)
+
+
+def check(c, rt, chunk=0):
+    out = hip_eval(c, chunk)
+    ref, mean, scale = oracle_eval(c)
+    L = 1 if c["mu"].dim() == 1 else c["mu"].shape[0]
+    assert float(out["elbo"]) == pytest.approx(float(ref), rel=rt)
+    torch.testing.assert_close(out["mean"].double().cpu().reshape(mean.shape), mean, rtol=rt, atol=rt)
+    torch.testing.assert_close(out["scale"].double().cpu().reshape(scale.shape), scale, rtol=rt, atol=rt)
+    return out
+
+
+def test_config1_full():
+    """configs[0]: N=1000, M=64, single latent, RBF, fp64, un-whitened; also pinned by the reference fixture."""
+    from gpzoo_amd.synthetic import make_config
+    from helpers import load_case
+    out = check(make_config(1), 1e-5)
+    assert float(out["elbo"]) == pytest.approx(load_case("cfg1_f64")["elbo"], rel=1e-5)
+
+
+def test_config2_scaled():
+    from gpzoo_amd.synthetic import make_config
+    check(make_config(2, N=20000), 1e-3, chunk=8192)      # M=512, L=8, NSF_RBF fp32, 3 chunks
+
+
+def test_config3_scaled():
+    from gpzoo_amd.synthetic import make_config
+    check(make_config(3, N=6000, M=1024, L=4), 1e-3)      # Matern-3/2 fp32, 8 Cholesky panels
+
+
+def test_config5_scaled():
+    from gpzoo_amd.synthetic import make_config
+    check(make_config(5, N=6000, M=300, L=3), 1e-5)       # MGGP_NSF_RBF fp64, ragged M, 4 groups
+
+
+def test_unwhitened_multi_panel_fp64():
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(2, N=3000, M=300, L=3, dtype=torch.float64)
+    c["whitened"] = False
+    check(c, 1e-5)
+
+
+@pytest.mark.parametrize("N,M,L,d", [(1, 1, 1, 2), (7, 3, 2, 2), (1001, 130, 2, 2), (500, 129, 1, 2), (257, 64, 3, 2)])
+def test_ragged_and_tiny_extents(N, M, L, d):
+    from gpzoo_amd.synthetic import make_config
+    check(make_config(2, N=max(N, M), M=M, L=L, dtype=torch.float64) if N >= M else make_config(2, N=N, M=M, L=L), 1e-5)
+
+
+def test_config3_full_size_properties():
+    """N=200k, M=2048, L=32 fp32 (the benchmark workload): properties that need no oracle."""
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(3)
+    a = hip_eval(c, want_Lu=False)
+    b = hip_eval(c, want_Lu=False)
+    assert torch.equal(a["elbo"], b["elbo"]) and torch.equal(a["mean"], b["mean"])       # bitwise reproducible
+    assert torch.equal(a["scale"], b["scale"])
+    d = hip_eval(c, chunk=4096, want_Lu=False)                                              # 49 chunks instead of 17
+    assert torch.equal(a["mean"], d["mean"]) and torch.equal(a["scale"], d["scale"])       # chunking is invisible
+    assert float(d["elbo"]) == pytest.approx(float(a["elbo"]), rel=1e-12)
+    assert torch.isfinite(a["mean"]).all() and (a["scale"] > 0).all()
+    # additivity over latent shards (what the multi-GPU path relies on): two 16-latent halves
+    tot = 0.0
+    for lo in (0, 16):
+        h = dict(c)
+        for k in ("sigma", "lengthscale", "mu", "Lu_raw", "y"):
+            h[k] = c[k][lo:lo + 16]
+        o = hip_eval(h, want_Lu=False)
+        tot += float(o["elbo"])
+        assert torch.equal(o["mean"], a["mean"][lo:lo + 16])
+    assert tot == pytest.approx(float(a["elbo"]), rel=1e-12)
+    assert float((a["kl"] > 0).sum()) == 32
+
+
+def test_padding_invariance_in_M():
+    """M=2000 is padded to 2048 internally: same answer as the oracle's un-padded arithmetic."""
+    from gpzoo_amd.synthetic import make_config
+    check(make_config(3, N=3000, M=2000, L=2), 1e-3)

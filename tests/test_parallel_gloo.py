@@ -1,0 +1,52 @@
+"""CPU, world_size 2, gloo: latent sharding + scalar all-reduce reproduce the single-rank ELBO.
+The per-rank evaluator is injected (the oracle stands in for the HIP pass, which needs a GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gpzoo_amd.synthetic import make_config
+
+
+def _oracle_eval(p):
+    from oracle import svgp_oracle as O
+    e, _, _ = O.elbo_eval(p["kind"], p["whitened"], p["X"], p["y"], p["Z"], p["sigma"], p["lengthscale"], p["mu"],
+                          p["Lu_raw"], p["jitter"], p["noise_sd"])
+    return e
+
+
+def _worker(rank, world, port, L, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpzoo_amd.parallel import sharded_elbo
+    torch.set_num_threads(2)
+    full = make_config(2, N=400, M=48, L=L, dtype=torch.float64)
+    e = sharded_elbo(full, L, local_eval=_oracle_eval)
+    # a rank may also draw only its own block (what bench.py does): same numbers, same sum
+    from gpzoo_amd.synthetic import shard_latents
+    own = make_config(2, N=400, M=48, L=L, latents=shard_latents(L, world, rank), dtype=torch.float64)
+    own["presharded"] = True
+    e2 = sharded_elbo(own, L, local_eval=_oracle_eval)
+    if rank == 0:
+        q.put((float(e), float(e2)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("L", [5, 1])
+def test_two_rank_sum_matches_single_rank(L):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, L, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    e, e2 = q.get()
+    ref = float(_oracle_eval(make_config(2, N=400, M=48, L=L, dtype=torch.float64)))
+    assert e == pytest.approx(ref, rel=1e-12)
+    assert e2 == pytest.approx(ref, rel=1e-12)
