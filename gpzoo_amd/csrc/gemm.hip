@@ -45,7 +45,7 @@ template <> struct Mma<double> {
 
 
 template <typename T, bool BT, int EPI>
-__global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams<T> p) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void gemm128_kernel(const GemmParams<T> p) {
   using M = Mma<T>;
   using vec_t = typename M::vec_t;
   using acc_t = typename M::acc_t;
@@ -116,19 +116,24 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams<T> p) {
   constexpr int BROWS = 256 / NV;             // 8 / 4 rows per pass
   const int rb_row = tid / NV, rb_vc = (tid % NV) * VEC;
 
+  // running global pointers of this thread's two 16-byte pieces of each tile
+  const T* pa[2];
+  const T* pb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    pa[h] = Ag + (int64_t)(ra_row + 64 * h) * p.lda + k_begin + ra_vc;
+    pb[h] = BT ? Bg + (int64_t)(ra_row + 64 * h) * p.ldb + k_begin + ra_vc
+               : Bg + (int64_t)(k_begin + rb_row + BROWS * h) * p.ldb + rb_vc;
+  }
+  const int64_t b_step = BT ? (int64_t)BK : (int64_t)BK * p.ldb;
   vec_t ga[2], gb[2];
-  auto gload = [&](int k0) {
+  auto gload = [&]() {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      ga[h] = *reinterpret_cast<const vec_t*>(Ag + (int64_t)(ra_row + 64 * h) * p.lda + k0 + ra_vc);
-    if (BT) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        gb[h] = *reinterpret_cast<const vec_t*>(Bg + (int64_t)(ra_row + 64 * h) * p.ldb + k0 + ra_vc);
-    } else {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        gb[h] = *reinterpret_cast<const vec_t*>(Bg + (int64_t)(k0 + rb_row + BROWS * h) * p.ldb + rb_vc);
+    for (int h = 0; h < 2; ++h) {
+      ga[h] = *reinterpret_cast<const vec_t*>(pa[h]);
+      gb[h] = *reinterpret_cast<const vec_t*>(pb[h]);
+      pa[h] += BK;
+      pb[h] += b_step;
     }
   };
   auto sstore = [&](int buf) {
@@ -152,16 +157,8 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams<T> p) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = acc_t{0, 0, 0, 0};
 
-  const int nk = (k_end - k_begin) / BK;
-  if (nk > 0) {
-    gload(k_begin);
-    sstore(0);
-  }
-  __syncthreads();
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nk) gload(k_begin + (t + 1) * BK);
-    // fragments: lane (r, q) owns k = VEC*q + j, j < VEC
+  // One k-tile of MFMAs: lane (r, q) owns k = VEC*q + j, j < VEC.
+  auto compute = [&](int buf) {
     vec_t fa[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -189,7 +186,37 @@ __global__ __launch_bounds__(256) void gemm128_kernel(const GemmParams<T> p) {
           for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni], acc[mi][ni]);
       }
     }
+  };
+
+  // In the diagonal 128-block of a triangular A, a wave whose 64 rows x 16 k lie entirely in the
+  // zero triangle skips that k-tile's MFMAs (a quarter of the block's work) but still stages and
+  // syncs.  The skipped tiles are a prefix (A upper, lower-half waves) or a suffix (A lower,
+  // upper-half waves) of the k-range, so the loop is split in three straight-line loops instead
+  // of branching around the MFMAs (hipcc shuffles all accumulators through VGPRs otherwise).
+  const int nk = (k_end - k_begin) / BK;
+  const int wm_s = __builtin_amdgcn_readfirstlane(wm);
+  int n_pre = 0, n_post = 0;
+  if ((p.flags & GF_A_LOWER) && wm_s == 0 && k_end == (ti + 1) * 128) n_post = min(nk, 64 / BK);
+  if ((p.flags & GF_A_UPPER) && wm_s == 1 && k_begin == ti * 128) n_pre = min(nk, 64 / BK);
+  if (nk > 0) {
+    gload();
+    sstore(0);
+  }
+  __syncthreads();
+  int t = 0;
+  for (; t < n_pre; ++t) {
+    if (t + 1 < nk) { gload(); sstore((t & 1) ^ 1); }
+    __syncthreads();
+  }
+  for (; t < nk - n_post; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) gload();
+    compute(buf);
     if (t + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  for (; t < nk; ++t) {
+    if (t + 1 < nk) { gload(); sstore((t & 1) ^ 1); }
     __syncthreads();
   }
 
