@@ -223,20 +223,6 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void gemm128_kernel(co
   // ---------------- epilogue ----------------
   const int64_t crow0 = (int64_t)ti * 128 + wm * 64;
   const int64_t ccol0 = (int64_t)tj * 128 + wn * 64;
-  if (EPI != EPI_STATS) {
-    T* Cg = p.C + b0 * p.sC0 + b1 * p.sC1;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          T* dst = Cg + (crow0 + mi * 16 + M::crow(q, g)) * p.ldc + ccol0 + ni * 16 + r;
-          T v = p.alpha * acc[mi][ni][g];
-          if (p.beta != (T)0) v += p.beta * *dst;
-          *dst = v;
-        }
-  }
   if (EPI != EPI_STORE) {
     // column sums over this block's 128 rows: registers -> lane groups -> the two wm waves
     T* red = smem;  // [2 stats][2 wm][128 cols]; all tile reads are behind the loop's last barrier
@@ -264,6 +250,48 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void gemm128_kernel(co
       const int64_t o = ((int64_t)b0 * p.mt + ti) * p.ncols + (int64_t)tj * 128 + tid;
       p.ps_sq[o] = red[tid] + red[128 + tid];
       if (EPI == EPI_STORE_STATS) p.ps_mu[o] = red[256 + tid] + red[384 + tid];
+    }
+  }
+  if (EPI == EPI_STORE_STATS) __syncthreads();   // the strips below reuse the reduction scratch
+  if (EPI != EPI_STATS) {
+    T* Cg = p.C + b0 * p.sC0 + b1 * p.sC1;
+    if (EPI == EPI_STORE && p.beta != (T)0) {
+      // read-modify-write (trailing updates): straight from the accumulator layout
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            T* dst = Cg + (crow0 + mi * 16 + M::crow(q, g)) * p.ldc + ccol0 + ni * 16 + r;
+            *dst = p.alpha * acc[mi][ni][g] + p.beta * *dst;
+          }
+    } else {
+      // pure store: transpose each wave's 64x64 through its private LDS strip so every store
+      // instruction writes whole 256-byte row segments (16 B per lane) instead of 64-byte pieces
+      constexpr int MPP = VEC == 4 ? 2 : 1;       // 16-row sub-tiles per pass (LDS budget)
+      constexpr int LDE = 64 + VEC;               // strip row stride (elements), keeps 16-B alignment
+      T* strip = smem + wave * (MPP * 16 * LDE);
+#pragma unroll
+      for (int pass = 0; pass < 4 / MPP; ++pass) {
+#pragma unroll
+        for (int mm = 0; mm < MPP; ++mm)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              strip[(mm * 16 + M::crow(q, g)) * LDE + ni * 16 + r] = p.alpha * acc[pass * MPP + mm][ni][g];
+        __syncthreads();
+        constexpr int LPR = 64 / VEC;             // lanes per 64-element row
+        constexpr int RPI = 64 / LPR;             // rows per wave instruction
+#pragma unroll
+        for (int it = 0; it < MPP * 16 / RPI; ++it) {
+          const int row = it * RPI + lane / LPR, c4 = (lane % LPR) * VEC;
+          const vec_t v = *reinterpret_cast<const vec_t*>(strip + row * LDE + c4);
+          *reinterpret_cast<vec_t*>(Cg + (crow0 + pass * MPP * 16 + row) * p.ldc + ccol0 + c4) = v;
+        }
+        __syncthreads();
+      }
     }
   }
 }
