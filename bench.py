@@ -85,11 +85,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # rehearsals may run several ranks on one GPU (gloo only)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GPZ_DIST_BACKEND", "nccl")   # nccl == RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gpzoo_amd import ops
     from gpzoo_amd.configs import spec_for_config

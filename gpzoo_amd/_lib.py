@@ -52,6 +52,9 @@ _SIGNATURES = {
                                        C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpz_svgp_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
     "gpz_svgp_forward": (C.c_int, [C.POINTER(SvgpProblem), C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gpz_wsvgp_precomputed_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
+    "gpz_wsvgp_precomputed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpz_profile_enable": (C.c_int, [C.c_int32]),
     "gpz_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32]),
 }

@@ -190,7 +190,7 @@ struct FinalizeArgs {
   T* mean; T* scale;                         // (L,N) or null
   double* part;                              // [L][nfb_total]
   int64_t N, n0, nc, nfb_total, fb0;
-  int mt, whitened;
+  int mt, mt1, whitened;                     // row tiles of ps2, and of ps1/pm1
   double clamp_min, noise_sd;
 };
 
@@ -203,10 +203,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs<T> a) {
   double term = 0.0;
   if (c < a.nc && n < a.N) {
     T s1 = 0, m1 = 0, s2 = 0;
-    for (int i = 0; i < a.mt; ++i) {
-      const int64_t o = ((int64_t)l * a.mt + i) * a.nc + c;
-      s1 += a.ps1[o]; m1 += a.pm1[o]; s2 += a.ps2[o];
+    for (int i = 0; i < a.mt1; ++i) {
+      const int64_t o = ((int64_t)l * a.mt1 + i) * a.nc + c;
+      s1 += a.ps1[o]; m1 += a.pm1[o];
     }
+    for (int i = 0; i < a.mt; ++i) s2 += a.ps2[((int64_t)l * a.mt + i) * a.nc + c];
     const T sg = a.sigma[l];
     T var;
     if (a.whitened) {
@@ -419,7 +420,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     f.ps1 = b.ps1; f.pm1 = b.pm1; f.ps2 = b.ps2; f.sigma = static_cast<const T*>(p->k.sigma);
     f.y = static_cast<const T*>(p->y); f.mean = static_cast<T*>(p->mean); f.scale = static_cast<T*>(p->scale);
     f.part = b.ll_part; f.N = N; f.n0 = n0; f.nc = ncp; f.nfb_total = pl.nfb_total; f.fb0 = ci * pl.nfb_chunk;
-    f.mt = (int)pl.nblk; f.whitened = wh; f.clamp_min = p->var_clamp_min; f.noise_sd = p->noise_sd;
+    f.mt = f.mt1 = (int)pl.nblk; f.whitened = wh; f.clamp_min = p->var_clamp_min; f.noise_sd = p->noise_sd;
     prof_begin(PROF_FINAL, s);
     // blocks beyond this chunk's columns still write a zero partial so the slab is fully defined
     hipLaunchKernelGGL((finalize_kernel<T>), dim3((unsigned)pl.nfb_chunk, L32), dim3(256), 0, s, f);
@@ -435,6 +436,111 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
   r.L = L32; r.whitened = wh; r.M = M; r.has_y = p->y != nullptr;
   hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, s, r);
   GPZ_LAUNCH_OK();
+  return 0;
+}
+
+
+// ---- WSVGP.forward_precomputed (gp.py:308-322): moments from a caller-supplied W (L,N,M) ----
+// Wt chunk = transpose(W[:, n0:n0+nc, :]) zero padded to (Mp, ncp), plus per-row sum(W^2) and W.mu.
+template <typename T>
+__global__ __launch_bounds__(256) void w_transpose_kernel(const T* __restrict__ W, int64_t N, int64_t M, int64_t n0,
+                                                         int64_t Mp, int64_t ncp, T* __restrict__ Wt) {
+  __shared__ T tile[32][33];
+  const int l = blockIdx.z;
+  const int64_t c0 = (int64_t)blockIdx.x * 32, m0 = (int64_t)blockIdx.y * 32;   // chunk column / inducing index
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t n = n0 + c0 + rr, m = m0 + tx;
+    tile[rr][tx] = (n < N && m < M) ? W[((int64_t)l * N + n) * M + m] : (T)0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) Wt[((int64_t)l * Mp + m0 + rr) * ncp + c0 + tx] = tile[tx][rr];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void w_rowstats_kernel(const T* __restrict__ W, const T* __restrict__ mu, int64_t N,
+                                                        int64_t M, int64_t n0, int64_t ncp, T* __restrict__ ps1,
+                                                        T* __restrict__ pm1) {
+  const int l = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + wave, n = n0 + c;
+  if (c >= ncp) return;
+  T s = 0, m = 0;
+  if (n < N)
+    for (int64_t k = lane; k < M; k += 64) {
+      const T w = W[((int64_t)l * N + n) * M + k];
+      s = fma(w, w, s);
+      m = fma(w, mu[(int64_t)l * M + k], m);
+    }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); m += __shfl_down(m, o); }
+  if (lane == 0) { ps1[(int64_t)l * ncp + c] = s; pm1[(int64_t)l * ncp + c] = m; }
+}
+
+struct PrePlan { int64_t Mp, nblk, nc, nchunks, nfb_chunk, nlu; };
+static PrePlan pre_plan(int64_t L, int64_t N, int64_t M, int esz) {
+  PrePlan pl;
+  pl.Mp = pad_up(M); pl.nblk = pl.Mp / NB;
+  int64_t chunk = (int64_t)(2.0 * (1ull << 30) / ((double)L * pl.Mp * esz));
+  if (chunk < 1024) chunk = 1024;
+  pl.nc = pad_up(chunk > N ? N : chunk);
+  pl.nchunks = (N + pl.nc - 1) / pl.nc;
+  pl.nfb_chunk = (pl.nc + 255) / 256;
+  pl.nlu = (pl.Mp / 32) * (pl.Mp / 32);
+  return pl;
+}
+
+template <typename T>
+struct PreBuffers { T *LuT, *Wc, *ps1, *pm1, *ps2; double *lu_part, *ll_part; size_t bytes; };
+template <typename T>
+static PreBuffers<T> pre_carve(const PrePlan& pl, int64_t L, void* ws) {
+  PreBuffers<T> b;
+  Carver c(ws);
+  b.LuT = c.take<T>(L * pl.Mp * pl.Mp);
+  b.Wc = c.take<T>(L * pl.Mp * pl.nc);
+  b.ps1 = c.take<T>(L * pl.nc);
+  b.pm1 = c.take<T>(L * pl.nc);
+  b.ps2 = c.take<T>(L * pl.nblk * pl.nc);
+  b.lu_part = c.take<double>(L * 2 * pl.nlu);
+  b.ll_part = c.take<double>(L * pl.nfb_chunk * pl.nchunks);
+  b.bytes = c.used();
+  return b;
+}
+
+template <typename T>
+static int precomputed_t(const void* W, const void* sigma, const void* mu, const void* Lu_raw, int64_t L, int64_t N,
+                         int64_t M, void* mean, void* scale, void* Lu, void* ws, size_t ws_bytes, hipStream_t s) {
+  const PrePlan pl = pre_plan(L, N, M, sizeof(T));
+  PreBuffers<T> b = pre_carve<T>(pl, L, ws);
+  GPZ_REQUIRE(ws_bytes >= b.bytes, "gpz_wsvgp_precomputed: workspace too small");
+  const int L32 = (int)L;
+  const int64_t Mp = pl.Mp, mm = Mp * Mp;
+  hipLaunchKernelGGL((lu_prepare_kernel<T>), dim3((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32), dim3(256), 0, s,
+                     static_cast<const T*>(Lu_raw), M, Mp, b.LuT, (double*)nullptr, static_cast<T*>(Lu), b.lu_part);
+  GPZ_LAUNCH_OK();
+  for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
+    const int64_t n0 = ci * pl.nc;
+    const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
+    const int64_t ncp = pad_up(nreal);
+    hipLaunchKernelGGL((w_transpose_kernel<T>), dim3((unsigned)(ncp / 32), (unsigned)(Mp / 32), L32), dim3(256), 0, s,
+                       static_cast<const T*>(W), N, M, n0, Mp, ncp, b.Wc);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL((w_rowstats_kernel<T>), dim3((unsigned)((ncp + 3) / 4), L32), dim3(256), 0, s,
+                       static_cast<const T*>(W), static_cast<const T*>(mu), N, M, n0, ncp, b.ps1, b.pm1);
+    GPZ_LAUNCH_OK();
+    GemmParams<T> g2;
+    g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+    g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+    g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = (int)(ncp / NB); g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+    g2.super_cols = 16; g2.ps_sq = b.ps2; g2.ncols = ncp;
+    if (int rc = gemm_launch(g2, EPI_STATS, s)) return rc;
+    FinalizeArgs<T> f;
+    f.ps1 = b.ps1; f.pm1 = b.pm1; f.ps2 = b.ps2; f.sigma = static_cast<const T*>(sigma); f.y = nullptr;
+    f.mean = static_cast<T*>(mean); f.scale = static_cast<T*>(scale); f.part = b.ll_part; f.N = N; f.n0 = n0;
+    f.nc = ncp; f.nfb_total = pl.nfb_chunk * pl.nchunks; f.fb0 = ci * pl.nfb_chunk; f.mt = (int)pl.nblk; f.mt1 = 1;
+    f.whitened = 1; f.clamp_min = 0.0; f.noise_sd = 1.0;
+    hipLaunchKernelGGL((finalize_kernel<T>), dim3((unsigned)pl.nfb_chunk, L32), dim3(256), 0, s, f);
+    GPZ_LAUNCH_OK();
+  }
   return 0;
 }
 
@@ -467,4 +573,21 @@ extern "C" int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* 
   hipStream_t s = static_cast<hipStream_t>(stream);
   return p->dtype == GPZ_F32 ? svgp_forward_t<float>(p, chunk, ws, ws_bytes, s)
                              : svgp_forward_t<double>(p, chunk, ws, ws_bytes, s);
+}
+
+extern "C" size_t gpz_wsvgp_precomputed_workspace_bytes(int64_t L, int64_t N, int64_t M, int32_t dtype) {
+  if (L < 1 || N < 1 || M < 1) return 0;
+  const PrePlan pl = pre_plan(L, N, M, dtype == GPZ_F32 ? 4 : 8);
+  return dtype == GPZ_F32 ? pre_carve<float>(pl, L, nullptr).bytes : pre_carve<double>(pl, L, nullptr).bytes;
+}
+
+extern "C" int gpz_wsvgp_precomputed(const void* W, const void* sigma, const void* mu, const void* Lu_raw, int64_t L,
+                                     int64_t N, int64_t M, int32_t dtype, void* mean, void* scale, void* Lu, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  GPZ_REQUIRE(W && sigma && mu && Lu_raw && mean && scale && ws, "gpz_wsvgp_precomputed: null pointer");
+  GPZ_REQUIRE(L >= 1 && N >= 1 && M >= 1, "gpz_wsvgp_precomputed: bad extents");
+  GPZ_REQUIRE(dtype == GPZ_F32 || dtype == GPZ_F64, "gpz_wsvgp_precomputed: bad dtype");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == GPZ_F32 ? precomputed_t<float>(W, sigma, mu, Lu_raw, L, N, M, mean, scale, Lu, ws, ws_bytes, s)
+                          : precomputed_t<double>(W, sigma, mu, Lu_raw, L, N, M, mean, scale, Lu, ws, ws_bytes, s);
 }

@@ -224,6 +224,27 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     return out
 
 
+def wsvgp_precomputed(W, sigma, mu, Lu_raw) -> dict:
+    """q(F) moments from a caller-supplied W (L,N,M) or (N,M): WSVGP.forward_precomputed."""
+    _need_cuda(W, mu, Lu_raw)
+    lib = _lib.load()
+    dt = W.dtype
+    M = W.shape[-1]
+    W3 = W.detach().reshape(-1, W.shape[-2], M).contiguous()
+    L, N = W3.shape[0], W3.shape[1]
+    mu2 = mu.detach().to(dt).reshape(-1, M).expand(L, M).contiguous()
+    Lu3 = Lu_raw.detach().to(dt).reshape(-1, M, M).expand(L, M, M).contiguous()
+    sig = sigma.detach().to(dt).reshape(-1).expand(L).contiguous()
+    out = {"mean": torch.empty((L, N), dtype=dt, device=W.device), "scale": torch.empty((L, N), dtype=dt, device=W.device),
+           "Lu": torch.empty((L, M, M), dtype=dt, device=W.device)}
+    nbytes = lib.gpz_wsvgp_precomputed_workspace_bytes(L, N, M, _dt(W3))
+    ws = _workspace(W.device, nbytes)
+    rc = lib.gpz_wsvgp_precomputed(_ptr(W3), _ptr(sig), _ptr(mu2), _ptr(Lu3), L, N, M, _dt(W3), _ptr(out["mean"]),
+                                   _ptr(out["scale"]), _ptr(out["Lu"]), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "gpz_wsvgp_precomputed")
+    return out
+
+
 def profile_enable(on: bool = True):
     _lib.check(_lib.load().gpz_profile_enable(int(on)), "gpz_profile_enable")
 

@@ -131,6 +131,14 @@ size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
 int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes,
                      void* stream);
 
+/* Moments from a caller-supplied W (L,N,M): WSVGP.forward_precomputed, gp.py:308-322
+ * (cov = clamp(sigma^2 - sum W^2, 0) + sum (W Lu)^2, mean = W mu).  sigma (L,), mu (L,M),
+ * Lu_raw (L,M,M) -> mean, scale (L,N) and the constrained Lu (L,M,M, may be NULL). */
+size_t gpz_wsvgp_precomputed_workspace_bytes(int64_t L, int64_t N, int64_t M, int32_t dtype);
+int gpz_wsvgp_precomputed(const void* W, const void* sigma, const void* mu, const void* Lu_raw,
+                          int64_t L, int64_t N, int64_t M, int32_t dtype, void* mean, void* scale,
+                          void* Lu, void* ws, size_t ws_bytes, void* stream);
+
 /* Timing hooks used by bench.py: HIP events recorded on `stream` around the
  * dominant kernels of the last gpz_svgp_forward call (roofline.achieved). */
 int gpz_profile_enable(int32_t on);

@@ -135,3 +135,17 @@ def test_not_positive_definite_forward_raises():
     gp = gp.cuda()
     with pytest.raises(torch.linalg.LinAlgError, match="not positive-definite"):
         gp(torch.randn(20, 2, dtype=torch.float64).cuda())
+
+
+@pytest.mark.parametrize("name", ["wsvgp_nsf_rbf_f64", "wsvgp_matern32_f32", "wsvgp_rbf_f64"])
+def test_forward_precomputed(name):
+    """WSVGP.forward_precomputed (gp.py:308-322): W = (L^-1 Kzx)^T supplied by the caller."""
+    c = load_case(name)
+    model = build(name, c)
+    W = torch.linalg.solve_triangular(c["chol"], c["Kzx"], upper=False).transpose(-1, -2).contiguous().cuda()
+    qF, qU, pU = model.gp.forward_precomputed(W)
+    rt = rtol_for(W.dtype)
+    torch.testing.assert_close(qF.mean.cpu(), c["mean"], rtol=rt, atol=rt * 1e-1)
+    torch.testing.assert_close(qF.scale.cpu(), c["scale"], rtol=rt, atol=rt * 1e-1)
+    torch.testing.assert_close(qU.scale_tril.cpu(), c["Lu"], rtol=rt, atol=rt * 1e-2)
+    assert pU is None
