@@ -1,0 +1,246 @@
+// diag128.hip -- Cholesky factor AND inverse of a 128x128 SPD diagonal block, one workgroup per
+// matrix, fp64, everything resident in LDS (the "LDS staging of the diagonal panel" of the
+// blocked right-looking factorisation, reference call sites gp.py:213/270/360).
+//
+// The block is processed as a 4x4 grid of 32x32 sub-blocks:
+//   * a 32x32 diagonal sub-block is factored and inverted by ONE wave with the rows held in
+//     registers; the pivot column / the row being eliminated is broadcast with v_readlane, so the
+//     sweep needs no LDS traffic and no barrier (wavefront-level reductions);
+//   * the sub-panel solve  L[a][s] = A[a][s] inv(L[s][s])^T  and the in-block trailing update
+//     A[a][b] -= L[a][s] L[b][s]^T  run on v_mfma_f64_16x16x4_f64 with operands read from LDS;
+//   * the inverse of the whole block is assembled by recursive doubling (32 -> 64 -> 128), again on
+//     MFMA; the accumulator tile of C*A is fed straight back as the B operand of -B*(C*A) (the f64
+//     C/D layout row = (lane>>4) + 4*reg makes register g of a tile exactly k-step g's operand).
+// Storage: S[128][129] doubles.  L lives row-major in the lower triangle; the inverse X is kept
+// transposed and shifted one column right, X[i][c] at S[c][i+1], which is free space.
+#include "common.h"
+
+namespace gpz {
+
+namespace {
+constexpr int DP = 129;  // LDS pitch
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ d4 mma(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// X[i][c], i >= c, of the inverse
+__device__ __forceinline__ double& XT(double* S, int c, int i) { return S[c * DP + i + 1]; }
+
+// One wave: Cholesky of the 32x32 block at offset o.  Lane i (and its twin i+32) holds row i in
+// registers; only the pivot crosses lanes through v_readlane.  Each finished column is written to
+// LDS and the multipliers l_kj come back as uniform-address (broadcast) reads.
+__device__ __forceinline__ void factor32(double* S, int o, int lane, int32_t* info, int64_t gbase, int64_t m_real) {
+  const int i = lane & 31;
+  double a[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) a[k] = S[(o + i) * DP + o + k];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    double d = bcast(a[j], j);
+    if (!(d > 0.0)) {
+      if (lane == 0 && gbase + j < m_real) atomicCAS(info, 0, (int)(gbase + j + 1));
+      d = 1.0;
+    }
+    const double r = 1.0 / sqrt(d);
+    a[j] = (i == j) ? d * r : a[j] * r;
+    if (i >= j) S[(o + i) * DP + o + j] = a[j];
+    // registers above the diagonal (k > i) accumulate garbage that is never stored or read back
+#pragma unroll
+    for (int k = j + 1; k < 32; ++k) a[k] = fma(-a[j], S[(o + k) * DP + o + j], a[k]);
+    __builtin_amdgcn_sched_barrier(0);   // one column step at a time: keeps the broadcast reads short-lived
+  }
+}
+
+// One wave: inverse of the factored 32x32 lower-triangular block at offset o by forward
+// substitution; lane c owns column c (x[k] == 0 for k < c by construction), L[ii][k] is a broadcast read.
+__device__ __forceinline__ void invert32(double* S, int o, int lane) {
+  const int c = lane & 31;
+  double x[32];
+#pragma unroll
+  for (int ii = 0; ii < 32; ++ii) {
+    double acc = (ii == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < ii; ++k) acc = fma(-S[(o + ii) * DP + o + k], x[k], acc);
+    x[ii] = acc / S[(o + ii) * DP + o + ii];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int ii = 0; ii < 32; ++ii)
+      if (ii >= c) XT(S, o + c, o + ii) = x[ii];
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void diag128_kernel(double* __restrict__ A, int64_t lda, int64_t stride, int bk,
+                                                     double* __restrict__ Dinv, int64_t dinv_stride,
+                                                     int32_t* __restrict__ info, int64_t m_real, int factor) {
+  extern __shared__ __attribute__((aligned(16))) double S[];  // [128][129]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x;
+  if (bk < 0) bk = blockIdx.y;   // all diagonal blocks in one launch (inverse-only mode)
+  double* Ab = A + (int64_t)b * stride + (int64_t)bk * 128 * (lda + 1);
+  for (int e = tid; e < 128 * 128; e += 256) {
+    const int i = e >> 7, j = e & 127;
+    S[i * DP + j] = (j <= i) ? Ab[(int64_t)i * lda + j] : 0.0;
+  }
+  if (tid < 128) S[tid * DP + 128] = 0.0;
+  __syncthreads();
+
+  for (int s = 0; s < 4; ++s) {
+    const int o = 32 * s;
+    if (w == 0) {
+      if (factor) factor32(S, o, lane, info + b, (int64_t)bk * 128 + o, m_real);
+      invert32(S, o, lane);
+    }
+    __syncthreads();
+    if (!factor || s == 3) continue;
+    const int R0 = o + 32;
+    // ---- sub-panel: rows R0..127, columns o..o+31, in place: L = A * inv(Lss)^T ----
+    {
+      const int ntiles = ((128 - R0) / 16) * 2;
+      d4 acc[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        acc[u] = d4{0, 0, 0, 0};
+        const int t = w + 4 * u;
+        if (t < ntiles) {
+          const int i0 = R0 + 16 * (t >> 1), j = 16 * (t & 1) + r;
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const int k = 4 * kk + q;
+            const double av = S[(i0 + r) * DP + o + k];
+            const double bv = (j >= k) ? XT(S, o + k, o + j) : 0.0;   // inv(Lss)[j][k]
+            acc[u] = mma(av, bv, acc[u]);
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int t = w + 4 * u;
+        if (t < ntiles) {
+          const int i0 = R0 + 16 * (t >> 1), j0 = 16 * (t & 1);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) S[(i0 + q + 4 * g) * DP + o + j0 + r] = acc[u][g];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- in-block trailing update: A[a][b] -= L[a][s] L[b][s]^T, 16x16 tiles with a >= b ----
+    {
+      const int n16 = (128 - R0) / 16;
+      const int nl = n16 * (n16 + 1) / 2;
+      for (int t = w; t < nl; t += 4) {
+        int ta = 0, rem = t;
+        while (rem > ta) { rem -= ta + 1; ++ta; }
+        const int i0 = R0 + 16 * ta, j0 = R0 + 16 * rem;
+        d4 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = S[(i0 + q + 4 * g) * DP + j0 + r];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int k = o + 4 * kk + q;
+          acc = mma(-S[(i0 + r) * DP + k], S[(j0 + r) * DP + k], acc);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) S[(i0 + q + 4 * g) * DP + j0 + r] = acc[g];
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- write the factor back (zeros above the diagonal) ----
+  if (factor)
+    for (int e = tid; e < 128 * 128; e += 256) {
+      const int i = e >> 7, j = e & 127;
+      Ab[(int64_t)i * lda + j] = (j <= i) ? S[i * DP + j] : 0.0;
+    }
+
+  // ---- inverse, level 1: 32 -> 64.  wave = (pair p, column tile jt of the left block) ----
+  {
+    const int p = w >> 1, jt = w & 1;
+    const int oA = 64 * p, oB = oA + 32;
+    const int j = 16 * jt + r;
+    d4 T[2], X[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      T[it] = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k = 4 * kk + q;
+        const double av = S[(oB + 16 * it + r) * DP + oA + k];                 // C = L[2p+1][2p]
+        const double bv = (k >= j) ? XT(S, oA + j, oA + k) : 0.0;              // A^-1[k][j]
+        T[it] = mma(av, bv, T[it]);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      X[it] = d4{0, 0, 0, 0};
+      const int i = 16 * it + r;
+#pragma unroll
+      for (int kt = 0; kt <= it; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int k = 16 * kt + 4 * g + q;
+          const double av = (k <= i) ? XT(S, oB + k, oB + i) : 0.0;            // B^-1[i][k]
+          X[it] = mma(-av, T[kt][g], X[it]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) XT(S, oA + j, oB + 16 * it + q + 4 * g) = X[it][g];
+  }
+  __syncthreads();
+  // ---- inverse, level 2: 64 -> 128.  wave = column tile jt of the left 64 columns ----
+  {
+    const int jt = w, j = 16 * jt + r;
+    d4 T[4], X[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      T[kt] = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = 4 * kk + q;
+        const double av = S[(64 + 16 * kt + r) * DP + k];                      // C = L[64:128][0:64]
+        const double bv = (k >= j) ? XT(S, j, k) : 0.0;                        // A^-1[k][j], A = X[0:64][0:64]
+        T[kt] = mma(av, bv, T[kt]);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      X[it] = d4{0, 0, 0, 0};
+      const int i = 16 * it + r;
+#pragma unroll
+      for (int kt = 0; kt <= it; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int k = 16 * kt + 4 * g + q;
+          const double av = (k <= i) ? XT(S, 64 + k, 64 + i) : 0.0;            // B^-1[i][k], B = X[64:][64:]
+          X[it] = mma(-av, T[kt][g], X[it]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) XT(S, j, 64 + 16 * it + q + 4 * g) = X[it][g];
+  }
+  __syncthreads();
+  double* Db = Dinv + (int64_t)b * dinv_stride + (int64_t)bk * 128 * 128;
+  for (int e = tid; e < 128 * 128; e += 256) {
+    const int i = e >> 7, c = e & 127;
+    Db[e] = (c <= i) ? XT(S, c, i) : 0.0;
+  }
+}
+
+}  // namespace gpz

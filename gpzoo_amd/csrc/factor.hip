@@ -7,9 +7,10 @@
 // fp32 rounding of the big products instead of cond(Kzz) * eps32.
 //
 // Per 128-wide panel k:
-//   1. potf2_inv_kernel  one workgroup per matrix: diagonal block in LDS, column
-//                        sweeps with workgroup-level rank-1 updates; also emits the
-//                        inverse of the block (used by the panel solve and trtri).
+//   1. diag128_kernel    one workgroup per matrix: diagonal block resident in LDS, 32x32
+//                        sub-blocks factored by one wave with readlane broadcasts, MFMA for
+//                        the in-block updates; also emits the inverse of the block (used by
+//                        the panel solve and trtri).  csrc/diag128.hip
 //   2. panel             L[i][k] = A[i][k] * inv(L[k][k])^T          (MFMA GEMM, NT)
 //   3. trailing          A[i][j] -= L[i][k] * L[j][k]^T, i >= j > k  (MFMA SYRK/GEMM)
 // Triangular inverse by recursive doubling: with the diagonal blocks inverted,
@@ -25,66 +26,9 @@ namespace gpz {
 constexpr int NB = 128;        // panel width == GEMM tile
 constexpr int P2 = NB + 1;     // LDS pitch (doubles)
 
-// Factor the diagonal block (bk, bk) of every matrix in place, write zeros above
-// its diagonal, and write the block's inverse (full 128x128, zeros above) to Dinv.
-__global__ __launch_bounds__(256) void potf2_inv_kernel(double* __restrict__ A, int64_t lda, int64_t stride,
-                                                       int bk, double* __restrict__ Dinv, int64_t dinv_stride,
-                                                       int32_t* __restrict__ info, int64_t m_real) {
-  extern __shared__ __attribute__((aligned(16))) double S[];  // [128][129]
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x;
-  double* Ab = A + (int64_t)b * stride + (int64_t)bk * NB * (lda + 1);
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, j = e & 127;
-    S[i * P2 + j] = (j <= i) ? Ab[(int64_t)i * lda + j] : 0.0;
-  }
-  const int ti = tid >> 4, tk = tid & 15;
-  // ---- Cholesky: right-looking column sweep ----
-  for (int j = 0; j < NB; ++j) {
-    __syncthreads();
-    double d = S[j * P2 + j];
-    const bool bad = !(d > 0.0);
-    if (bad) {
-      if (tid == 0 && (int64_t)bk * NB + j < m_real) atomicCAS(&info[b], 0, bk * NB + j + 1);
-      d = 1.0;
-    }
-    const double rs = 1.0 / sqrt(d);
-    if (tid < NB - 1 - j) S[(j + 1 + tid) * P2 + j] *= rs;
-    __syncthreads();
-    if (tid == 0) S[j * P2 + j] = d * rs;
-    for (int i = j + 1 + ti; i < NB; i += 16) {
-      const double lij = S[i * P2 + j];
-      for (int k = j + 1 + tk; k <= i; k += 16) S[i * P2 + k] -= lij * S[k * P2 + j];
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, j = e & 127;
-    Ab[(int64_t)i * lda + j] = (j <= i) ? S[i * P2 + j] : 0.0;
-  }
-  // ---- inverse: X[i][c] (i >= c) kept transposed above the diagonal at S[c][i+1] ----
-  __syncthreads();
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int c = e >> 7, i = e & 127;
-    if (i >= c) S[c * P2 + i + 1] = (i == c) ? 1.0 : 0.0;
-  }
-  for (int k = 0; k < NB; ++k) {
-    __syncthreads();
-    const double rk = 1.0 / S[k * P2 + k];
-    if (tid <= k) S[tid * P2 + k + 1] *= rk;          // row k of X is final
-    __syncthreads();
-    for (int i = k + 1 + ti; i < NB; i += 16) {
-      const double lik = S[i * P2 + k];
-      for (int c = tk; c <= k; c += 16) S[c * P2 + i + 1] -= lik * S[c * P2 + k + 1];
-    }
-  }
-  __syncthreads();
-  double* Db = Dinv + (int64_t)b * dinv_stride + (int64_t)bk * NB * NB;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, c = e & 127;
-    Db[e] = (c <= i) ? S[c * P2 + i + 1] : 0.0;
-  }
-}
+// csrc/diag128.hip: factor (optional) + inverse of the diagonal 128-block(s), one workgroup each.
+__global__ void diag128_kernel(double* __restrict__ A, int64_t lda, int64_t stride, int bk, double* __restrict__ Dinv,
+                               int64_t dinv_stride, int32_t* __restrict__ info, int64_t m_real, int factor);
 
 // Copies the inverted diagonal blocks into the diagonal of Linv (rest zeroed by memset).
 __global__ void scatter_diag_kernel(const double* __restrict__ Dinv, int64_t dinv_stride, double* __restrict__ Linv,
@@ -95,7 +39,7 @@ __global__ void scatter_diag_kernel(const double* __restrict__ Dinv, int64_t din
   for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) dst[(int64_t)(e >> 7) * ld + (e & 127)] = src[e];
 }
 
-static bool g_potf2_attr_set = false;
+static bool g_diag_attr_set = false;
 
 // In-place Cholesky of `batch` padded (Mp,Mp) fp64 matrices; Dinv receives the inverse of
 // every diagonal 128-block: (batch, Mp/128, 128, 128).
@@ -105,35 +49,52 @@ int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t bat
   const int nblk = (int)(Mp / NB);
   const int64_t dstride = (int64_t)nblk * NB * NB;
   const size_t lds = (size_t)NB * P2 * sizeof(double);
-  if (!g_potf2_attr_set) {
-    GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel),
+  if (!g_diag_attr_set) {
+    GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(diag128_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    g_potf2_attr_set = true;
+    g_diag_attr_set = true;
   }
   GPZ_HIP_OK(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, s));
   prof_begin(PROF_POTRF_ALL, s);
-  for (int k = 0; k < nblk; ++k) {
-    hipLaunchKernelGGL(potf2_inv_kernel, dim3((unsigned)batch), dim3(256), lds, s, A, lda, stride, k, Dinv, dstride,
-                       info, m_real);
+  auto diag = [&](int k) -> int {
+    hipLaunchKernelGGL(diag128_kernel, dim3((unsigned)batch), dim3(256), lds, s, A, lda, stride, k, Dinv, dstride, info,
+                       m_real, 1);
     GPZ_LAUNCH_OK();
-    const int rem = nblk - k - 1;
-    if (rem == 0) break;
-    // panel: rows below the diagonal block, in place
+    return 0;
+  };
+  // rows [r0, nblk) of block column k, in place: L = A * inv(L[k][k])^T
+  auto panel = [&](int k, int r0) -> int {
+    if (r0 >= nblk) return 0;
     GemmParams<double> g;
-    g.A = A + (int64_t)(k + 1) * NB * lda + (int64_t)k * NB; g.lda = lda; g.sA0 = stride;
+    g.A = A + (int64_t)r0 * NB * lda + (int64_t)k * NB; g.lda = lda; g.sA0 = stride;
     g.B = Dinv + (int64_t)k * NB * NB; g.ldb = NB; g.sB0 = dstride;
     g.C = const_cast<double*>(g.A); g.ldc = lda; g.sC0 = stride;
-    g.nb0 = (int)batch; g.mt = rem; g.nt = 1; g.K = NB; g.flags = GF_B_TRANS;
-    if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
-    // trailing update: A22 -= L21 L21^T (lower tiles only)
+    g.nb0 = (int)batch; g.mt = nblk - r0; g.nt = 1; g.K = NB; g.flags = GF_B_TRANS;
+    return gemm_launch(g, EPI_STORE, s);
+  };
+  // A[r0:, c0:c0+nc] -= L[r0:, k0:k0+kb] * L[c0:c0+nc, k0:k0+kb]^T   (block units; lower tiles when square)
+  auto update = [&](int r0, int c0, int nc, int k0, int kb, bool lower) -> int {
+    if (r0 >= nblk || nc <= 0) return 0;
     GemmParams<double> t;
-    t.A = g.A; t.lda = lda; t.sA0 = stride;
-    t.B = g.A; t.ldb = lda; t.sB0 = stride;
-    t.C = A + (int64_t)(k + 1) * NB * (lda + 1); t.ldc = lda; t.sC0 = stride;
-    t.nb0 = (int)batch; t.mt = rem; t.nt = rem; t.K = NB; t.flags = GF_B_TRANS | GF_TILES_LOWER;
+    t.A = A + (int64_t)r0 * NB * lda + (int64_t)k0 * NB; t.lda = lda; t.sA0 = stride;
+    t.B = A + (int64_t)c0 * NB * lda + (int64_t)k0 * NB; t.ldb = lda; t.sB0 = stride;
+    t.C = A + (int64_t)r0 * NB * lda + (int64_t)c0 * NB; t.ldc = lda; t.sC0 = stride;
+    t.nb0 = (int)batch; t.mt = nblk - r0; t.nt = nc; t.K = kb * NB;
+    t.flags = GF_B_TRANS | (lower ? GF_TILES_LOWER : 0);
     t.alpha = -1.0; t.beta = 1.0;
+    return gemm_launch(t, EPI_STORE, s);
+  };
+  // Two block columns per outer step: the trailing SYRK then runs with K = 256, which halves the
+  // read-modify-write traffic on the trailing matrix and doubles the MFMA work per tile.
+  for (int k = 0; k < nblk; k += 2) {
+    if (int rc = diag(k)) return rc;
+    if (int rc = panel(k, k + 1)) return rc;
+    if (k + 1 >= nblk) break;
+    if (int rc = update(k + 1, k + 1, 1, k, 1, false)) return rc;   // block column k+1 only
+    if (int rc = diag(k + 1)) return rc;
+    if (int rc = panel(k + 1, k + 2)) return rc;
     prof_begin(PROF_POTRF_TRAIL, s);
-    if (int rc = gemm_launch(t, EPI_STORE, s)) return rc;
+    if (int rc = update(k + 2, k + 2, nblk - k - 2, k, 2, true)) return rc;
     prof_end(PROF_POTRF_TRAIL, s);
   }
   prof_end(PROF_POTRF_ALL, s);
@@ -259,43 +220,6 @@ extern "C" size_t gpz_trsm_workspace_bytes(int64_t M, int64_t N, int64_t batch) 
   return c.used();
 }
 
-namespace gpz {
-// Inverts the diagonal 128-blocks of an already-factored lower-triangular matrix.
-__global__ __launch_bounds__(256) void trinv_diag_kernel(const double* __restrict__ Lc, int64_t ld, int64_t stride,
-                                                        double* __restrict__ Dinv, int64_t dinv_stride) {
-  extern __shared__ __attribute__((aligned(16))) double S[];
-  const int tid = threadIdx.x, b = blockIdx.y, bk = blockIdx.x;
-  const double* Lb = Lc + (int64_t)b * stride + (int64_t)bk * NB * (ld + 1);
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, j = e & 127;
-    if (j <= i) S[i * P2 + j] = Lb[(int64_t)i * ld + j];
-  }
-  __syncthreads();
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int c = e >> 7, i = e & 127;
-    if (i >= c) S[c * P2 + i + 1] = (i == c) ? 1.0 : 0.0;
-  }
-  const int ti = tid >> 4, tk = tid & 15;
-  for (int k = 0; k < NB; ++k) {
-    __syncthreads();
-    const double rk = 1.0 / S[k * P2 + k];
-    if (tid <= k) S[tid * P2 + k + 1] *= rk;
-    __syncthreads();
-    for (int i = k + 1 + ti; i < NB; i += 16) {
-      const double lik = S[i * P2 + k];
-      for (int c = tk; c <= k; c += 16) S[c * P2 + i + 1] -= lik * S[c * P2 + k + 1];
-    }
-  }
-  __syncthreads();
-  double* Db = Dinv + (int64_t)b * dinv_stride + (int64_t)bk * NB * NB;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, c = e & 127;
-    Db[e] = (c <= i) ? S[c * P2 + i + 1] : 0.0;
-  }
-}
-static bool g_trinv_attr_set = false;
-}  // namespace gpz
-
 extern "C" int gpz_trsm_lln_batched(const double* Lc, int64_t ldl, int64_t stride_l, double* B, int64_t ldb,
                                     int64_t stride_b, int64_t M, int64_t N, int64_t batch, void* ws, size_t ws_bytes,
                                     void* stream) {
@@ -316,13 +240,13 @@ extern "C" int gpz_trsm_lln_batched(const double* Lc, int64_t ldl, int64_t strid
   hipLaunchKernelGGL(pad_copy_in_kernel, grid, dim3(256), 0, s, Lc, ldl, stride_l, M, Lp, Mp, 1);
   GPZ_LAUNCH_OK();
   const size_t lds = (size_t)NB * P2 * sizeof(double);
-  if (!g_trinv_attr_set) {
-    GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(trinv_diag_kernel),
+  if (!g_diag_attr_set) {
+    GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(diag128_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    g_trinv_attr_set = true;
+    g_diag_attr_set = true;
   }
-  hipLaunchKernelGGL(trinv_diag_kernel, dim3(nblk, (unsigned)batch), dim3(256), lds, s, Lp, Mp, Mp * Mp, Dinv,
-                     (int64_t)nblk * NB * NB);
+  hipLaunchKernelGGL(diag128_kernel, dim3((unsigned)batch, nblk), dim3(256), lds, s, Lp, Mp, Mp * Mp, -1, Dinv,
+                     (int64_t)nblk * NB * NB, (int32_t*)nullptr, M, 0);
   GPZ_LAUNCH_OK();
   if (int rc = trtri_padded(Lp, Mp, Mp * Mp, Dinv, Linv, Mp, batch, T, s)) return rc;
   // padded right-hand side (rows >= M and columns >= N are zero)

@@ -44,18 +44,33 @@ template <> struct Mma<double> {
 };
 
 
-template <typename T, bool BT, int EPI>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void gemm128_kernel(const GemmParams<T> p) {
+// LDS bytes of one instantiation (two buffers of an A and a B tile)
+template <typename T, int KV, bool BT>
+constexpr size_t gemm_lds_bytes() {
+  constexpr int VEC = 16 / sizeof(T), BK = 4 * VEC * KV, LDR = BK + VEC, LDN = 128 + (VEC == 4 ? 4 : 8);
+  return sizeof(T) * 2 * (128 * LDR + (BT ? 128 * LDR : BK * LDN));
+}
+
+// KV = number of 64-byte k-chunks per staged tile (1: 16-deep f32 / 8-deep f64 tiles, 37 KB of LDS).
+// NI = 16-column sub-tiles per wave: 4 gives 4 waves (2x2) of 64x64, 2 gives 8 waves (2x4) of
+// 64x32.  fp64 MFMAs only reach their rate with >= 3 waves per SIMD (36 TF with one wave, 49 TF
+// with three or more, measured), which the 128 accumulator registers of a 64x64 fp64 wave tile
+// rule out; 64x32 halves them.
+template <typename T, int KV, int NI, bool BT, int EPI>
+__global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(const GemmParams<T> p) {
+  constexpr int WN = 8 / NI;                // waves along N
+  constexpr int NT = 128 * WN;              // threads: 2 x WN waves
   using M = Mma<T>;
   using vec_t = typename M::vec_t;
   using acc_t = typename M::acc_t;
   constexpr int VEC = M::VEC;
-  constexpr int BK = 4 * VEC;               // 16 (f32) / 8 (f64): 64 bytes of k per row
-  constexpr int LDR = BK + VEC;             // [row][k] tiles: 80-byte rows (2-way on 16-B reads) so 4 blocks fit a CU
+  constexpr int BK = 4 * VEC * KV;          // k-depth of a staged tile
+  constexpr int LDR = BK + VEC;             // [row][k] tile row: 16-byte pad (2-way on 16-B reads)
   constexpr int LDN = 128 + (VEC == 4 ? 4 : 8);  // [k][n] tile row (elements)
   constexpr int A_ELEMS = 128 * LDR;
   constexpr int B_ELEMS = BT ? 128 * LDR : BK * LDN;
-  __shared__ __attribute__((aligned(16))) T smem[2 * (A_ELEMS + B_ELEMS)];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* const smem = reinterpret_cast<T*>(smem_raw);
   auto sA = [&](int buf) -> T* { return smem + buf * (A_ELEMS + B_ELEMS); };
   auto sB = [&](int buf) -> T* { return smem + buf * (A_ELEMS + B_ELEMS) + A_ELEMS; };
 
@@ -105,31 +120,36 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void gemm128_kernel(co
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 15, q = lane >> 4;
 
   // ---------------- staging maps (16 bytes per thread per load) ----------------
-  // [row][k] tiles (A, and B when BT): 4 vectors per row, 64 rows per pass, 2 passes
-  const int ra_row = tid >> 2, ra_vc = (tid & 3) * VEC;
+  // [row][k] tiles (A, and B when BT): VPR vectors per row, 256/VPR rows per pass
+  constexpr int VPR = BK / VEC;               // 4 (KV=1) / 8 (KV=2)
+  constexpr int RROWS = NT / VPR;             // rows per pass
+  constexpr int RP = 128 / RROWS;             // passes
+  const int ra_row = tid / VPR, ra_vc = (tid % VPR) * VEC;
   // [k][n] tile: 128/VEC vectors per row
   constexpr int NV = 128 / VEC;               // 32 / 64 threads per row
-  constexpr int BROWS = 256 / NV;             // 8 / 4 rows per pass
+  constexpr int BROWS = NT / NV;              // rows per pass
+  constexpr int NP = BK / BROWS;              // passes
+  static_assert(NP == RP, "A and B staging use the same number of passes");
   const int rb_row = tid / NV, rb_vc = (tid % NV) * VEC;
 
-  // running global pointers of this thread's two 16-byte pieces of each tile
-  const T* pa[2];
-  const T* pb[2];
+  // running global pointers of this thread's 16-byte pieces of each tile
+  const T* pa[RP];
+  const T* pb[RP];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    pa[h] = Ag + (int64_t)(ra_row + 64 * h) * p.lda + k_begin + ra_vc;
-    pb[h] = BT ? Bg + (int64_t)(ra_row + 64 * h) * p.ldb + k_begin + ra_vc
+  for (int h = 0; h < RP; ++h) {
+    pa[h] = Ag + (int64_t)(ra_row + RROWS * h) * p.lda + k_begin + ra_vc;
+    pb[h] = BT ? Bg + (int64_t)(ra_row + RROWS * h) * p.ldb + k_begin + ra_vc
                : Bg + (int64_t)(k_begin + rb_row + BROWS * h) * p.ldb + rb_vc;
   }
   const int64_t b_step = BT ? (int64_t)BK : (int64_t)BK * p.ldb;
-  vec_t ga[2], gb[2];
+  vec_t ga[RP], gb[RP];
   auto gload = [&]() {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < RP; ++h) {
       ga[h] = *reinterpret_cast<const vec_t*>(pa[h]);
       gb[h] = *reinterpret_cast<const vec_t*>(pb[h]);
       pa[h] += BK;
@@ -138,52 +158,56 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void gemm128_kernel(co
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      *reinterpret_cast<vec_t*>(sA(buf) + (ra_row + 64 * h) * LDR + ra_vc) = ga[h];
+    for (int h = 0; h < RP; ++h)
+      *reinterpret_cast<vec_t*>(sA(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = ga[h];
     if (BT) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-        *reinterpret_cast<vec_t*>(sB(buf) + (ra_row + 64 * h) * LDR + ra_vc) = gb[h];
+      for (int h = 0; h < RP; ++h)
+        *reinterpret_cast<vec_t*>(sB(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = gb[h];
     } else {
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < RP; ++h)
         *reinterpret_cast<vec_t*>(sB(buf) + (rb_row + BROWS * h) * LDN + rb_vc) = gb[h];
     }
   };
 
-  acc_t acc[4][4];
+  acc_t acc[4][NI];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = acc_t{0, 0, 0, 0};
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc_t{0, 0, 0, 0};
 
-  // One k-tile of MFMAs: lane (r, q) owns k = VEC*q + j, j < VEC.
+  // One staged tile of MFMAs.  In each 64-byte k-chunk lane (r, q) owns k = VEC*q + j, j < VEC.
   auto compute = [&](int buf) {
-    vec_t fa[4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-      fa[mi] = *reinterpret_cast<const vec_t*>(sA(buf) + (wm * 64 + mi * 16 + r) * LDR + q * VEC);
-    if (BT) {
-      vec_t fb[4];
+    for (int kc = 0; kc < KV; ++kc) {
+      const int ko = kc * 4 * VEC;
+      vec_t fa[4];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        fb[ni] = *reinterpret_cast<const vec_t*>(sB(buf) + (wn * 64 + ni * 16 + r) * LDR + q * VEC);
+      for (int mi = 0; mi < 4; ++mi)
+        fa[mi] = *reinterpret_cast<const vec_t*>(sA(buf) + (wm * 64 + mi * 16 + r) * LDR + ko + q * VEC);
+      if (BT) {
+        vec_t fb[NI];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j)
+        for (int ni = 0; ni < NI; ++ni)
+          fb[ni] = *reinterpret_cast<const vec_t*>(sB(buf) + (wn * 16 * NI + ni * 16 + r) * LDR + ko + q * VEC);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int j = 0; j < VEC; ++j)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni][j], acc[mi][ni]);
-    } else {
+          for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        T fb[4];
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni][j], acc[mi][ni]);
+      } else {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) fb[ni] = sB(buf)[(q * VEC + j) * LDN + wn * 64 + ni * 16 + r];
+        for (int j = 0; j < VEC; ++j) {
+          T fb[NI];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+          for (int ni = 0; ni < NI; ++ni) fb[ni] = sB(buf)[(ko + q * VEC + j) * LDN + wn * 16 * NI + ni * 16 + r];
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni], acc[mi][ni]);
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni], acc[mi][ni]);
+        }
       }
     }
   };
@@ -222,13 +246,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void gemm128_kernel(co
 
   // ---------------- epilogue ----------------
   const int64_t crow0 = (int64_t)ti * 128 + wm * 64;
-  const int64_t ccol0 = (int64_t)tj * 128 + wn * 64;
+  const int64_t ccol0 = (int64_t)tj * 128 + wn * 16 * NI;
   if (EPI != EPI_STORE) {
     // column sums over this block's 128 rows: registers -> lane groups -> the two wm waves
     T* red = smem;  // [2 stats][2 wm][128 cols]; all tile reads are behind the loop's last barrier
     const T* mu = (EPI == EPI_STORE_STATS) ? p.mu + b0 * p.sMu + crow0 : nullptr;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
       T ssq = 0, smu = 0;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -241,8 +265,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void gemm128_kernel(co
       ssq += __shfl_xor(ssq, 16); ssq += __shfl_xor(ssq, 32);
       if (EPI == EPI_STORE_STATS) { smu += __shfl_xor(smu, 16); smu += __shfl_xor(smu, 32); }
       if (q == 0) {
-        red[wm * 128 + wn * 64 + ni * 16 + r] = ssq;
-        if (EPI == EPI_STORE_STATS) red[256 + wm * 128 + wn * 64 + ni * 16 + r] = smu;
+        red[wm * 128 + wn * 16 * NI + ni * 16 + r] = ssq;
+        if (EPI == EPI_STORE_STATS) red[256 + wm * 128 + wn * 16 * NI + ni * 16 + r] = smu;
       }
     }
     __syncthreads();
@@ -260,29 +284,30 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void gemm128_kernel(co
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             T* dst = Cg + (crow0 + mi * 16 + M::crow(q, g)) * p.ldc + ccol0 + ni * 16 + r;
             *dst = p.alpha * acc[mi][ni][g] + p.beta * *dst;
           }
     } else {
-      // pure store: transpose each wave's 64x64 through its private LDS strip so every store
-      // instruction writes whole 256-byte row segments (16 B per lane) instead of 64-byte pieces
+      // pure store: transpose each wave's tile through its private LDS strip so every store
+      // instruction writes whole row segments (16 B per lane) instead of 64-byte pieces
+      constexpr int WC = 16 * NI;                 // columns per wave
       constexpr int MPP = VEC == 4 ? 2 : 1;       // 16-row sub-tiles per pass (LDS budget)
-      constexpr int LDE = 64 + VEC;               // strip row stride (elements), keeps 16-B alignment
+      constexpr int LDE = WC + VEC;               // strip row stride (elements), keeps 16-B alignment
       T* strip = smem + wave * (MPP * 16 * LDE);
 #pragma unroll
       for (int pass = 0; pass < 4 / MPP; ++pass) {
 #pragma unroll
         for (int mm = 0; mm < MPP; ++mm)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               strip[(mm * 16 + M::crow(q, g)) * LDE + ni * 16 + r] = p.alpha * acc[pass * MPP + mm][ni][g];
         __syncthreads();
-        constexpr int LPR = 64 / VEC;             // lanes per 64-element row
+        constexpr int LPR = WC / VEC;             // lanes per row of the strip
         constexpr int RPI = 64 / LPR;             // rows per wave instruction
 #pragma unroll
         for (int it = 0; it < MPP * 16 / RPI; ++it) {
@@ -314,14 +339,27 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   }
   GPZ_REQUIRE(nblocks < (1ll << 31), "gemm: grid too large");
   const bool bt = (p.flags & GF_B_TRANS) != 0;
-  dim3 grid((unsigned)nblocks), block(256);
-#define GPZ_GEMM(BT, EPI) hipLaunchKernelGGL((gemm128_kernel<T, BT, EPI>), grid, block, 0, s, p)
-  if (epilogue == EPI_STORE) { if (bt) GPZ_GEMM(true, EPI_STORE); else GPZ_GEMM(false, EPI_STORE); }
-  else if (epilogue == EPI_STORE_STATS) { GPZ_REQUIRE(!bt, "gemm: stats epilogues are NN only"); GPZ_GEMM(false, EPI_STORE_STATS); }
-  else { GPZ_REQUIRE(!bt, "gemm: stats epilogues are NN only"); GPZ_GEMM(false, EPI_STATS); }
-#undef GPZ_GEMM
-  GPZ_LAUNCH_OK();
-  return 0;
+  if (epilogue != EPI_STORE) GPZ_REQUIRE(!bt, "gemm: stats epilogues are NN only");
+  constexpr int KV = 1;
+  constexpr int NI = sizeof(T) == 4 ? 4 : 2;
+  dim3 grid((unsigned)nblocks), block(1024 / NI);
+  auto launch = [&](auto kernel, size_t lds) -> int {
+    static bool attr_set = false;   // one flag per instantiation of this lambda's call operator
+    if (!attr_set && lds > 64 * 1024) {
+      GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
+    GPZ_LAUNCH_OK();
+    return 0;
+  };
+  if (epilogue == EPI_STORE)
+    return bt ? launch(gemm128_kernel<T, KV, NI, true, EPI_STORE>, gemm_lds_bytes<T, KV, true>())
+              : launch(gemm128_kernel<T, KV, NI, false, EPI_STORE>, gemm_lds_bytes<T, KV, false>());
+  if (epilogue == EPI_STORE_STATS)
+    return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_STATS>, gemm_lds_bytes<T, KV, false>());
+  return launch(gemm128_kernel<T, KV, NI, false, EPI_STATS>, gemm_lds_bytes<T, KV, false>());
 }
 
 template int gemm_launch<float>(const GemmParams<float>&, int, hipStream_t);
