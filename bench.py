@@ -80,6 +80,31 @@ def cpu_baseline(cfg_id: int, c: dict, sample: int) -> dict:
             "sample_elbo": float(e)}
 
 
+def trailing_flops(nblk: int) -> float:
+    """Flops of the timed K=256 trailing SYRK launches of one matrix (csrc/factor.hip): after the two
+    block columns (k, k+1) the lower tiles of the remaining (nblk-k-2)^2 blocks get a 128x128x256 update."""
+    f = 0.0
+    for k in range(0, nblk - 2, 2):
+        rem = nblk - k - 2
+        f += rem * (rem + 1) / 2 * 128.0 * 128.0 * 256.0 * 2.0
+    return f
+
+
+def pmc_traffic(cfg_id, N, M, L, chunk):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01/traffic_stage1.json, FETCH_SIZE doubled per the gfx950 note) when this run is the
+    workload those passes measured; null otherwise.  bench.py itself cannot read PMC counters."""
+    f = os.path.join(ROOT, "profiles", "r01", "traffic_stage1.json")
+    try:
+        t = json.load(open(f))
+        w = t["workload"]
+        if (w["config"], w["N"], w["M"], w["L"], w["chunk"]) == (cfg_id, N, M, L, chunk):
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,7 +177,8 @@ def main():
         ach1 = flops1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
         roof = {"bound": "mfma", "kernel": "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx)" % dname,
                 "achieved": ach1, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach1 / PEAK[dname],
-                "traffic": None, "launches": n1, "avg_launch_ms": ms1 / max(n1, 1)}
+                "traffic": pmc_traffic(cfg_id, N, M, Lper, a.chunk), "launches": n1,
+                "avg_launch_ms": ms1 / max(n1, 1)}
         kms, kn = prof["kfill"]
         esz = 4 if dname == "f32" else 8
         kbytes = (Lper * float(Mp) * N * esz) * a.steps
@@ -164,9 +190,10 @@ def main():
             "stage1_ms_per_eval": ms1 / a.steps,
             "potrf_ms_per_eval": prof["potrf_all"][0] / a.steps,
             "potrf_trailing": {"bound": "mfma", "dtype": "f64",
-                               "achieved_TFLOPs": (Lper * float(Mp) ** 3 / 3.0) * a.steps / (prof["potrf_trailing"][0] * 1e-3) / 1e12
+                               "achieved_TFLOPs": trailing_flops(Mp // 128) * Lper * a.steps / (prof["potrf_trailing"][0] * 1e-3) / 1e12
                                if prof["potrf_trailing"][0] > 0 else 0.0, "peak_TFLOPs": PEAK["f64"],
-                               "ms_per_eval": prof["potrf_trailing"][0] / a.steps},
+                               "ms_per_eval": prof["potrf_trailing"][0] / a.steps,
+                               "note": "K=256 SYRK launches only (90 % of the M^3/3 factorisation flops at M=2048)"},
             "trtri_ms_per_eval": prof["trtri"][0] / a.steps,
             "finalize_ms_per_eval": prof["finalize"][0] / a.steps,
         }
