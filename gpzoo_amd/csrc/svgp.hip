@@ -236,42 +236,49 @@ struct ReduceArgs {
   const double* fro_part; int64_t nfro;        // [L][nfro] (un-whitened: ||Linv Lu||_F^2) or null
   const double* mu_part; int64_t nmu;          // [L][nmu]
   const double* chol_logdiag;                  // (L,)
-  double* kl; double* loglik; double* elbo;
+  double* kl; double* loglik; double* elbo; double* contrib;
   int L, whitened; int64_t M;
   int has_y;
 };
 
+// One block per latent: KL and log-likelihood sums; the per-latent ELBO contribution goes to
+// `contrib`, summed in index order by elbo_sum_kernel (fixed order: bitwise reproducible).
 __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
   __shared__ double sh[8];
-  double total = 0.0;
-  for (int l = 0; l < a.L; ++l) {
-    double v = 0.0;
-    for (int64_t i = threadIdx.x; i < a.nfb; i += 256) v += a.ll_part[(int64_t)l * a.nfb + i];
-    const double ll = block_sum(v, sh);
+  const int l = blockIdx.x;
+  double v = 0.0;
+  for (int64_t i = threadIdx.x; i < a.nfb; i += 256) v += a.ll_part[(int64_t)l * a.nfb + i];
+  const double ll = block_sum(v, sh);
+  v = 0.0;
+  for (int64_t i = threadIdx.x; i < a.nlu; i += 256) v += a.lu_part[((int64_t)l * 2) * a.nlu + i];
+  double fro = block_sum(v, sh);
+  v = 0.0;
+  for (int64_t i = threadIdx.x; i < a.nlu; i += 256) v += a.lu_part[((int64_t)l * 2 + 1) * a.nlu + i];
+  const double logdiag_q = block_sum(v, sh);
+  if (a.fro_part) {
     v = 0.0;
-    for (int64_t i = threadIdx.x; i < a.nlu; i += 256) v += a.lu_part[((int64_t)l * 2) * a.nlu + i];
-    double fro = block_sum(v, sh);
-    v = 0.0;
-    for (int64_t i = threadIdx.x; i < a.nlu; i += 256) v += a.lu_part[((int64_t)l * 2 + 1) * a.nlu + i];
-    const double logdiag_q = block_sum(v, sh);
-    if (a.fro_part) {
-      v = 0.0;
-      for (int64_t i = threadIdx.x; i < a.nfro; i += 256) v += a.fro_part[(int64_t)l * a.nfro + i];
-      fro = block_sum(v, sh);
-    }
-    v = 0.0;
-    for (int64_t i = threadIdx.x; i < a.nmu; i += 256) v += a.mu_part[(int64_t)l * a.nmu + i];
-    const double mu2 = block_sum(v, sh);
-    if (threadIdx.x == 0) {
-      double kl;
-      if (a.whitened) kl = 0.5 * (-2.0 * logdiag_q + fro + mu2 - (double)a.M);          // utilities.py:34
-      else kl = a.chol_logdiag[l] - logdiag_q + 0.5 * (fro + mu2 - (double)a.M);          // MVN||MVN closed form
-      if (a.kl) a.kl[l] = kl;
-      if (a.loglik) a.loglik[l] = ll;
-      total += (a.has_y ? ll : 0.0) - kl;
-    }
+    for (int64_t i = threadIdx.x; i < a.nfro; i += 256) v += a.fro_part[(int64_t)l * a.nfro + i];
+    fro = block_sum(v, sh);
   }
-  if (threadIdx.x == 0 && a.elbo) *a.elbo = total;
+  v = 0.0;
+  for (int64_t i = threadIdx.x; i < a.nmu; i += 256) v += a.mu_part[(int64_t)l * a.nmu + i];
+  const double mu2 = block_sum(v, sh);
+  if (threadIdx.x == 0) {
+    double kl;
+    if (a.whitened) kl = 0.5 * (-2.0 * logdiag_q + fro + mu2 - (double)a.M);          // utilities.py:34
+    else kl = a.chol_logdiag[l] - logdiag_q + 0.5 * (fro + mu2 - (double)a.M);          // MVN||MVN closed form
+    if (a.kl) a.kl[l] = kl;
+    if (a.loglik) a.loglik[l] = ll;
+    a.contrib[l] = (a.has_y ? ll : 0.0) - kl;
+  }
+}
+
+__global__ void elbo_sum_kernel(const double* __restrict__ contrib, int L, double* __restrict__ elbo) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && elbo) {
+    double t = 0.0;
+    for (int l = 0; l < L; ++l) t += contrib[l];
+    *elbo = t;
+  }
 }
 
 struct Plan {
@@ -303,7 +310,7 @@ template <typename T>
 struct Buffers {
   double *Kzz, *Dinv, *Linv, *Tmp, *LuD, *LuW;
   T *LinvG, *LuT, *muE, *Kc, *Wc, *ps1, *pm1, *ps2;
-  double *ll_part, *lu_part, *fro_part, *mu_part, *chol_logdiag;
+  double *ll_part, *lu_part, *fro_part, *mu_part, *chol_logdiag, *contrib;
   size_t bytes;
 };
 
@@ -331,6 +338,7 @@ static Buffers<T> carve(const Plan& pl, bool whitened, void* ws) {
   b.fro_part = whitened ? nullptr : c.take<double>(pl.L * pl.nlu);
   b.mu_part = c.take<double>(pl.L * pl.nmu);
   b.chol_logdiag = c.take<double>(pl.L);
+  b.contrib = c.take<double>(pl.L);
   b.bytes = c.used();
   return b;
 }
@@ -434,7 +442,10 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
   r.fro_part = b.fro_part; r.nfro = pl.nlu; r.mu_part = b.mu_part; r.nmu = pl.nmu;
   r.chol_logdiag = b.chol_logdiag; r.kl = p->kl; r.loglik = p->loglik; r.elbo = p->elbo;
   r.L = L32; r.whitened = wh; r.M = M; r.has_y = p->y != nullptr;
-  hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, s, r);
+  r.contrib = b.contrib;
+  hipLaunchKernelGGL(reduce_kernel, dim3(L32), dim3(256), 0, s, r);
+  GPZ_LAUNCH_OK();
+  hipLaunchKernelGGL(elbo_sum_kernel, dim3(1), dim3(64), 0, s, b.contrib, L32, p->elbo);
   GPZ_LAUNCH_OK();
   return 0;
 }
