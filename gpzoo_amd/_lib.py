@@ -38,6 +38,11 @@ class SvgpProblem(C.Structure):
     ]
 
 
+class SvgpGrads(C.Structure):
+    _fields_ = [("g_mean", C.c_void_p), ("g_scale", C.c_void_p), ("scale", C.c_void_p),
+                ("grad_mu", C.c_void_p), ("grad_Lu_raw", C.c_void_p)]
+
+
 _SIGNATURES = {
     "gpz_version": (C.c_int, []),
     "gpz_last_error": (C.c_char_p, []),
@@ -52,6 +57,9 @@ _SIGNATURES = {
                                        C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpz_svgp_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
     "gpz_svgp_forward": (C.c_int, [C.POINTER(SvgpProblem), C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gpz_svgp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
+    "gpz_svgp_backward": (C.c_int, [C.POINTER(SvgpProblem), C.POINTER(SvgpGrads), C.c_int64, C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
     "gpz_wsvgp_precomputed_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "gpz_wsvgp_precomputed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

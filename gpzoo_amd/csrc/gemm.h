@@ -20,6 +20,7 @@ enum GemmEpilogue : int {
   EPI_STORE = 0,       // C = alpha * A op(B) + beta * C
   EPI_STORE_STATS = 1, // store, plus per-column sum(v^2) and sum(mu[row] * v) over the tile's rows
   EPI_STATS = 2,       // per-column sum(v^2) only, nothing stored
+  EPI_STORE_COLSCALE = 3,  // C[i][j] = alpha * colscale[j] * (A op(B))[i][j]   (NN only; backward's P-bar)
 };
 
 template <typename T>
@@ -38,6 +39,7 @@ struct GemmParams {
   T* ps_sq = nullptr;       // [nb0][mt][ncols]
   T* ps_mu = nullptr;       // [nb0][mt][ncols]
   int64_t ncols = 0;        // nt * 128
+  const T* colscale = nullptr; int64_t sCs = 0;  // EPI_STORE_COLSCALE: (outer batch, ncols) factors
 };
 
 template <typename T>

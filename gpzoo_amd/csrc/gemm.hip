@@ -247,7 +247,7 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
   // ---------------- epilogue ----------------
   const int64_t crow0 = (int64_t)ti * 128 + wm * 64;
   const int64_t ccol0 = (int64_t)tj * 128 + wn * 16 * NI;
-  if (EPI != EPI_STORE) {
+  if (EPI == EPI_STORE_STATS || EPI == EPI_STATS) {
     // column sums over this block's 128 rows: registers -> lane groups -> the two wm waves
     T* red = smem;  // [2 stats][2 wm][128 cols]; all tile reads are behind the loop's last barrier
     const T* mu = (EPI == EPI_STORE_STATS) ? p.mu + b0 * p.sMu + crow0 : nullptr;
@@ -297,6 +297,10 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
       constexpr int MPP = VEC == 4 ? 2 : 1;       // 16-row sub-tiles per pass (LDS budget)
       constexpr int LDE = WC + VEC;               // strip row stride (elements), keeps 16-B alignment
       T* strip = smem + wave * (MPP * 16 * LDE);
+      T cs[NI];                                   // alpha, times the column factor when asked for
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        cs[ni] = (EPI == EPI_STORE_COLSCALE) ? p.alpha * p.colscale[b0 * p.sCs + ccol0 + ni * 16 + r] : p.alpha;
 #pragma unroll
       for (int pass = 0; pass < 4 / MPP; ++pass) {
 #pragma unroll
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              strip[(mm * 16 + M::crow(q, g)) * LDE + ni * 16 + r] = p.alpha * acc[pass * MPP + mm][ni][g];
+              strip[(mm * 16 + M::crow(q, g)) * LDE + ni * 16 + r] = cs[ni] * acc[pass * MPP + mm][ni][g];
         __syncthreads();
         constexpr int LPR = WC / VEC;             // lanes per row of the strip
         constexpr int RPI = 64 / LPR;             // rows per wave instruction
@@ -339,7 +343,8 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   }
   GPZ_REQUIRE(nblocks < (1ll << 31), "gemm: grid too large");
   const bool bt = (p.flags & GF_B_TRANS) != 0;
-  if (epilogue != EPI_STORE) GPZ_REQUIRE(!bt, "gemm: stats epilogues are NN only");
+  if (epilogue != EPI_STORE) GPZ_REQUIRE(!bt, "gemm: stats / column-scale epilogues are NN only");
+  if (epilogue == EPI_STORE_COLSCALE) GPZ_REQUIRE(p.colscale && p.beta == (T)0, "gemm: column-scale epilogue needs factors and beta = 0");
   constexpr int KV = 1;
   constexpr int NI = sizeof(T) == 4 ? 4 : 2;
   dim3 grid((unsigned)nblocks), block(1024 / NI);
@@ -357,6 +362,8 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   if (epilogue == EPI_STORE)
     return bt ? launch(gemm128_kernel<T, KV, NI, true, EPI_STORE>, gemm_lds_bytes<T, KV, true>())
               : launch(gemm128_kernel<T, KV, NI, false, EPI_STORE>, gemm_lds_bytes<T, KV, false>());
+  if (epilogue == EPI_STORE_COLSCALE)
+    return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_COLSCALE>, gemm_lds_bytes<T, KV, false>());
   if (epilogue == EPI_STORE_STATS)
     return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_STATS>, gemm_lds_bytes<T, KV, false>());
   return launch(gemm128_kernel<T, KV, NI, false, EPI_STATS>, gemm_lds_bytes<T, KV, false>());

@@ -343,15 +343,13 @@ static Buffers<T> carve(const Plan& pl, bool whitened, void* ws) {
   return b;
 }
 
+// Steps shared by the forward and backward passes: Kzz + jitter I (fp64, identity padded), its
+// Cholesky factor and inverse, and q(U)'s parameters in the form the two big products need.
 template <typename T>
-static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes, hipStream_t s) {
-  const Plan pl = make_plan(p, chunk);
+static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, hipStream_t s) {
   const bool wh = p->whitened != 0;
-  Buffers<T> b = carve<T>(pl, wh, ws);
-  GPZ_REQUIRE(ws_bytes >= b.bytes, "gpz_svgp_forward: workspace too small (%zu < %zu)", ws_bytes, b.bytes);
-  const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, N = pl.N, mm = Mp * Mp;
+  const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, mm = Mp * Mp;
   const int L32 = (int)L;
-
   // 1. Kzz + jitter I (fp64, identity padded), Cholesky, inverse
   if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, p->gZ, p->gZ, b.Kzz, Mp, mm, p->jitter, 1,
                             GPZ_F64, s))
@@ -392,6 +390,20 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
                        static_cast<const T*>(p->mu), M, Mp, b.Linv, b.muE, b.mu_part);
     GPZ_LAUNCH_OK();
   }
+
+  return 0;
+}
+
+template <typename T>
+static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes, hipStream_t s) {
+  const Plan pl = make_plan(p, chunk);
+  const bool wh = p->whitened != 0;
+  Buffers<T> b = carve<T>(pl, wh, ws);
+  GPZ_REQUIRE(ws_bytes >= b.bytes, "gpz_svgp_forward: workspace too small (%zu < %zu)", ws_bytes, b.bytes);
+  const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, N = pl.N, mm = Mp * Mp;
+  const int L32 = (int)L;
+
+  if (int rc = prepare_t<T>(p, pl, b, s)) return rc;
 
   // 3. chunks of columns
   static const int super_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 16; }();
@@ -555,6 +567,201 @@ static int precomputed_t(const void* W, const void* sigma, const void* mu, const
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward pass for frozen kernel hyper-parameters (the big notebooks' training mode,
+// Slideseq_NSF_newest_version.ipynb:500-504): gradients of a scalar loss w.r.t. mu and the raw
+// Lu, given dLoss/dmean and dLoss/dscale of q(F).  With W = Linv Kzx, P = LuE^T W,
+// gv2 = dLoss/dscale / scale (= 2 dLoss/dvar, zero where the variance clamp is active):
+//   d/d muE = W gm,   d/d LuE = tril(W (P diag(gv2))^T)
+// whitened: LuE = Lu, muE = mu;  un-whitened: LuE = Linv Lu, muE = Linv mu, so the results are
+// pulled back through Linv^T.  Cost: the forward's two products (W is recomputed per chunk, P is
+// stored column-scaled) plus one (M x n)(n x M) accumulation -- 1.5x the forward.
+template <typename T>
+__global__ void colscale_kernel(const T* __restrict__ g_scale, const T* __restrict__ scale, int64_t N, int64_t n0,
+                                int64_t ncp, int whitened, double clamp_min, T* __restrict__ out) {
+  const int l = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncp) return;
+  const int64_t n = n0 + c;
+  T v = 0;
+  if (n < N) {
+    const T sc = scale[(int64_t)l * N + n];
+    const bool clamped = !whitened && (double)sc * (double)sc <= clamp_min * (1.0 + 1e-6);
+    if (sc > (T)0 && !clamped) v = g_scale[(int64_t)l * N + n] / sc;
+  }
+  out[(int64_t)l * ncp + c] = v;
+}
+
+// part[l][ci][m] = sum_c Wt[l][m][c] * g_mean[l][n0 + c]   (one wave per row)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ Wt, int64_t Mp, int64_t ncp,
+                                                    const T* __restrict__ g_mean, int64_t N, int64_t n0,
+                                                    double* __restrict__ part, int64_t nchunks, int64_t ci) {
+  const int l = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nreal = (N - n0 < ncp) ? N - n0 : ncp;
+  const T* row = Wt + ((int64_t)l * Mp + m) * ncp;
+  const T* g = g_mean + (int64_t)l * N + n0;
+  double acc = 0.0;
+  for (int64_t c = lane; c < nreal; c += 64) acc += (double)row[c] * (double)g[c];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane == 0) part[((int64_t)l * nchunks + ci) * Mp + m] = acc;
+}
+
+// v[l][m] = sum_ci part[l][ci][m]
+__global__ void chunk_sum_kernel(const double* __restrict__ part, int64_t nchunks, int64_t Mp, double* __restrict__ v) {
+  const int l = blockIdx.y;
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= Mp) return;
+  double t = 0.0;
+  for (int64_t ci = 0; ci < nchunks; ++ci) t += part[((int64_t)l * nchunks + ci) * Mp + m];
+  v[(int64_t)l * Mp + m] = t;
+}
+
+// out[l][a] = sum_{i >= a} Linv[l][i][a] * v[l][i]   (Linv^T v, Linv lower triangular) or v itself
+template <typename T>
+__global__ void mu_grad_kernel(const double* __restrict__ v, const double* __restrict__ Linv, int64_t Mp, int64_t M,
+                               T* __restrict__ out) {
+  const int l = blockIdx.y;
+  const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a >= M) return;
+  double t;
+  if (!Linv) {
+    t = v[(int64_t)l * Mp + a];
+  } else {
+    t = 0.0;
+    const double* Lb = Linv + (int64_t)l * Mp * Mp;
+    for (int64_t i = a; i < M; ++i) t += Lb[i * Mp + a] * v[(int64_t)l * Mp + i];
+  }
+  out[(int64_t)l * M + a] = (T)t;
+}
+
+// zero the strict upper triangle of (L,Mp,Mp)
+template <typename T>
+__global__ void tril_kernel(T* __restrict__ G, int64_t Mp) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < Mp && j > i) G[(int64_t)l * Mp * Mp + i * Mp + j] = (T)0;
+}
+
+// chain rule of the constraint Lu = tril(raw, -1) + diag(exp(diag raw))
+template <typename T>
+__global__ void lu_grad_kernel(const T* __restrict__ G, int64_t Mp, int64_t M, const T* __restrict__ raw,
+                               T* __restrict__ out) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  const T g = G[(int64_t)l * Mp * Mp + i * Mp + j];
+  T v = 0;
+  if (j < i) v = g;
+  else if (j == i) v = g * (T)exp((double)raw[(int64_t)l * M * M + i * M + i]);
+  out[(int64_t)l * M * M + i * M + j] = v;
+}
+
+template <typename T>
+struct BwdBuffers { T *Pc, *G, *G2, *LinvT, *cs; double *mu_part, *mu_sum; size_t bytes; };
+
+template <typename T>
+static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, void* ws, size_t offset) {
+  BwdBuffers<T> b;
+  Carver c(ws);
+  c.off = offset;
+  const int64_t mm = pl.L * pl.Mp * pl.Mp;
+  b.Pc = c.take<T>(pl.L * pl.Mp * pl.nc);
+  b.G = c.take<T>(mm);
+  b.G2 = whitened ? nullptr : c.take<T>(mm);
+  b.LinvT = whitened ? nullptr : c.take<T>(mm);
+  b.cs = c.take<T>(pl.L * pl.nc);
+  b.mu_part = c.take<double>(pl.L * pl.nchunks * pl.Mp);
+  b.mu_sum = c.take<double>(pl.L * pl.Mp);
+  b.bytes = c.used();
+  return b;
+}
+
+template <typename T>
+static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int64_t chunk, void* ws, size_t ws_bytes,
+                           hipStream_t s) {
+  const Plan pl = make_plan(p, chunk);
+  const bool wh = p->whitened != 0;
+  Buffers<T> b = carve<T>(pl, wh, ws);
+  BwdBuffers<T> w = carve_bwd<T>(pl, wh, ws, b.bytes);
+  GPZ_REQUIRE(ws_bytes >= w.bytes, "gpz_svgp_backward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+  const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, N = pl.N, mm = Mp * Mp;
+  const int L32 = (int)L;
+  gpz_svgp_problem q = *p;          // forward-only outputs are not produced again
+  q.chol = nullptr; q.Lu = nullptr;
+  if (int rc = prepare_t<T>(&q, pl, b, s)) return rc;
+  GPZ_HIP_OK(hipMemsetAsync(w.G, 0, sizeof(T) * L * mm, s));
+  static const int super_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 16; }();
+  const int64_t esz = sizeof(T);
+  for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
+    const int64_t n0 = ci * pl.nc;
+    const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
+    const int64_t ncp = pad_up(nreal);
+    const int nt = (int)(ncp / NB);
+    if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
+                              p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
+                              pl.f32 ? GPZ_F32 : GPZ_F64, s))
+      return rc;
+    GemmParams<T> g1;  // W = Linv * Kzx
+    g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
+    g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
+    g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
+    g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
+    g1.super_cols = super_cols;
+    if (int rc = gemm_launch(g1, EPI_STORE, s)) return rc;
+    hipLaunchKernelGGL((colscale_kernel<T>), dim3((unsigned)((ncp + 255) / 256), L32), dim3(256), 0, s,
+                       static_cast<const T*>(g->g_scale), static_cast<const T*>(g->scale), N, n0, ncp, (int)wh,
+                       p->var_clamp_min, w.cs);
+    GPZ_LAUNCH_OK();
+    GemmParams<T> g2;  // Pbar = (LuE^T W) diag(gv2)
+    g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+    g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+    g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
+    g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+    g2.super_cols = super_cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
+    if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
+    GemmParams<T> g3;  // G += W Pbar^T  (lower tiles)
+    g3.A = b.Wc; g3.lda = ncp; g3.sA0 = Mp * ncp;
+    g3.B = w.Pc; g3.ldb = ncp; g3.sB0 = Mp * ncp;
+    g3.C = w.G; g3.ldc = Mp; g3.sC0 = mm;
+    g3.nb0 = L32; g3.mt = g3.nt = (int)pl.nblk; g3.K = (int)ncp; g3.flags = GF_B_TRANS | GF_TILES_LOWER;
+    g3.alpha = 1; g3.beta = 1;
+    if (int rc = gemm_launch(g3, EPI_STORE, s)) return rc;
+    hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Wc, Mp, ncp,
+                       static_cast<const T*>(g->g_mean), N, n0, w.mu_part, pl.nchunks, ci);
+    GPZ_LAUNCH_OK();
+  }
+  hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.mu_part, pl.nchunks,
+                     Mp, w.mu_sum);
+  GPZ_LAUNCH_OK();
+  hipLaunchKernelGGL((mu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, w.mu_sum,
+                     wh ? (const double*)nullptr : b.Linv, Mp, M, static_cast<T*>(g->grad_mu));
+  GPZ_LAUNCH_OK();
+  const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
+  T* Gfin = w.G;
+  if (!wh) {
+    // dLoss/dLu = tril(Linv^T tril(dLoss/dLuE))
+    hipLaunchKernelGGL((tril_kernel<T>), gm, dim3(256), 0, s, w.G, Mp);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL((transpose_cast_kernel<T>), dim3((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32), dim3(256), 0, s,
+                       b.Linv, Mp, w.LinvT, b.fro_part);   // fro_part is scratch here
+    GPZ_LAUNCH_OK();
+    GPZ_HIP_OK(hipMemsetAsync(w.G2, 0, sizeof(T) * L * mm, s));
+    GemmParams<T> g4;
+    g4.A = w.LinvT; g4.lda = Mp; g4.sA0 = mm;
+    g4.B = w.G; g4.ldb = Mp; g4.sB0 = mm;
+    g4.C = w.G2; g4.ldc = Mp; g4.sC0 = mm;
+    g4.nb0 = L32; g4.mt = g4.nt = (int)pl.nblk; g4.K = (int)Mp; g4.flags = GF_A_UPPER | GF_B_LOWER | GF_TILES_LOWER;
+    if (int rc = gemm_launch(g4, EPI_STORE, s)) return rc;
+    Gfin = w.G2;
+  }
+  hipLaunchKernelGGL((lu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)M, L32), dim3(256), 0, s, Gfin, Mp,
+                     M, static_cast<const T*>(p->Lu_raw), static_cast<T*>(g->grad_Lu_raw));
+  GPZ_LAUNCH_OK();
+  return 0;
+}
+
 static int check_problem(const gpz_svgp_problem* p) {
   GPZ_REQUIRE(p, "gpz_svgp: null problem");
   GPZ_REQUIRE(p->dtype == GPZ_F32 || p->dtype == GPZ_F64, "gpz_svgp: bad dtype %d", p->dtype);
@@ -601,4 +808,22 @@ extern "C" int gpz_wsvgp_precomputed(const void* W, const void* sigma, const voi
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == GPZ_F32 ? precomputed_t<float>(W, sigma, mu, Lu_raw, L, N, M, mean, scale, Lu, ws, ws_bytes, s)
                           : precomputed_t<double>(W, sigma, mu, Lu_raw, L, N, M, mean, scale, Lu, ws, ws_bytes, s);
+}
+
+extern "C" size_t gpz_svgp_backward_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk) {
+  if (check_problem(p)) return 0;
+  const Plan pl = make_plan(p, chunk);
+  const bool wh = p->whitened != 0;
+  if (p->dtype == GPZ_F32) return carve_bwd<float>(pl, wh, nullptr, carve<float>(pl, wh, nullptr).bytes).bytes;
+  return carve_bwd<double>(pl, wh, nullptr, carve<double>(pl, wh, nullptr).bytes).bytes;
+}
+
+extern "C" int gpz_svgp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int64_t chunk, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  GPZ_REQUIRE(g && g->g_mean && g->g_scale && g->scale && g->grad_mu && g->grad_Lu_raw && ws,
+              "gpz_svgp_backward: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return p->dtype == GPZ_F32 ? svgp_backward_t<float>(p, g, chunk, ws, ws_bytes, s)
+                             : svgp_backward_t<double>(p, g, chunk, ws, ws_bytes, s);
 }

@@ -10,7 +10,8 @@ parameters after construction.  ``forward`` is ONE call into
 solves and the q(F) reductions never round-trip through torch ops, and neither
 Kzx nor W is materialised for more than one N-chunk.
 
-Forward only (SURVEY.md §8f "next" #1): returned tensors carry no autograd graph.
+Training: ``qF`` is differentiable w.r.t. ``mu`` and ``Lu`` (``gpz_svgp_backward``; Z and the kernel
+hyper-parameters are treated as frozen -- the first half of SURVEY.md §8f "next" #1).
 """
 from __future__ import annotations
 
@@ -19,8 +20,39 @@ import torch.nn as nn
 from torch import distributions
 from torch.distributions import constraints
 
+import warnings
+
 from . import ops
 from .kernels import kernel_spec
+
+
+class _QFMoments(torch.autograd.Function):
+    """(mean, scale) of q(F) as a differentiable function of mu and the raw Lu.
+
+    forward = gpz_svgp_forward, backward = gpz_svgp_backward (frozen kernel hyper-parameters:
+    SURVEY.md §8f "next" #1, first half).  Z and the kernel parameters get no gradient."""
+
+    @staticmethod
+    def forward(ctx, mu, Lu_raw, call):
+        out = call["forward"](mu, Lu_raw)
+        ctx.call = call
+        ctx.save_for_backward(mu, Lu_raw, out["scale"])
+        ctx.mark_non_differentiable(out["Lu"])
+        chol = out.get("chol")
+        if chol is None:
+            chol = out["Lu"].new_empty(0)
+        ctx.mark_non_differentiable(chol)
+        return out["mean"], out["scale"], out["Lu"], chol
+
+    @staticmethod
+    def backward(ctx, g_mean, g_scale, _g_lu, _g_chol):
+        mu, Lu_raw, scale = ctx.saved_tensors
+        if g_mean is None:
+            g_mean = torch.zeros_like(scale)
+        if g_scale is None:
+            g_scale = torch.zeros_like(scale)
+        grad_mu, grad_Lu = ctx.call["backward"](mu, Lu_raw, g_mean, g_scale, scale)
+        return grad_mu.reshape(mu.shape), grad_Lu.reshape(Lu_raw.shape), None
 
 
 class _FusedGP(nn.Module):
@@ -76,8 +108,39 @@ class _FusedGP(nn.Module):
     def _forward(self, X, groupsX=None, verbose=False):
         if verbose:
             print('gpz_svgp_forward: kernels, cholesky, solves and moments in one fused pass')
-        _, out = self._evaluate(X, groupsX, want_chol=not self._whitened)
-        return self._distributions(out)
+        train = torch.is_grad_enabled() and (self.mu.requires_grad or self.Lu.requires_grad)
+        if not train:
+            _, out = self._evaluate(X, groupsX, want_chol=not self._whitened)
+            return self._distributions(out)
+        frozen = [self.Z] + [t for t in self.kernel.parameters()]
+        if any(t.requires_grad for t in frozen) and not getattr(_FusedGP, "_warned", False):
+            _FusedGP._warned = True
+            warnings.warn("gpzoo_amd: gradients are propagated to mu and Lu only; Z and the kernel hyper-parameters "
+                          "are treated as frozen (set requires_grad=False on them, as the Slide-seq notebooks do)")
+        spec = kernel_spec(self.kernel, X, self._latents())
+        gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
+        args = (spec, X, self.Z)
+        common = dict(clamp_min=self._clamp_min, **gk)
+
+        def fwd(mu, Lu_raw):
+            return ops.svgp_forward(*args, mu, Lu_raw, float(self.jitter), self._whitened,
+                                    want_chol=not self._whitened, **common)
+
+        def bwd(mu, Lu_raw, g_mean, g_scale, scale):
+            return ops.svgp_backward(*args, mu, Lu_raw, float(self.jitter), self._whitened, g_mean, g_scale, scale,
+                                     **common)
+
+        mean, scale, _, chol = _QFMoments.apply(self.mu, self.Lu, dict(forward=fwd, backward=bwd))
+        # q(U)'s scale_tril through torch so that KL terms differentiate w.r.t. the raw parameter
+        Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
+        single = self.mu.dim() == 1
+        pick = (lambda t: t[0]) if single else (lambda t: t)
+        qF = distributions.Normal(pick(mean), pick(scale))
+        qU = distributions.MultivariateNormal(self.mu, scale_tril=Lu)
+        pU = None
+        if not self._whitened:
+            pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(chol))
+        return qF, qU, pU
 
     def elbo(self, X, y, noise_sd, groupsX=None, chunk=0):
         """Closed-form Gaussian ELBO (mggp_test_exact.ipynb:157-159 / utilities.py:479-481

@@ -166,16 +166,9 @@ def solve_triangular_lower(Lc: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return Bw.to(dt).reshape(B.shape)
 
 
-def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, *, gX=None, gZ=None,
-                 y=None, noise_sd: Optional[float] = None, clamp_min: float = 1e-6, chunk: int = 0,
-                 want_moments: bool = True, want_Lu: bool = True, want_chol: bool = False,
-                 check_info: bool = True) -> dict:
-    """One fused forward pass (gpz_svgp_forward).  Returns a dict with mean, scale
-    (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars."""
-    _need_cuda(X, Z, mu, Lu_raw)
-    lib = _lib.load()
+def _problem(spec: KernelSpec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep: list):
+    """Fill a gpz_svgp_problem from tensors (inputs only); returns (problem, prepared tensors)."""
     dt = X.dtype
-    keep: list = []
     X = X.detach().contiguous()
     Z = Z.detach().to(dt).contiguous()
     L = spec.L
@@ -193,6 +186,20 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
         gZ = gZ.detach().to(device=dev, dtype=torch.int64).contiguous()
         p.gX, p.gZ = gX.data_ptr(), gZ.data_ptr()
     p.jitter, p.var_clamp_min = float(jitter), float(clamp_min)
+    keep.extend([X, Z, mu, Lu_raw, gX, gZ])
+    return p, (L, M, N, dt, dev)
+
+
+def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, *, gX=None, gZ=None,
+                 y=None, noise_sd: Optional[float] = None, clamp_min: float = 1e-6, chunk: int = 0,
+                 want_moments: bool = True, want_Lu: bool = True, want_chol: bool = False,
+                 check_info: bool = True) -> dict:
+    """One fused forward pass (gpz_svgp_forward).  Returns a dict with mean, scale
+    (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars."""
+    _need_cuda(X, Z, mu, Lu_raw)
+    lib = _lib.load()
+    keep: list = []
+    p, (L, M, N, dt, dev) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
     out = {}
     if y is not None:
         y = y.detach().to(dt).reshape(L, N).contiguous()
@@ -222,6 +229,32 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     out["kl"], out["loglik"], out["elbo"] = scal[:L], scal[L:2 * L], scal[2 * L]
     out["info"] = info
     return out
+
+
+def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
+                  gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0):
+    """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) for frozen kernel hyper-parameters (gpz_svgp_backward)."""
+    _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
+    lib = _lib.load()
+    keep: list = []
+    p, (L, M, N, dt, dev) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
+    info = torch.empty(L, dtype=torch.int32, device=dev)
+    p.info = info.data_ptr()
+    g = _lib.SvgpGrads()
+    gm = g_mean.detach().to(dt).reshape(L, N).contiguous()
+    gs = g_scale.detach().to(dt).reshape(L, N).contiguous()
+    sc = scale.detach().to(dt).reshape(L, N).contiguous()
+    grad_mu = torch.empty((L, M), dtype=dt, device=dev)
+    grad_Lu = torch.empty((L, M, M), dtype=dt, device=dev)
+    g.g_mean, g.g_scale, g.scale = gm.data_ptr(), gs.data_ptr(), sc.data_ptr()
+    g.grad_mu, g.grad_Lu_raw = grad_mu.data_ptr(), grad_Lu.data_ptr()
+    nbytes = lib.gpz_svgp_backward_workspace_bytes(C.byref(p), int(chunk))
+    if nbytes == 0:
+        _lib.check(-1, "gpz_svgp_backward_workspace_bytes")
+    ws = _workspace(dev, nbytes)
+    rc = lib.gpz_svgp_backward(C.byref(p), C.byref(g), int(chunk), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "gpz_svgp_backward")
+    return grad_mu, grad_Lu
 
 
 def wsvgp_precomputed(W, sigma, mu, Lu_raw) -> dict:

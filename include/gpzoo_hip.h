@@ -131,6 +131,24 @@ size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
 int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes,
                      void* stream);
 
+/* Backward of gpz_svgp_forward for FROZEN kernel hyper-parameters (Z, sigma, lengthscale,
+ * group parameters; the training mode of Slideseq_NSF_newest_version.ipynb:500-504): given
+ * dLoss/dmean and dLoss/dscale of q(F) (and the forward's scale) writes dLoss/dmu (L,M) and
+ * dLoss/dLu_raw (L,M,M) -- what torch autograd produces through gp.py:276-296 / 218-228 for
+ * loss.backward() (utilities.py:485).  Same problem description as the forward; its output
+ * fields are ignored. */
+typedef struct gpz_svgp_grads {
+  const void* g_mean;    /* (L,N) dtype */
+  const void* g_scale;   /* (L,N) dtype */
+  const void* scale;     /* (L,N) dtype: forward output */
+  void* grad_mu;         /* (L,M) dtype */
+  void* grad_Lu_raw;     /* (L,M,M) dtype, zeros above the diagonal */
+} gpz_svgp_grads;
+
+size_t gpz_svgp_backward_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
+int gpz_svgp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int64_t chunk, void* ws,
+                      size_t ws_bytes, void* stream);
+
 /* Moments from a caller-supplied W (L,N,M): WSVGP.forward_precomputed, gp.py:308-322
  * (cov = clamp(sigma^2 - sum W^2, 0) + sum (W Lu)^2, mean = W mu).  sigma (L,), mu (L,M),
  * Lu_raw (L,M,M) -> mean, scale (L,N) and the constrained Lu (L,M,M, may be NULL). */

@@ -10,7 +10,8 @@ inputs + outputs as .npz next to this script.  The fixtures are data only.
 
 Stored per case: inputs (X, y, Z, groups, sigma, lengthscale, a, embedding, mu,
 Lu_raw, jitter, noise_sd) and reference outputs (Kxx, Kzx, Kzz_jit, chol, mean,
-scale, Lu, kl, elbo).  The reference has no tests of its own, so these pin the
+scale, Lu, kl, elbo, and the gradients of -ELBO w.r.t. mu and Lu from the reference's
+own autograd graph).  The reference has no tests of its own, so these pin the
 oracle (tests/test_oracle_golden.py) and the HIP path (tests/test_hip_golden.py)
 to torch 2.10.0's CPU arithmetic run through the reference's code.
 """
@@ -104,7 +105,21 @@ def run_case(name, gp_cls, kern, inp, dtype, jitter, noise_sd, whitened, mggp):
         else:
             kl = distributions.kl_divergence(qU, pU)
         elbo = pY.log_prob(y).double().sum() - (qF.scale.double() ** 2).sum() / (2 * s.double() ** 2) - kl.double().sum()
+    # gradients of -ELBO w.r.t. mu and Lu through the reference's own autograd graph (loss.backward(),
+    # utilities.py:485): goldens for the backward pass
+    model.zero_grad()
+    pY_g, qF_g, qU_g, pU_g = model(X=X, E=1, **fkw)
+    s_g = torch.nn.functional.softplus(model.noise)
+    if whitened:
+        kl_g = (whitened_KL(qU_g.mean, qU_g.scale_tril) if qU_g.mean.dim() == 1 else
+                torch.stack([whitened_KL(qU_g.mean[l], qU_g.scale_tril[l]) for l in range(qU_g.mean.shape[0])]).sum())
+    else:
+        kl_g = distributions.kl_divergence(qU_g, pU_g).sum()
+    loss = -(pY_g.log_prob(y).sum() - (qF_g.scale ** 2).sum() / (2 * s_g ** 2) - kl_g)
+    loss.backward()
+    grad_mu, grad_Lu = gp.mu.grad.detach().clone(), gp.Lu.grad.detach().clone()
     out = {k: v.to(dtype).numpy() if v.is_floating_point() else v.numpy() for k, v in inp.items()}
+    out.update(grad_mu=grad_mu.numpy(), grad_Lu=grad_Lu.numpy())
     out.update(
         sigma=kern.sigma.detach().numpy(), lengthscale=kern.lengthscale.detach().numpy(),
         jitter=np.float64(jitter), noise_sd=np.float64(float(s)),
