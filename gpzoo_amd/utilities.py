@@ -67,3 +67,46 @@ def svgp_forward(Kxx, Kzz, W, inducing_mean, inducing_cov):
     mean = W @ inducing_mean.unsqueeze(-1)
     cov = Kxx + ((W @ (inducing_cov - Kzz)) * W).sum(-1)
     return mean, cov
+
+
+def _elbo_terms(model, X, y, E, **kwargs):
+    """-ELBO of one step in the reference's Monte-Carlo form (utilities.py:479-481):
+    mean over E samples of log p(y | F), minus KL(qU || pU) (whitened KL when pU is None)."""
+    from torch import distributions
+    pY, _, qU, pU = model(X=X, E=E, **kwargs)
+    loglik = pY.log_prob(y).mean(dim=0).sum() if pY.loc.dim() > y.dim() else pY.log_prob(y).sum()
+    kl = whitened_KL_batched(qU.mean, qU.scale_tril).sum() if pU is None else distributions.kl_divergence(qU, pU).sum()
+    return -(loglik - kl)
+
+
+def train(model, optimizer, X, y, device=None, steps=200, E=20, **kwargs):
+    """Full-batch optimisation loop with the reference's signature (utilities.py:471-493).  The
+    forward and the mu / Lu gradients run on the fused HIP path; the optimiser step is torch's.
+    Returns the list of losses (one host sync per step, as in the reference)."""
+    losses = []
+    for _ in range(steps):
+        optimizer.zero_grad()
+        loss = _elbo_terms(model, X, y, E, **kwargs)
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.item())
+    return losses
+
+
+def train_batched(model, optimizer, X, y, device=None, steps=200, E=20, batch_size=1000, **kwargs):
+    """Mini-batched variant (reference utilities.py:600-632 shape): a fresh random subset of
+    `batch_size` spots per step, log-likelihood rescaled by N / batch_size is NOT applied, like
+    the reference."""
+    losses = []
+    N = X.shape[0]
+    for _ in range(steps):
+        idx = torch.multinomial(torch.ones(N, device=X.device), min(batch_size, N), replacement=False)
+        optimizer.zero_grad()
+        kw = dict(kwargs)
+        if "groupsX" in kw:
+            kw["groupsX"] = kw["groupsX"][idx]
+        loss = _elbo_terms(model, X[idx], y[..., idx], E, **kw)
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.item())
+    return losses

@@ -61,3 +61,28 @@ def test_backward_multi_chunk_matches_single_chunk():
     ((mean * gm.cpu()).sum() + (scale * gs.cpu()).sum()).backward()
     torch.testing.assert_close(a[0].cpu(), mu.grad, rtol=1e-8, atol=1e-8)
     torch.testing.assert_close(a[1].cpu(), Lur.grad, rtol=1e-8, atol=1e-8)
+
+
+def test_train_loop_decreases_loss():
+    """A few Adam steps through gpzoo.utilities.train (reference signature) on the fused path."""
+    import torch.nn as nn
+    from gpzoo.gp import WSVGP
+    from gpzoo.kernels import NSF_RBF
+    from gpzoo.likelihoods import GaussianLikelihood
+    from gpzoo.utilities import train, train_batched
+    torch.manual_seed(0)
+    N, M, L = 600, 40, 2
+    X = (torch.rand(N, 2) * 20 - 10)
+    y = torch.stack([torch.sin(X[:, 0] / 3), torch.cos(X[:, 1] / 4)]) + 0.1 * torch.randn(L, N)
+    gp = WSVGP(NSF_RBF(sigma=1.0, lengthscale=3.0, L=L), dim=2, M=M, jitter=1e-2)
+    gp.Z = nn.Parameter(X[:M].clone(), requires_grad=False)
+    gp.mu = nn.Parameter(torch.zeros(L, M))
+    gp.Lu = nn.Parameter(0.01 * torch.randn(L, M, M))
+    for t in gp.kernel.parameters():
+        t.requires_grad_(False)
+    model = GaussianLikelihood(gp, noise=0.5).cuda()
+    opt = torch.optim.Adam([gp.mu, gp.Lu], lr=5e-2)
+    losses = train(model, opt, X.cuda(), y.cuda(), torch.device("cuda"), steps=40, E=4)
+    assert losses[-1] < 0.7 * losses[0]
+    losses_b = train_batched(model, opt, X.cuda(), y.cuda(), torch.device("cuda"), steps=5, E=2, batch_size=200)
+    assert all(map(lambda v: v == v, losses_b))
