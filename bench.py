@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="spots in the CPU-baseline sample")
+    ap.add_argument("--with-backward", action="store_true",
+                    help="also time one forward + backward (mu, Lu gradients) pass, outside the timed region")
     return ap.parse_args()
 
 
@@ -167,6 +169,21 @@ def main():
     t = float(tmax)
     elbo = float(elbo)
 
+    train_ms = None
+    if a.with_backward:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(2):
+            ev0.record()
+            o = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], chunk=a.chunk,
+                                 want_Lu=False, **extra)
+            gmean = (o["mean"] - g["y"]) / c["noise_sd"] ** 2          # d(-ELBO)/dmean of the Gaussian closed form
+            gscale = o["scale"] / c["noise_sd"] ** 2                     # d(-ELBO)/dscale
+            ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], gmean, gscale,
+                              o["scale"], chunk=a.chunk, **extra)
+            ev1.record()
+            torch.cuda.synchronize()
+            train_ms = ev0.elapsed_time(ev1)
+
     if rank == 0:
         Mp = (M + 127) // 128 * 128
         ms1, n1 = prof["stage1"]
@@ -208,6 +225,8 @@ def main():
                        "whitened": bool(c["whitened"]), "chunk": a.chunk, "factor_dtype": "f64"},
             "elbo": elbo, "roofline": roof, "kernels": sub,
         }
+        if train_ms is not None:
+            res["forward_backward_ms"] = train_ms
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg_id, c, a.cpu_sample)
         elif not a.no_cpu_baseline:
