@@ -107,3 +107,37 @@ def test_padding_invariance_in_M():
     """M=2000 is padded to 2048 internally: same answer as the oracle's un-padded arithmetic."""
     from gpzoo_amd.synthetic import make_config
     check(make_config(3, N=3000, M=2000, L=2), 1e-3)
+
+
+def test_many_latents_and_odd_input_dims():
+    """L > 256 exercises the per-launch latent batching of the fill; d = 1 and d = 3 inputs."""
+    import torch
+    from gpzoo_amd import _lib, ops
+    from gpzoo_amd.ops import KernelSpec
+    from oracle import svgp_oracle as O
+    g = torch.Generator().manual_seed(3)
+    for d, L in ((1, 300), (3, 5)):
+        X = torch.randn(90, d, generator=g, dtype=torch.float64) * 3
+        Z = torch.randn(20, d, generator=g, dtype=torch.float64) * 3
+        sig = 0.5 + torch.rand(L, generator=g, dtype=torch.float64)
+        ell = 1.0 + 3 * torch.rand(L, generator=g, dtype=torch.float64)
+        for kind, name in ((_lib.KERNEL_RBF, "batched_rbf"), (_lib.KERNEL_MATERN32, "matern32")):
+            K = ops.kfill(KernelSpec(kind, sig.cuda(), ell.cuda(), True), Z.cuda(), X.cuda())
+            torch.testing.assert_close(K.cpu(), O.kernel_matrix(name, Z, X, sig, ell), rtol=1e-10, atol=1e-12)
+        mu = torch.randn(L, 20, generator=g, dtype=torch.float64)
+        Lu = 0.1 * torch.randn(L, 20, 20, generator=g, dtype=torch.float64)
+        y = torch.randn(L, 90, generator=g, dtype=torch.float64)
+        out = ops.svgp_forward(KernelSpec(_lib.KERNEL_RBF, sig.cuda(), ell.cuda(), True), X.cuda(), Z.cuda(), mu.cuda(),
+                               Lu.cuda(), 1e-2, True, y=y.cuda(), noise_sd=0.7)
+        ref, mean, scale = O.elbo_eval("batched_rbf", True, X, y, Z, sig, ell, mu, Lu, 1e-2, 0.7)
+        assert float(out["elbo"]) == pytest.approx(float(ref), rel=1e-8)
+        torch.testing.assert_close(out["scale"].cpu(), scale, rtol=1e-7, atol=1e-9)
+
+
+def test_fp32_ill_conditioned_stays_within_tolerance():
+    """Small jitter (cond(Kzz) ~ 1e4): the fp32 path keeps 1e-3 against the fp64 oracle because
+    Kzz, its factor and inverse are carried in fp64."""
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(3, N=4000, M=512, L=2)
+    c["jitter"] = 1e-3
+    check(c, 1e-3)
