@@ -314,6 +314,23 @@ struct Buffers {
   size_t bytes;
 };
 
+// The factor cache holds what depends only on (Z, kernel hyper-parameters, jitter): the Cholesky
+// factor of Kzz, its inverse in fp64 and in GEMM precision, and sum(log diag L) per latent.
+template <typename T>
+struct FactorCache { double *Kzz, *Linv, *logdiag; T* LinvG; size_t bytes; };
+template <typename T>
+static FactorCache<T> carve_cache(const Plan& pl, void* mem) {
+  FactorCache<T> f;
+  Carver c(mem);
+  const int64_t mm = pl.L * pl.Mp * pl.Mp;
+  f.Kzz = c.take<double>(mm);
+  f.Linv = c.take<double>(mm);
+  f.LinvG = sizeof(T) == 8 ? reinterpret_cast<T*>(f.Linv) : c.take<T>(mm);
+  f.logdiag = c.take<double>(pl.L);
+  f.bytes = c.used();
+  return f;
+}
+
 template <typename T>
 static Buffers<T> carve(const Plan& pl, bool whitened, void* ws) {
   Buffers<T> b;
@@ -350,18 +367,31 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
   const bool wh = p->whitened != 0;
   const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, mm = Mp * Mp;
   const int L32 = (int)L;
-  // 1. Kzz + jitter I (fp64, identity padded), Cholesky, inverse
-  if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, p->gZ, p->gZ, b.Kzz, Mp, mm, p->jitter, 1,
-                            GPZ_F64, s))
-    return rc;
-  if (int rc = potrf_padded(b.Kzz, Mp, Mp, mm, L, M, b.Dinv, p->info, s)) return rc;
-  hipLaunchKernelGGL((chol_out_kernel<T>), dim3(p->chol ? 64 : 1, L32), dim3(256), 0, s, b.Kzz, Mp, M,
-                     static_cast<T*>(p->chol), b.chol_logdiag);
-  GPZ_LAUNCH_OK();
-  if (int rc = trtri_padded(b.Kzz, Mp, mm, b.Dinv, b.Linv, Mp, L, b.Tmp, s)) return rc;
-  if (sizeof(T) == 4) {
-    hipLaunchKernelGGL((cast_kernel<T>), dim3(2048), dim3(256), 0, s, b.Linv, b.LinvG, L * mm);
+  // 1. Kzz + jitter I (fp64, identity padded), Cholesky, inverse -- or the caller's cached copy
+  if (p->factor_cache) {
+    FactorCache<T> f = carve_cache<T>(pl, p->factor_cache);
+    b.Kzz = f.Kzz; b.Linv = f.Linv; b.LinvG = f.LinvG; b.chol_logdiag = f.logdiag;
+  }
+  if (!(p->factor_cache && p->factor_cache_valid)) {
+    if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, p->gZ, p->gZ, b.Kzz, Mp, mm, p->jitter, 1,
+                              GPZ_F64, s))
+      return rc;
+    if (int rc = potrf_padded(b.Kzz, Mp, Mp, mm, L, M, b.Dinv, p->info, s)) return rc;
+    hipLaunchKernelGGL((chol_out_kernel<T>), dim3(p->chol ? 64 : 1, L32), dim3(256), 0, s, b.Kzz, Mp, M,
+                       static_cast<T*>(p->chol), b.chol_logdiag);
     GPZ_LAUNCH_OK();
+    if (int rc = trtri_padded(b.Kzz, Mp, mm, b.Dinv, b.Linv, Mp, L, b.Tmp, s)) return rc;
+    if (sizeof(T) == 4) {
+      hipLaunchKernelGGL((cast_kernel<T>), dim3(2048), dim3(256), 0, s, b.Linv, b.LinvG, L * mm);
+      GPZ_LAUNCH_OK();
+    }
+  } else {
+    GPZ_HIP_OK(hipMemsetAsync(p->info, 0, sizeof(int32_t) * L, s));
+    if (p->chol) {
+      hipLaunchKernelGGL((chol_out_kernel<T>), dim3(64, L32), dim3(256), 0, s, b.Kzz, Mp, M, static_cast<T*>(p->chol),
+                         b.chol_logdiag);
+      GPZ_LAUNCH_OK();
+    }
   }
 
   // 2. q(U) parameters in the form the two products need
@@ -826,4 +856,10 @@ extern "C" int gpz_svgp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads
   hipStream_t s = static_cast<hipStream_t>(stream);
   return p->dtype == GPZ_F32 ? svgp_backward_t<float>(p, g, chunk, ws, ws_bytes, s)
                              : svgp_backward_t<double>(p, g, chunk, ws, ws_bytes, s);
+}
+
+extern "C" size_t gpz_svgp_factor_cache_bytes(const gpz_svgp_problem* p) {
+  if (check_problem(p)) return 0;
+  const Plan pl = make_plan(p, 0);
+  return p->dtype == GPZ_F32 ? carve_cache<float>(pl, nullptr).bytes : carve_cache<double>(pl, nullptr).bytes;
 }

@@ -85,6 +85,18 @@ class _FusedGP(nn.Module):
     def _latents(self) -> int:
         return 1 if self.mu.dim() == 1 else int(self.mu.shape[0])
 
+    def _cache_args(self, spec, X) -> dict:
+        """Factor cache keyed on everything chol(Kzz) depends on (identity + in-place version of Z and
+        the kernel tensors, jitter, dtype): frozen hyper-parameters => one factorisation per model,
+        not one per step.  ``gp.cache_factor = False`` restores the
+        reference's recompute-every-call behaviour."""
+        if not getattr(self, "cache_factor", True):
+            return {}
+        cache = self.__dict__.setdefault("_factor_cache", ops.FactorCache())
+        deps = [self.Z, *self.kernel.parameters(), getattr(self.kernel, "embedding", None),
+                getattr(self, "groupsZ", None)]
+        return dict(cache=cache, cache_key=ops.factor_key(spec, self.Z, self.jitter, X.dtype, deps))
+
     def _evaluate(self, X, groupsX=None, y=None, noise_sd=None, want_moments=True, want_Lu=True,
                   want_chol=False, chunk=0):
         spec = kernel_spec(self.kernel, X, self._latents())
@@ -93,7 +105,8 @@ class _FusedGP(nn.Module):
         gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
         return spec, ops.svgp_forward(spec, X, self.Z, self.mu, self.Lu, float(self.jitter), self._whitened,
                                       y=y, noise_sd=noise_sd, clamp_min=self._clamp_min, chunk=chunk,
-                                      want_moments=want_moments, want_Lu=want_Lu, want_chol=want_chol, **gk)
+                                      want_moments=want_moments, want_Lu=want_Lu, want_chol=want_chol,
+                                      **self._cache_args(spec, X), **gk)
 
     def _distributions(self, out):
         single = self.mu.dim() == 1
@@ -120,7 +133,7 @@ class _FusedGP(nn.Module):
         spec = kernel_spec(self.kernel, X, self._latents())
         gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
         args = (spec, X, self.Z)
-        common = dict(clamp_min=self._clamp_min, **gk)
+        common = dict(clamp_min=self._clamp_min, **self._cache_args(spec, X), **gk)
 
         def fwd(mu, Lu_raw):
             return ops.svgp_forward(*args, mu, Lu_raw, float(self.jitter), self._whitened,

@@ -166,6 +166,36 @@ def solve_triangular_lower(Lc: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return Bw.to(dt).reshape(B.shape)
 
 
+class FactorCache:
+    """Device buffer for chol(Kzz), its inverse and log-determinant, valid for one key.
+
+    The key is built by the caller from the identities and in-place version counters of every tensor
+    the factor depends on (Z, sigma, lengthscale, group parameters) plus jitter/dtype/shape, so an
+    optimiser step, a parameter replacement or a jitter change invalidates it (SURVEY §8f "next" #3:
+    the reference refactors Kzz every step even when those are frozen)."""
+
+    def __init__(self):
+        self.buf = None
+        self.key = None
+
+    def attach(self, lib, p: "SvgpProblem", key, device):
+        nbytes = lib.gpz_svgp_factor_cache_bytes(C.byref(p))
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.key = None
+        p.factor_cache = self.buf.data_ptr()
+        p.factor_cache_valid = int(self.key == key)
+        self._pending = key
+
+    def commit(self):
+        self.key = self._pending
+
+
+def factor_key(spec: "KernelSpec", Z, jitter, dtype, tensors) -> tuple:
+    ids = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors if t is not None)
+    return (spec.kind, spec.L, float(spec.group_pow), float(jitter), str(dtype), tuple(Z.shape), ids)
+
+
 def _problem(spec: KernelSpec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep: list):
     """Fill a gpz_svgp_problem from tensors (inputs only); returns (problem, prepared tensors)."""
     dt = X.dtype
@@ -193,7 +223,7 @@ def _problem(spec: KernelSpec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp
 def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, *, gX=None, gZ=None,
                  y=None, noise_sd: Optional[float] = None, clamp_min: float = 1e-6, chunk: int = 0,
                  want_moments: bool = True, want_Lu: bool = True, want_chol: bool = False,
-                 check_info: bool = True) -> dict:
+                 check_info: bool = True, cache: Optional[FactorCache] = None, cache_key=None) -> dict:
     """One fused forward pass (gpz_svgp_forward).  Returns a dict with mean, scale
     (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars."""
     _need_cuda(X, Z, mu, Lu_raw)
@@ -218,6 +248,8 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     info = torch.empty(L, dtype=torch.int32, device=dev)
     p.kl, p.loglik, p.elbo = scal.data_ptr(), scal.data_ptr() + 8 * L, scal.data_ptr() + 16 * L
     p.info = info.data_ptr()
+    if cache is not None:
+        cache.attach(lib, p, cache_key, dev)
     nbytes = lib.gpz_svgp_workspace_bytes(C.byref(p), int(chunk))
     if nbytes == 0:
         _lib.check(-1, "gpz_svgp_workspace_bytes")
@@ -225,14 +257,19 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     rc = lib.gpz_svgp_forward(C.byref(p), int(chunk), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "gpz_svgp_forward")
     if check_info and bool(info.any()):
+        if cache is not None:
+            cache.key = None
         _raise_not_pd(info, "linalg.cholesky")
+    if cache is not None:
+        cache.commit()
     out["kl"], out["loglik"], out["elbo"] = scal[:L], scal[L:2 * L], scal[2 * L]
     out["info"] = info
     return out
 
 
 def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
-                  gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0):
+                  gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0, cache: Optional[FactorCache] = None,
+                  cache_key=None):
     """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) for frozen kernel hyper-parameters (gpz_svgp_backward)."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
     lib = _lib.load()
@@ -248,12 +285,16 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     grad_Lu = torch.empty((L, M, M), dtype=dt, device=dev)
     g.g_mean, g.g_scale, g.scale = gm.data_ptr(), gs.data_ptr(), sc.data_ptr()
     g.grad_mu, g.grad_Lu_raw = grad_mu.data_ptr(), grad_Lu.data_ptr()
+    if cache is not None:
+        cache.attach(lib, p, cache_key, dev)
     nbytes = lib.gpz_svgp_backward_workspace_bytes(C.byref(p), int(chunk))
     if nbytes == 0:
         _lib.check(-1, "gpz_svgp_backward_workspace_bytes")
     ws = _workspace(dev, nbytes)
     rc = lib.gpz_svgp_backward(C.byref(p), C.byref(g), int(chunk), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "gpz_svgp_backward")
+    if cache is not None:
+        cache.commit()
     return grad_mu, grad_Lu
 
 

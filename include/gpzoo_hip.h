@@ -125,7 +125,16 @@ typedef struct gpz_svgp_problem {
   double* loglik;        /* (L,) sum_n log N(y; mean, s^2) - var / (2 s^2) */
   double* elbo;          /* (1,) sum_l loglik - kl */
   int32_t* info;         /* (L,) potrf info */
+  /* optional cache of everything that depends only on (Z, kernel hyper-parameters, jitter):
+   * chol(Kzz), its inverse and sum(log diag).  NULL: recompute every call like the reference
+   * (SURVEY §3.3).  Non-NULL (gpz_svgp_factor_cache_bytes bytes, caller owned): filled when
+   * factor_cache_valid == 0, reused when 1 -- the caller flips the flag and invalidates it when
+   * Z / sigma / lengthscale / group parameters / jitter change (SURVEY §8f "next" #3). */
+  void* factor_cache;
+  int64_t factor_cache_valid;
 } gpz_svgp_problem;
+
+size_t gpz_svgp_factor_cache_bytes(const gpz_svgp_problem* p);
 
 size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
 int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes,

@@ -149,3 +149,31 @@ def test_forward_precomputed(name):
     torch.testing.assert_close(qF.scale.cpu(), c["scale"], rtol=rt, atol=rt * 1e-1)
     torch.testing.assert_close(qU.scale_tril.cpu(), c["Lu"], rtol=rt, atol=rt * 1e-2)
     assert pU is None
+
+
+def test_factor_cache_reuse_and_invalidation():
+    """Frozen hyper-parameters: the second call reuses chol(Kzz)/Linv (bit-identical results); an
+    in-place change of Z, a kernel parameter or jitter invalidates the cache."""
+    c = load_case("svgp_nsf_rbf_f64")
+    model = build("svgp_nsf_rbf_f64", c)
+    gp = model.gp
+    X = c["X"].cuda()
+    with torch.no_grad():
+        a = gp(X)
+        assert gp._factor_cache.key is not None
+        key0 = gp._factor_cache.key
+        b = gp(X)                                          # cache hit
+        assert gp._factor_cache.key == key0
+        assert torch.equal(a[0].mean, b[0].mean) and torch.equal(a[0].scale, b[0].scale)
+        assert torch.equal(a[2].scale_tril, b[2].scale_tril)
+        gp.kernel.lengthscale.mul_(1.5)                    # in-place update, as an optimiser step does
+        d = gp(X)
+        assert gp._factor_cache.key != key0
+        assert not torch.equal(a[0].mean, d[0].mean)
+        gp.cache_factor = False
+        e = gp(X)                                          # recompute-every-call path gives the same numbers
+        assert torch.equal(d[0].mean, e[0].mean) and torch.equal(d[0].scale, e[0].scale)
+        gp.cache_factor = True
+        gp.jitter = 5e-2
+        f = gp(X)
+        assert not torch.equal(d[0].scale, f[0].scale)
