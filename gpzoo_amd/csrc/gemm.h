@@ -21,6 +21,7 @@ enum GemmEpilogue : int {
   EPI_STORE_STATS = 1, // store, plus per-column sum(v^2) and sum(mu[row] * v) over the tile's rows
   EPI_STATS = 2,       // per-column sum(v^2) only, nothing stored
   EPI_STORE_COLSCALE = 3,  // C[i][j] = alpha * colscale[j] * (A op(B))[i][j]   (NN only; backward's P-bar)
+  EPI_WBAR = 4,            // C[i][j] = alpha * acc + rowvec[i] * colvec[j] - aux[i][j] * colscale[j]  (backward's W-bar)
 };
 
 template <typename T>
@@ -39,7 +40,10 @@ struct GemmParams {
   T* ps_sq = nullptr;       // [nb0][mt][ncols]
   T* ps_mu = nullptr;       // [nb0][mt][ncols]
   int64_t ncols = 0;        // nt * 128
-  const T* colscale = nullptr; int64_t sCs = 0;  // EPI_STORE_COLSCALE: (outer batch, ncols) factors
+  const T* colscale = nullptr; int64_t sCs = 0;  // EPI_STORE_COLSCALE / EPI_WBAR: (outer batch, ncols) factors
+  const T* colvec = nullptr;                     // EPI_WBAR: (outer batch, ncols), stride sCs
+  const T* rowvec = nullptr; int64_t sRv = 0;    // EPI_WBAR: (outer batch, rows)
+  const T* aux = nullptr;                        // EPI_WBAR: matrix laid out like C (same ldc / strides)
 };
 
 template <typename T>

@@ -316,8 +316,17 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
 #pragma unroll
         for (int it = 0; it < MPP * 16 / RPI; ++it) {
           const int row = it * RPI + lane / LPR, c4 = (lane % LPR) * VEC;
-          const vec_t v = *reinterpret_cast<const vec_t*>(strip + row * LDE + c4);
-          *reinterpret_cast<vec_t*>(Cg + (crow0 + pass * MPP * 16 + row) * p.ldc + ccol0 + c4) = v;
+          vec_t v = *reinterpret_cast<const vec_t*>(strip + row * LDE + c4);
+          const int64_t grow = crow0 + pass * MPP * 16 + row;
+          if (EPI == EPI_WBAR) {
+            const vec_t w = *reinterpret_cast<const vec_t*>(p.aux + b0 * p.sC0 + b1 * p.sC1 + grow * p.ldc + ccol0 + c4);
+            const vec_t sc = *reinterpret_cast<const vec_t*>(p.colscale + b0 * p.sCs + ccol0 + c4);
+            const vec_t cv = *reinterpret_cast<const vec_t*>(p.colvec + b0 * p.sCs + ccol0 + c4);
+            const T rv = p.rowvec[b0 * p.sRv + grow];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = v[e] + rv * cv[e] - w[e] * sc[e];
+          }
+          *reinterpret_cast<vec_t*>(Cg + grow * p.ldc + ccol0 + c4) = v;
         }
         __syncthreads();
       }
@@ -362,6 +371,10 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   if (epilogue == EPI_STORE)
     return bt ? launch(gemm128_kernel<T, KV, NI, true, EPI_STORE>, gemm_lds_bytes<T, KV, true>())
               : launch(gemm128_kernel<T, KV, NI, false, EPI_STORE>, gemm_lds_bytes<T, KV, false>());
+  if (epilogue == EPI_WBAR) {
+    GPZ_REQUIRE(p.colscale && p.colvec && p.rowvec && p.aux && p.beta == (T)0, "gemm: W-bar epilogue needs its operands");
+    return launch(gemm128_kernel<T, KV, NI, false, EPI_WBAR>, gemm_lds_bytes<T, KV, false>());
+  }
   if (epilogue == EPI_STORE_COLSCALE)
     return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_COLSCALE>, gemm_lds_bytes<T, KV, false>());
   if (epilogue == EPI_STORE_STATS)

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "gemm.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace gpz {
@@ -29,6 +30,18 @@ int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t bat
                  int32_t* info, hipStream_t s);
 int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* Dinv, double* Linv, int64_t Mp,
                  int64_t batch, double* T, hipStream_t s);
+
+struct KgradArgs {
+  const void* Kbar; int64_t ld, stride;
+  const void* Z; const void* X;
+  const int64_t* gZ; const int64_t* gX;
+  const void* sigma; const void* ell; const void* ga; const void* gr2;
+  double gpow, scalar_scale;
+  int64_t M, ncols, Mp;
+  int d, G;
+  double* acc;
+};
+int kgrad_launch(int dtype, int kind, const KgradArgs& a, int L, hipStream_t s);
 
 constexpr int NB = 128;
 
@@ -54,7 +67,8 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 template <typename T>
 __global__ __launch_bounds__(256) void lu_prepare_kernel(const T* __restrict__ raw, int64_t M, int64_t Mp,
                                                         T* __restrict__ LuT, double* __restrict__ LuD,
-                                                        T* __restrict__ LuOut, double* __restrict__ part) {
+                                                        T* __restrict__ LuOut, double* __restrict__ part,
+                                                        T* __restrict__ LuN = nullptr) {
   __shared__ double tile[32][33];
   __shared__ double sh[8];
   const int l = blockIdx.z;
@@ -72,6 +86,7 @@ __global__ __launch_bounds__(256) void lu_prepare_kernel(const T* __restrict__ r
     tile[rr][tx] = v;
     if (LuOut && i < M && j < M) LuOut[(int64_t)l * M * M + i * M + j] = (T)v;
     if (LuD && i < Mp && j < Mp) LuD[(int64_t)l * Mp * Mp + i * Mp + j] = v;
+    if (LuN && i < Mp && j < Mp) LuN[(int64_t)l * Mp * Mp + i * Mp + j] = (T)v;   // padded, lower, not transposed
   }
   __syncthreads();
   if (LuT)
@@ -608,18 +623,124 @@ static int precomputed_t(const void* W, const void* sigma, const void* mu, const
 // stored column-scaled) plus one (M x n)(n x M) accumulation -- 1.5x the forward.
 template <typename T>
 __global__ void colscale_kernel(const T* __restrict__ g_scale, const T* __restrict__ scale, int64_t N, int64_t n0,
-                                int64_t ncp, int whitened, double clamp_min, T* __restrict__ out) {
+                                int64_t ncp, int whitened, double clamp_min, T* __restrict__ out,
+                                const T* __restrict__ g_mean = nullptr, const T* __restrict__ ps1 = nullptr, int mt = 0,
+                                const T* __restrict__ sigma = nullptr, T* __restrict__ out_c = nullptr,
+                                T* __restrict__ out_gm = nullptr) {
   const int l = blockIdx.y;
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= ncp) return;
   const int64_t n = n0 + c;
-  T v = 0;
+  T v = 0, vc = 0, gm = 0;
   if (n < N) {
     const T sc = scale[(int64_t)l * N + n];
     const bool clamped = !whitened && (double)sc * (double)sc <= clamp_min * (1.0 + 1e-6);
     if (sc > (T)0 && !clamped) v = g_scale[(int64_t)l * N + n] / sc;
+    vc = v;
+    if (out_c && whitened) {           // gp.py:287 clamp(Kxx - sum W^2, min=0): no gradient through a clamped term
+      T s1 = 0;
+      for (int i = 0; i < mt; ++i) s1 += ps1[((int64_t)l * mt + i) * ncp + c];
+      const T sg = sigma[l];
+      if (!(sg * sg - s1 > (T)0)) vc = 0;
+    }
+    if (g_mean) gm = g_mean[(int64_t)l * N + n];
   }
   out[(int64_t)l * ncp + c] = v;
+  if (out_c) out_c[(int64_t)l * ncp + c] = vc;
+  if (out_gm) out_gm[(int64_t)l * ncp + c] = gm;
+}
+
+// acc[l] += sigma_l * sum_c csc[l][c]   (d var / d sigma through Kxx = sigma^2; one block per latent)
+template <typename T>
+__global__ __launch_bounds__(256) void sigma_direct_kernel(const T* __restrict__ csc, int64_t ncp,
+                                                          const T* __restrict__ sigma, double* __restrict__ acc) {
+  __shared__ double sh[8];
+  const int l = blockIdx.x;
+  double v = 0.0;
+  for (int64_t c = threadIdx.x; c < ncp; c += 256) v += (double)csc[(int64_t)l * ncp + c];
+  const double t = block_sum(v, sh);
+  if (threadIdx.x == 0) acc[l] += (double)sigma[l] * t;
+}
+
+// dst = transpose(tril(src)) for (L,Mp,Mp) fp64 (src may hold garbage above the diagonal)
+__global__ __launch_bounds__(256) void tril_transpose_kernel(const double* __restrict__ src, int64_t Mp,
+                                                            double* __restrict__ dst) {
+  __shared__ double tile[32][33];
+  const int l = blockIdx.z;
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t i = i0 + rr, j = j0 + tx;
+    tile[rr][tx] = (j <= i) ? src[(int64_t)l * Mp * Mp + i * Mp + j] : 0.0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) dst[(int64_t)l * Mp * Mp + (j0 + rr) * Mp + i0 + tx] = tile[tx][rr];
+}
+
+// Lbar = -tril(GL) (+ tril(upstream dLoss/dchol)) in fp64
+template <typename T>
+__global__ void lbar_kernel(const T* __restrict__ GL, int64_t Mp, int64_t M, const T* __restrict__ g_chol,
+                            double* __restrict__ Lbar) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  double v = 0.0;
+  if (j <= i) {
+    v = -(double)GL[(int64_t)l * Mp * Mp + i * Mp + j];
+    if (g_chol && i < M) v += (double)g_chol[(int64_t)l * M * M + i * M + j];
+  }
+  Lbar[(int64_t)l * Mp * Mp + i * Mp + j] = v;
+}
+
+// Phi: keep the lower triangle, halve the diagonal (Cholesky backward, Murray 2016)
+__global__ void phi_kernel(double* __restrict__ A, int64_t Mp) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  double& v = A[(int64_t)l * Mp * Mp + i * Mp + j];
+  if (j > i) v = 0.0;
+  else if (j == i) v *= 0.5;
+}
+
+// dst = P + P^T, cast to T
+template <typename T>
+__global__ __launch_bounds__(256) void sym_cast_kernel(const double* __restrict__ P, int64_t Mp, T* __restrict__ dst) {
+  __shared__ double tile[32][33];
+  const int l = blockIdx.z;
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) tile[rr][tx] = P[(int64_t)l * Mp * Mp + (j0 + rr) * Mp + i0 + tx];  // P[j][i]
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t i = i0 + rr, j = j0 + tx;
+    dst[(int64_t)l * Mp * Mp + i * Mp + j] = (T)(P[(int64_t)l * Mp * Mp + i * Mp + j] + tile[tx][rr]);
+  }
+}
+
+// grad_Z[m][k] = sum_l acc[l][m][k];  grad_theta[l][0..2] = sum_m acc[l][m][4..6] (+ direct sigma term)
+__global__ __launch_bounds__(256) void kgrad_finish_kernel(const double* __restrict__ acc, int L, int64_t Mp, int64_t M,
+                                                          int d, const double* __restrict__ sig_direct,
+                                                          double* __restrict__ grad_Z, double* __restrict__ grad_theta) {
+  __shared__ double sh[8];
+  if (blockIdx.y == 0) {            // Z rows
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < M && grad_Z)
+      for (int k = 0; k < 4; ++k) {
+        double t = 0.0;
+        if (k < d)
+          for (int l = 0; l < L; ++l) t += acc[((int64_t)l * Mp + m) * 8 + k];
+        grad_Z[m * 4 + k] = t;
+      }
+  } else if ((int)blockIdx.x < L && grad_theta) {   // one block per latent
+    const int l = blockIdx.x;
+    for (int q = 0; q < 3; ++q) {
+      double v = 0.0;
+      for (int64_t m = threadIdx.x; m < M; m += 256) v += acc[((int64_t)l * Mp + m) * 8 + 4 + q];
+      const double t = block_sum(v, sh);
+      if (threadIdx.x == 0) grad_theta[l * 4 + q] = t + (q == 0 ? sig_direct[l] : 0.0);
+    }
+    if (threadIdx.x == 0) grad_theta[l * 4 + 3] = 0.0;
+  }
 }
 
 // part[l][ci][m] = sum_c Wt[l][m][c] * g_mean[l][n0 + c]   (one wave per row)
@@ -689,10 +810,15 @@ __global__ void lu_grad_kernel(const T* __restrict__ G, int64_t Mp, int64_t M, c
 }
 
 template <typename T>
-struct BwdBuffers { T *Pc, *G, *G2, *LinvT, *cs; double *mu_part, *mu_sum; size_t bytes; };
+struct BwdBuffers {
+  T *Pc, *G, *G2, *LinvT, *cs; double *mu_part, *mu_sum;
+  // kernel / Z gradients only
+  T *LuN, *GL, *csc, *gmc, *PS; double *D1, *D2, *D3, *kacc, *sig_direct;
+  size_t bytes;
+};
 
 template <typename T>
-static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, void* ws, size_t offset) {
+static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* ws, size_t offset) {
   BwdBuffers<T> b;
   Carver c(ws);
   c.off = offset;
@@ -700,10 +826,24 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, void* ws, size_t o
   b.Pc = c.take<T>(pl.L * pl.Mp * pl.nc);
   b.G = c.take<T>(mm);
   b.G2 = whitened ? nullptr : c.take<T>(mm);
-  b.LinvT = whitened ? nullptr : c.take<T>(mm);
+  b.LinvT = (whitened && !full) ? nullptr : c.take<T>(mm);
   b.cs = c.take<T>(pl.L * pl.nc);
   b.mu_part = c.take<double>(pl.L * pl.nchunks * pl.Mp);
   b.mu_sum = c.take<double>(pl.L * pl.Mp);
+  b.LuN = b.GL = b.csc = b.gmc = b.PS = nullptr;
+  b.D1 = b.D2 = b.D3 = b.kacc = b.sig_direct = nullptr;
+  if (full) {
+    b.LuN = c.take<T>(mm);
+    b.GL = c.take<T>(mm);
+    b.PS = c.take<T>(mm);
+    b.csc = c.take<T>(pl.L * pl.nc);
+    b.gmc = c.take<T>(pl.L * pl.nc);
+    b.D1 = c.take<double>(mm);
+    b.D2 = c.take<double>(mm);
+    b.D3 = c.take<double>(mm);
+    b.kacc = c.take<double>(pl.L * pl.Mp * 8);
+    b.sig_direct = c.take<double>(pl.L);
+  }
   b.bytes = c.used();
   return b;
 }
@@ -713,8 +853,10 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
                            hipStream_t s) {
   const Plan pl = make_plan(p, chunk);
   const bool wh = p->whitened != 0;
+  const bool full = g->grad_theta != nullptr || g->grad_Z != nullptr;   // kernel hyper-parameter / Z gradients
+  GPZ_REQUIRE(!(full && !wh), "gpz_svgp_backward: kernel / Z gradients are implemented for the whitened path only");
   Buffers<T> b = carve<T>(pl, wh, ws);
-  BwdBuffers<T> w = carve_bwd<T>(pl, wh, ws, b.bytes);
+  BwdBuffers<T> w = carve_bwd<T>(pl, wh, full, ws, b.bytes);
   GPZ_REQUIRE(ws_bytes >= w.bytes, "gpz_svgp_backward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
   const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, N = pl.N, mm = Mp * Mp;
   const int L32 = (int)L;
@@ -722,6 +864,19 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   q.chol = nullptr; q.Lu = nullptr;
   if (int rc = prepare_t<T>(&q, pl, b, s)) return rc;
   GPZ_HIP_OK(hipMemsetAsync(w.G, 0, sizeof(T) * L * mm, s));
+  const dim3 g32((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32);
+  const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
+  if (full) {
+    GPZ_HIP_OK(hipMemsetAsync(w.GL, 0, sizeof(T) * L * mm, s));
+    GPZ_HIP_OK(hipMemsetAsync(w.kacc, 0, sizeof(double) * L * Mp * 8, s));
+    GPZ_HIP_OK(hipMemsetAsync(w.sig_direct, 0, sizeof(double) * L, s));
+    // Lu (lower, not transposed) in GEMM precision and Linv^T
+    hipLaunchKernelGGL((lu_prepare_kernel<T>), g32, dim3(256), 0, s, static_cast<const T*>(p->Lu_raw), M, Mp,
+                       (T*)nullptr, (double*)nullptr, (T*)nullptr, b.lu_part, w.LuN);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL((transpose_cast_kernel<T>), g32, dim3(256), 0, s, b.Linv, Mp, w.LinvT, (double*)w.D1);
+    GPZ_LAUNCH_OK();
+  }
   static const int super_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 16; }();
   const int64_t esz = sizeof(T);
   for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
@@ -729,20 +884,21 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
     const int64_t ncp = pad_up(nreal);
     const int nt = (int)(ncp / NB);
-    if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
-                              p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
-                              pl.f32 ? GPZ_F32 : GPZ_F64, s))
+    const void* Xc = static_cast<const char*>(p->X) + n0 * p->d * esz;
+    if (int rc = kfill_padded(&p->k, p->Z, M, Mp, Xc, nreal, ncp, p->d, p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp,
+                              Mp * ncp, 0.0, 0, pl.f32 ? GPZ_F32 : GPZ_F64, s))
       return rc;
-    GemmParams<T> g1;  // W = Linv * Kzx
+    GemmParams<T> g1;  // W = Linv * Kzx (column sums of W^2 only when the clamp mask is needed)
     g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
     g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
     g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
     g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
-    g1.super_cols = super_cols;
-    if (int rc = gemm_launch(g1, EPI_STORE, s)) return rc;
+    g1.super_cols = super_cols; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
+    if (int rc = gemm_launch(g1, full ? EPI_STORE_STATS : EPI_STORE, s)) return rc;
     hipLaunchKernelGGL((colscale_kernel<T>), dim3((unsigned)((ncp + 255) / 256), L32), dim3(256), 0, s,
                        static_cast<const T*>(g->g_scale), static_cast<const T*>(g->scale), N, n0, ncp, (int)wh,
-                       p->var_clamp_min, w.cs);
+                       p->var_clamp_min, w.cs, static_cast<const T*>(g->g_mean), (const T*)b.ps1, (int)pl.nblk,
+                       static_cast<const T*>(p->k.sigma), w.csc, w.gmc);
     GPZ_LAUNCH_OK();
     GemmParams<T> g2;  // Pbar = (LuE^T W) diag(gv2)
     g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
@@ -761,6 +917,40 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Wc, Mp, ncp,
                        static_cast<const T*>(g->g_mean), N, n0, w.mu_part, pl.nchunks, ci);
     GPZ_LAUNCH_OK();
+    if (full) {
+      // Wbar = Lu Pbar - W diag(gv2 c) + mu gm^T            (into the Kzx buffer, no longer needed)
+      GemmParams<T> g4;
+      g4.A = w.LuN; g4.lda = Mp; g4.sA0 = mm;
+      g4.B = w.Pc; g4.ldb = ncp; g4.sB0 = Mp * ncp;
+      g4.C = b.Kc; g4.ldc = ncp; g4.sC0 = Mp * ncp;
+      g4.nb0 = L32; g4.mt = (int)pl.nblk; g4.nt = nt; g4.K = (int)Mp; g4.flags = GF_A_LOWER | GF_GROUP_COLS;
+      g4.super_cols = super_cols; g4.colscale = w.csc; g4.colvec = w.gmc; g4.sCs = ncp; g4.rowvec = b.muE; g4.sRv = Mp;
+      g4.aux = b.Wc; g4.ncols = ncp;
+      if (int rc = gemm_launch(g4, EPI_WBAR, s)) return rc;
+      // Kbar_x = Linv^T Wbar                                   (into the Pbar buffer)
+      GemmParams<T> g5;
+      g5.A = w.LinvT; g5.lda = Mp; g5.sA0 = mm;
+      g5.B = b.Kc; g5.ldb = ncp; g5.sB0 = Mp * ncp;
+      g5.C = w.Pc; g5.ldc = ncp; g5.sC0 = Mp * ncp;
+      g5.nb0 = L32; g5.mt = (int)pl.nblk; g5.nt = nt; g5.K = (int)Mp; g5.flags = GF_A_UPPER | GF_GROUP_COLS;
+      g5.super_cols = super_cols;
+      if (int rc = gemm_launch(g5, EPI_STORE, s)) return rc;
+      // GL += Kbar_x W^T  (lower tiles):  dLoss/dL = -tril(GL)
+      GemmParams<T> g6 = g3;
+      g6.A = w.Pc; g6.B = b.Wc; g6.C = w.GL;
+      if (int rc = gemm_launch(g6, EPI_STORE, s)) return rc;
+      // kernel hyper-parameter and Z gradients from Kbar_x
+      KgradArgs ka;
+      ka.Kbar = w.Pc; ka.ld = ncp; ka.stride = Mp * ncp; ka.Z = p->Z; ka.X = Xc;
+      ka.gZ = p->gZ; ka.gX = p->gX ? p->gX + n0 : nullptr;
+      ka.sigma = p->k.sigma; ka.ell = p->k.lengthscale; ka.ga = p->k.group_a; ka.gr2 = p->k.group_r2;
+      ka.gpow = p->k.group_pow; ka.scalar_scale = 1.0; ka.M = M; ka.ncols = nreal; ka.Mp = Mp; ka.d = p->d;
+      ka.G = p->k.n_groups; ka.acc = w.kacc;
+      if (int rc = kgrad_launch(p->dtype, p->k.kind, ka, L32, s)) return rc;
+      hipLaunchKernelGGL((sigma_direct_kernel<T>), dim3(L32), dim3(256), 0, s, w.csc, ncp,
+                         static_cast<const T*>(p->k.sigma), w.sig_direct);
+      GPZ_LAUNCH_OK();
+    }
   }
   hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.mu_part, pl.nchunks,
                      Mp, w.mu_sum);
@@ -768,14 +958,12 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   hipLaunchKernelGGL((mu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, w.mu_sum,
                      wh ? (const double*)nullptr : b.Linv, Mp, M, static_cast<T*>(g->grad_mu));
   GPZ_LAUNCH_OK();
-  const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
   T* Gfin = w.G;
   if (!wh) {
     // dLoss/dLu = tril(Linv^T tril(dLoss/dLuE))
     hipLaunchKernelGGL((tril_kernel<T>), gm, dim3(256), 0, s, w.G, Mp);
     GPZ_LAUNCH_OK();
-    hipLaunchKernelGGL((transpose_cast_kernel<T>), dim3((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32), dim3(256), 0, s,
-                       b.Linv, Mp, w.LinvT, b.fro_part);   // fro_part is scratch here
+    hipLaunchKernelGGL((transpose_cast_kernel<T>), g32, dim3(256), 0, s, b.Linv, Mp, w.LinvT, b.fro_part);
     GPZ_LAUNCH_OK();
     GPZ_HIP_OK(hipMemsetAsync(w.G2, 0, sizeof(T) * L * mm, s));
     GemmParams<T> g4;
@@ -789,6 +977,39 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   hipLaunchKernelGGL((lu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)M, L32), dim3(256), 0, s, Gfin, Mp,
                      M, static_cast<const T*>(p->Lu_raw), static_cast<T*>(g->grad_Lu_raw));
   GPZ_LAUNCH_OK();
+  if (full) {
+    // Cholesky backward (Murray 2016): Kbar_zz = Linv^T Phi(L^T Lbar) Linv with Lbar = -tril(GL)
+    auto dgemm = [&](const double* A, const double* B, double* C, int flags) -> int {
+      GemmParams<double> d;
+      d.A = A; d.lda = Mp; d.sA0 = mm; d.B = B; d.ldb = Mp; d.sB0 = mm; d.C = C; d.ldc = Mp; d.sC0 = mm;
+      d.nb0 = L32; d.mt = d.nt = (int)pl.nblk; d.K = (int)Mp; d.flags = flags;
+      return gemm_launch(d, EPI_STORE, s);
+    };
+    hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Kzz, Mp, w.D1);            // D1 = L^T
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL((lbar_kernel<T>), gm, dim3(256), 0, s, w.GL, Mp, M, (const T*)nullptr, w.D2);   // D2 = Lbar
+    GPZ_LAUNCH_OK();
+    if (int rc = dgemm(w.D1, w.D2, w.D3, GF_A_UPPER | GF_B_LOWER)) return rc;                     // D3 = L^T Lbar
+    hipLaunchKernelGGL(phi_kernel, gm, dim3(256), 0, s, w.D3, Mp);
+    GPZ_LAUNCH_OK();
+    GPZ_HIP_OK(hipMemsetAsync(w.D2, 0, sizeof(double) * L * mm, s));
+    if (int rc = dgemm(w.D3, b.Linv, w.D2, GF_A_LOWER | GF_B_LOWER | GF_TILES_LOWER)) return rc;   // D2 = Phi Linv
+    hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Linv, Mp, w.D1);           // D1 = Linv^T
+    GPZ_LAUNCH_OK();
+    if (int rc = dgemm(w.D1, w.D2, w.D3, GF_A_UPPER | GF_B_LOWER)) return rc;                     // D3 = P
+    hipLaunchKernelGGL((sym_cast_kernel<T>), g32, dim3(256), 0, s, w.D3, Mp, w.PS);               // P + P^T
+    GPZ_LAUNCH_OK();
+    KgradArgs ka;
+    ka.Kbar = w.PS; ka.ld = Mp; ka.stride = mm; ka.Z = p->Z; ka.X = p->Z; ka.gZ = p->gZ; ka.gX = p->gZ;
+    ka.sigma = p->k.sigma; ka.ell = p->k.lengthscale; ka.ga = p->k.group_a; ka.gr2 = p->k.group_r2;
+    ka.gpow = p->k.group_pow; ka.scalar_scale = 0.5; ka.M = M; ka.ncols = M; ka.Mp = Mp; ka.d = p->d;
+    ka.G = p->k.n_groups; ka.acc = w.kacc;
+    if (int rc = kgrad_launch(p->dtype, p->k.kind, ka, L32, s)) return rc;
+    const unsigned fx = (unsigned)std::max<int64_t>((M + 255) / 256, L);
+    hipLaunchKernelGGL(kgrad_finish_kernel, dim3(fx, 2), dim3(256), 0, s, w.kacc, L32, Mp, M, p->d, w.sig_direct,
+                       g->grad_Z, g->grad_theta);
+    GPZ_LAUNCH_OK();
+  }
   return 0;
 }
 
@@ -844,8 +1065,8 @@ extern "C" size_t gpz_svgp_backward_workspace_bytes(const gpz_svgp_problem* p, i
   if (check_problem(p)) return 0;
   const Plan pl = make_plan(p, chunk);
   const bool wh = p->whitened != 0;
-  if (p->dtype == GPZ_F32) return carve_bwd<float>(pl, wh, nullptr, carve<float>(pl, wh, nullptr).bytes).bytes;
-  return carve_bwd<double>(pl, wh, nullptr, carve<double>(pl, wh, nullptr).bytes).bytes;
+  if (p->dtype == GPZ_F32) return carve_bwd<float>(pl, wh, true, nullptr, carve<float>(pl, wh, nullptr).bytes).bytes;
+  return carve_bwd<double>(pl, wh, true, nullptr, carve<double>(pl, wh, nullptr).bytes).bytes;
 }
 
 extern "C" int gpz_svgp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int64_t chunk, void* ws,

@@ -269,8 +269,9 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
 
 def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
                   gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0, cache: Optional[FactorCache] = None,
-                  cache_key=None):
-    """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) for frozen kernel hyper-parameters (gpz_svgp_backward)."""
+                  cache_key=None, kernel_grads: bool = False):
+    """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) (gpz_svgp_backward); with ``kernel_grads`` also
+    dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
     lib = _lib.load()
     keep: list = []
@@ -285,6 +286,10 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     grad_Lu = torch.empty((L, M, M), dtype=dt, device=dev)
     g.g_mean, g.g_scale, g.scale = gm.data_ptr(), gs.data_ptr(), sc.data_ptr()
     g.grad_mu, g.grad_Lu_raw = grad_mu.data_ptr(), grad_Lu.data_ptr()
+    if kernel_grads:
+        gth = torch.zeros((L, 4), dtype=torch.float64, device=dev)
+        gz = torch.zeros((M, 4), dtype=torch.float64, device=dev)
+        g.grad_theta, g.grad_Z = gth.data_ptr(), gz.data_ptr()
     if cache is not None:
         cache.attach(lib, p, cache_key, dev)
     nbytes = lib.gpz_svgp_backward_workspace_bytes(C.byref(p), int(chunk))
@@ -295,6 +300,8 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     _lib.check(rc, "gpz_svgp_backward")
     if cache is not None:
         cache.commit()
+    if kernel_grads:
+        return grad_mu, grad_Lu, gth[:, :3], gz[:, :X.shape[1]]
     return grad_mu, grad_Lu
 
 

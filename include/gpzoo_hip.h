@@ -140,18 +140,23 @@ size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
 int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes,
                      void* stream);
 
-/* Backward of gpz_svgp_forward for FROZEN kernel hyper-parameters (Z, sigma, lengthscale,
- * group parameters; the training mode of Slideseq_NSF_newest_version.ipynb:500-504): given
- * dLoss/dmean and dLoss/dscale of q(F) (and the forward's scale) writes dLoss/dmu (L,M) and
- * dLoss/dLu_raw (L,M,M) -- what torch autograd produces through gp.py:276-296 / 218-228 for
- * loss.backward() (utilities.py:485).  Same problem description as the forward; its output
- * fields are ignored. */
+/* Backward of gpz_svgp_forward: given dLoss/dmean and dLoss/dscale of q(F) (and the forward's
+ * scale) writes dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) -- what torch autograd produces through
+ * gp.py:276-296 / 218-228 for loss.backward() (utilities.py:485) with frozen kernel
+ * hyper-parameters (the training mode of Slideseq_NSF_newest_version.ipynb:500-504) -- and,
+ * optionally, the gradients w.r.t. sigma / lengthscale / group parameter and Z.  Same problem
+ * description as the forward; its output fields are ignored. */
 typedef struct gpz_svgp_grads {
   const void* g_mean;    /* (L,N) dtype */
   const void* g_scale;   /* (L,N) dtype */
   const void* scale;     /* (L,N) dtype: forward output */
   void* grad_mu;         /* (L,M) dtype */
   void* grad_Lu_raw;     /* (L,M,M) dtype, zeros above the diagonal */
+  /* optional (whitened path): gradients w.r.t. the kernel hyper-parameters and the inducing
+   * inputs -- what autograd sends through kernel.forward, cholesky and solve_triangular
+   * (kernels.py, gp.py:270-276).  NULL: frozen hyper-parameters. */
+  double* grad_theta;    /* (L,4) fp64: d/dsigma, d/dlengthscale, d/dgroup_a (effective), 0 */
+  double* grad_Z;        /* (M,4) fp64: first d columns used */
 } gpz_svgp_grads;
 
 size_t gpz_svgp_backward_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
