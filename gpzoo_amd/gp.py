@@ -10,8 +10,9 @@ parameters after construction.  ``forward`` is ONE call into
 solves and the q(F) reductions never round-trip through torch ops, and neither
 Kzx nor W is materialised for more than one N-chunk.
 
-Training: ``qF`` is differentiable w.r.t. ``mu`` and ``Lu`` (``gpz_svgp_backward``; Z and the kernel
-hyper-parameters are treated as frozen -- the first half of SURVEY.md §8f "next" #1).
+Training: ``qF`` is differentiable w.r.t. ``mu`` and ``Lu`` on every path and, on the whitened
+path (WSVGP / MGGP_WSVGP), also w.r.t. Z, sigma, lengthscale and group_diff_param
+(``gpz_svgp_backward``, SURVEY.md §8f "next" #1); the un-whitened SVGP treats those as frozen.
 """
 from __future__ import annotations
 
@@ -26,17 +27,25 @@ from . import ops
 from .kernels import kernel_spec
 
 
-class _QFMoments(torch.autograd.Function):
-    """(mean, scale) of q(F) as a differentiable function of mu and the raw Lu.
+def _like(grad_l: torch.Tensor, param: torch.Tensor) -> torch.Tensor:
+    """Per-latent gradient (L,) -> the parameter's own shape: (), (L,) or (L,1,1)."""
+    if param.numel() == 1:
+        return grad_l.sum().reshape(param.shape).to(param.dtype)
+    return grad_l.reshape(param.shape).to(param.dtype)
 
-    forward = gpz_svgp_forward, backward = gpz_svgp_backward (frozen kernel hyper-parameters:
-    SURVEY.md §8f "next" #1, first half).  Z and the kernel parameters get no gradient."""
+
+class _QFMoments(torch.autograd.Function):
+    """(mean, scale) of q(F) as a differentiable function of mu, the raw Lu and -- on the whitened
+    path -- Z and the kernel hyper-parameters.  forward = gpz_svgp_forward, backward =
+    gpz_svgp_backward (SURVEY.md §8f "next" #1)."""
 
     @staticmethod
-    def forward(ctx, mu, Lu_raw, call):
+    def forward(ctx, mu, Lu_raw, Z, sigma, lengthscale, group_param, call):
         out = call["forward"](mu, Lu_raw)
         ctx.call = call
-        ctx.save_for_backward(mu, Lu_raw, out["scale"])
+        ctx.save_for_backward(mu, Lu_raw, out["scale"], Z, sigma, lengthscale,
+                              group_param if group_param is not None else mu.new_empty(0))
+        ctx.has_group = group_param is not None
         ctx.mark_non_differentiable(out["Lu"])
         chol = out.get("chol")
         if chol is None:
@@ -46,13 +55,22 @@ class _QFMoments(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_mean, g_scale, _g_lu, _g_chol):
-        mu, Lu_raw, scale = ctx.saved_tensors
+        mu, Lu_raw, scale, Z, sigma, lengthscale, group_param = ctx.saved_tensors
         if g_mean is None:
             g_mean = torch.zeros_like(scale)
         if g_scale is None:
             g_scale = torch.zeros_like(scale)
-        grad_mu, grad_Lu = ctx.call["backward"](mu, Lu_raw, g_mean, g_scale, scale)
-        return grad_mu.reshape(mu.shape), grad_Lu.reshape(Lu_raw.shape), None
+        need_kernel = any(ctx.needs_input_grad[2:6])
+        res = ctx.call["backward"](mu, Lu_raw, g_mean, g_scale, scale, need_kernel)
+        grads = [res[0].reshape(mu.shape), res[1].reshape(Lu_raw.shape), None, None, None, None, None]
+        if need_kernel:
+            gth, gZ = res[2], res[3]
+            grads[2] = gZ.to(Z.dtype)
+            grads[3] = _like(gth[:, 0], sigma)
+            grads[4] = _like(gth[:, 1], lengthscale)
+            if ctx.has_group:
+                grads[5] = _like(gth[:, 2], group_param) * ctx.call["group_chain"]
+        return tuple(grads)
 
 
 class _FusedGP(nn.Module):
@@ -125,11 +143,15 @@ class _FusedGP(nn.Module):
         if not train:
             _, out = self._evaluate(X, groupsX, want_chol=not self._whitened)
             return self._distributions(out)
-        frozen = [self.Z] + [t for t in self.kernel.parameters()]
-        if any(t.requires_grad for t in frozen) and not getattr(_FusedGP, "_warned", False):
+        kparams = [self.Z, self.kernel.sigma, self.kernel.lengthscale]
+        gparam = getattr(self.kernel, "group_diff_param", None)
+        if gparam is not None:
+            kparams.append(gparam)
+        hyper_grad = any(t.requires_grad for t in kparams)
+        if hyper_grad and not self._whitened and not getattr(_FusedGP, "_warned", False):
             _FusedGP._warned = True
-            warnings.warn("gpzoo_amd: gradients are propagated to mu and Lu only; Z and the kernel hyper-parameters "
-                          "are treated as frozen (set requires_grad=False on them, as the Slide-seq notebooks do)")
+            warnings.warn("gpzoo_amd: on the un-whitened SVGP path gradients are propagated to mu and Lu only; Z and "
+                          "the kernel hyper-parameters are treated as frozen (WSVGP propagates all of them)")
         spec = kernel_spec(self.kernel, X, self._latents())
         gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
         args = (spec, X, self.Z)
@@ -139,11 +161,17 @@ class _FusedGP(nn.Module):
             return ops.svgp_forward(*args, mu, Lu_raw, float(self.jitter), self._whitened,
                                     want_chol=not self._whitened, **common)
 
-        def bwd(mu, Lu_raw, g_mean, g_scale, scale):
+        def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel):
             return ops.svgp_backward(*args, mu, Lu_raw, float(self.jitter), self._whitened, g_mean, g_scale, scale,
-                                     **common)
+                                     kernel_grads=need_kernel and self._whitened, **common)
 
-        mean, scale, _, chol = _QFMoments.apply(self.mu, self.Lu, dict(forward=fwd, backward=bwd))
+        call = dict(forward=fwd, backward=bwd)
+        if gparam is not None:
+            call["group_chain"] = self.kernel._group_a_chain()
+        det = (lambda t: t) if self._whitened else (lambda t: t.detach())
+        mean, scale, _, chol = _QFMoments.apply(self.mu, self.Lu, det(self.Z), det(self.kernel.sigma),
+                                                det(self.kernel.lengthscale), None if gparam is None else det(gparam),
+                                                call)
         # q(U)'s scale_tril through torch so that KL terms differentiate w.r.t. the raw parameter
         Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
         single = self.mu.dim() == 1

@@ -13,7 +13,8 @@ Deviations from the reference at HEAD, all documented in SURVEY.md §8a:
   * ``NSF_RBF(L=1).forward(diag=True)`` returns ``(1, N)`` instead of raising;
   * squared distances are formed by direct differencing (more accurate than
     cdist's / _squared_dist's matmul expansion in fp32).
-Forward only: outputs carry no autograd graph (backward is SURVEY §8f "next" #1).
+``forward`` itself returns plain tensors; gradients w.r.t. sigma / lengthscale / group_diff_param / Z
+flow through the GP modules' fused backward (gp.py), not through these standalone matrices.
 """
 from __future__ import annotations
 
@@ -116,6 +117,10 @@ class _MGGPMixin:
     def _group_a(self) -> torch.Tensor:
         raise NotImplementedError
 
+    def _group_a_chain(self) -> torch.Tensor:
+        """d(effective multiplier)/d(group_diff_param), element-wise."""
+        raise NotImplementedError
+
     def _group_pow(self, X) -> float:
         return 0.5 * self.input_dim
 
@@ -150,6 +155,9 @@ class MGGP_RBF(_MGGPMixin, RBF):
     def _group_a(self):
         return self.group_diff_param
 
+    def _group_a_chain(self):
+        return torch.ones_like(self.group_diff_param)
+
     def forward(self, X, Z, groupsX, groupsZ, diag=False):
         return self._mggp_forward(X, Z, groupsX, groupsZ, diag)
 
@@ -168,6 +176,9 @@ class MGGP_NSF_RBF(_MGGPMixin, NSF_RBF):
 
     def _group_a(self):
         return torch.square(self.group_diff_param)
+
+    def _group_a_chain(self):
+        return 2 * self.group_diff_param.detach()
 
     def forward(self, X, Z, groupsX, groupsZ, diag=False):
         return self._mggp_forward(X, Z, groupsX, groupsZ, diag)
@@ -193,6 +204,9 @@ class batched_MGGP_RBF(_MGGPMixin, batched_RBF):
 
     def _group_a(self):
         return torch.abs(self.group_diff_param)
+
+    def _group_a_chain(self):
+        return torch.sign(self.group_diff_param.detach())
 
     def _group_pow(self, X) -> float:
         return 0.5 * X.shape[-1]

@@ -119,7 +119,10 @@ def run_case(name, gp_cls, kern, inp, dtype, jitter, noise_sd, whitened, mggp):
     loss.backward()
     grad_mu, grad_Lu = gp.mu.grad.detach().clone(), gp.Lu.grad.detach().clone()
     out = {k: v.to(dtype).numpy() if v.is_floating_point() else v.numpy() for k, v in inp.items()}
-    out.update(grad_mu=grad_mu.numpy(), grad_Lu=grad_Lu.numpy())
+    out.update(grad_mu=grad_mu.numpy(), grad_Lu=grad_Lu.numpy(), grad_Z=gp.Z.grad.detach().numpy(),
+               grad_sigma=kern.sigma.grad.detach().numpy(), grad_lengthscale=kern.lengthscale.grad.detach().numpy())
+    if mggp:
+        out["grad_group_diff"] = kern.group_diff_param.grad.detach().numpy()
     out.update(
         sigma=kern.sigma.detach().numpy(), lengthscale=kern.lengthscale.detach().numpy(),
         jitter=np.float64(jitter), noise_sd=np.float64(float(s)),
