@@ -680,16 +680,40 @@ __global__ __launch_bounds__(256) void tril_transpose_kernel(const double* __res
 // Lbar = -tril(GL) (+ tril(upstream dLoss/dchol)) in fp64
 template <typename T>
 __global__ void lbar_kernel(const T* __restrict__ GL, int64_t Mp, int64_t M, const T* __restrict__ g_chol,
-                            double* __restrict__ Lbar) {
+                            const double* __restrict__ E, double* __restrict__ Lbar) {
   const int l = blockIdx.z;
   const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= Mp) return;
   double v = 0.0;
   if (j <= i) {
     v = -(double)GL[(int64_t)l * Mp * Mp + i * Mp + j];
+    if (E) v -= E[(int64_t)l * Mp * Mp + i * Mp + j];
     if (g_chol && i < M) v += (double)g_chol[(int64_t)l * M * M + i * M + j];
   }
   Lbar[(int64_t)l * Mp * Mp + i * Mp + j] = v;
+}
+
+// dst = (double) tril(src)
+template <typename T>
+__global__ void tril_to_double_kernel(const T* __restrict__ src, int64_t Mp, double* __restrict__ dst) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  const int64_t o = (int64_t)l * Mp * Mp + i * Mp + j;
+  dst[o] = (j <= i) ? (double)src[o] : 0.0;
+}
+
+// R[i][j] += u[i] * (Linv mu)[j]   (un-whitened: the muE = Linv mu dependence on the factor)
+template <typename T>
+__global__ void rank1_linv_mu_kernel(double* __restrict__ R, int64_t Mp, int64_t M, const double* __restrict__ u,
+                                     const double* __restrict__ Linv, const T* __restrict__ mu) {
+  const int l = blockIdx.z;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  const double* Lb = Linv + (int64_t)l * Mp * Mp + j * Mp;
+  double me = 0.0;
+  for (int64_t k = 0; k <= j; ++k) me += Lb[k] * (double)mu[(int64_t)l * M + k];
+  for (int64_t i = blockIdx.y; i < M; i += gridDim.y) R[(int64_t)l * Mp * Mp + i * Mp + j] += u[(int64_t)l * Mp + i] * me;
 }
 
 // Phi: keep the lower triangle, halve the diagonal (Cholesky backward, Murray 2016)
@@ -854,7 +878,6 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   const Plan pl = make_plan(p, chunk);
   const bool wh = p->whitened != 0;
   const bool full = g->grad_theta != nullptr || g->grad_Z != nullptr;   // kernel hyper-parameter / Z gradients
-  GPZ_REQUIRE(!(full && !wh), "gpz_svgp_backward: kernel / Z gradients are implemented for the whitened path only");
   Buffers<T> b = carve<T>(pl, wh, ws);
   BwdBuffers<T> w = carve_bwd<T>(pl, wh, full, ws, b.bytes);
   GPZ_REQUIRE(ws_bytes >= w.bytes, "gpz_svgp_backward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
@@ -871,8 +894,12 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     GPZ_HIP_OK(hipMemsetAsync(w.kacc, 0, sizeof(double) * L * Mp * 8, s));
     GPZ_HIP_OK(hipMemsetAsync(w.sig_direct, 0, sizeof(double) * L, s));
     // Lu (lower, not transposed) in GEMM precision and Linv^T
-    hipLaunchKernelGGL((lu_prepare_kernel<T>), g32, dim3(256), 0, s, static_cast<const T*>(p->Lu_raw), M, Mp,
-                       (T*)nullptr, (double*)nullptr, (T*)nullptr, b.lu_part, w.LuN);
+    if (wh) {
+      hipLaunchKernelGGL((lu_prepare_kernel<T>), g32, dim3(256), 0, s, static_cast<const T*>(p->Lu_raw), M, Mp,
+                         (T*)nullptr, (double*)nullptr, (T*)nullptr, b.lu_part, w.LuN);
+    } else {   // LuE = Linv Lu (lower), already formed in fp64 by the preparation step
+      hipLaunchKernelGGL((cast_kernel<T>), dim3(2048), dim3(256), 0, s, b.LuW, w.LuN, L * mm);
+    }
     GPZ_LAUNCH_OK();
     hipLaunchKernelGGL((transpose_cast_kernel<T>), g32, dim3(256), 0, s, b.Linv, Mp, w.LinvT, (double*)w.D1);
     GPZ_LAUNCH_OK();
@@ -985,9 +1012,24 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       d.nb0 = L32; d.mt = d.nt = (int)pl.nblk; d.K = (int)Mp; d.flags = flags;
       return gemm_launch(d, EPI_STORE, s);
     };
+    const double* E = nullptr;
+    if (!wh) {
+      // muE = Linv mu and LuE = Linv Lu also depend on the factor:
+      // E = Linv^T (tril(dLoss/dLuE) LuE^T + dLoss/dmuE muE^T),  Lbar -= tril(E)
+      hipLaunchKernelGGL((tril_to_double_kernel<T>), gm, dim3(256), 0, s, w.G, Mp, w.D1);
+      GPZ_LAUNCH_OK();
+      if (int rc = dgemm(w.D1, b.LuW, w.D2, GF_A_LOWER | GF_B_UPPER | GF_B_TRANS)) return rc;     // D2 = tril(G) LuE^T
+      hipLaunchKernelGGL((rank1_linv_mu_kernel<T>), dim3((unsigned)((M + 255) / 256), 64, L32), dim3(256), 0, s, w.D2,
+                         Mp, M, w.mu_sum, b.Linv, static_cast<const T*>(p->mu));
+      GPZ_LAUNCH_OK();
+      hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Linv, Mp, w.D1);         // D1 = Linv^T
+      GPZ_LAUNCH_OK();
+      if (int rc = dgemm(w.D1, w.D2, w.D3, GF_A_UPPER)) return rc;                                // D3 = E
+      E = w.D3;
+    }
+    hipLaunchKernelGGL((lbar_kernel<T>), gm, dim3(256), 0, s, w.GL, Mp, M, static_cast<const T*>(g->g_chol), E, w.D2);
+    GPZ_LAUNCH_OK();                                                                              // D2 = Lbar
     hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Kzz, Mp, w.D1);            // D1 = L^T
-    GPZ_LAUNCH_OK();
-    hipLaunchKernelGGL((lbar_kernel<T>), gm, dim3(256), 0, s, w.GL, Mp, M, (const T*)nullptr, w.D2);   // D2 = Lbar
     GPZ_LAUNCH_OK();
     if (int rc = dgemm(w.D1, w.D2, w.D3, GF_A_UPPER | GF_B_LOWER)) return rc;                     // D3 = L^T Lbar
     hipLaunchKernelGGL(phi_kernel, gm, dim3(256), 0, s, w.D3, Mp);

@@ -10,9 +10,9 @@ parameters after construction.  ``forward`` is ONE call into
 solves and the q(F) reductions never round-trip through torch ops, and neither
 Kzx nor W is materialised for more than one N-chunk.
 
-Training: ``qF`` is differentiable w.r.t. ``mu`` and ``Lu`` on every path and, on the whitened
-path (WSVGP / MGGP_WSVGP), also w.r.t. Z, sigma, lengthscale and group_diff_param
-(``gpz_svgp_backward``, SURVEY.md §8f "next" #1); the un-whitened SVGP treats those as frozen.
+Training: ``qF`` (and, un-whitened, ``pU.scale_tril``) is differentiable w.r.t. ``mu``, ``Lu``, ``Z``,
+``sigma``, ``lengthscale`` and ``group_diff_param`` through ``gpz_svgp_backward`` (SURVEY.md §8f
+"next" #1); parameters with ``requires_grad=False`` cost nothing.
 """
 from __future__ import annotations
 
@@ -20,8 +20,6 @@ import torch
 import torch.nn as nn
 from torch import distributions
 from torch.distributions import constraints
-
-import warnings
 
 from . import ops
 from .kernels import kernel_spec
@@ -50,7 +48,7 @@ class _QFMoments(torch.autograd.Function):
         chol = out.get("chol")
         if chol is None:
             chol = out["Lu"].new_empty(0)
-        ctx.mark_non_differentiable(chol)
+            ctx.mark_non_differentiable(chol)
         return out["mean"], out["scale"], out["Lu"], chol
 
     @staticmethod
@@ -61,7 +59,8 @@ class _QFMoments(torch.autograd.Function):
         if g_scale is None:
             g_scale = torch.zeros_like(scale)
         need_kernel = any(ctx.needs_input_grad[2:6])
-        res = ctx.call["backward"](mu, Lu_raw, g_mean, g_scale, scale, need_kernel)
+        res = ctx.call["backward"](mu, Lu_raw, g_mean, g_scale, scale, need_kernel,
+                                   _g_chol if (need_kernel and _g_chol is not None and _g_chol.numel()) else None)
         grads = [res[0].reshape(mu.shape), res[1].reshape(Lu_raw.shape), None, None, None, None, None]
         if need_kernel:
             gth, gZ = res[2], res[3]
@@ -147,11 +146,6 @@ class _FusedGP(nn.Module):
         gparam = getattr(self.kernel, "group_diff_param", None)
         if gparam is not None:
             kparams.append(gparam)
-        hyper_grad = any(t.requires_grad for t in kparams)
-        if hyper_grad and not self._whitened and not getattr(_FusedGP, "_warned", False):
-            _FusedGP._warned = True
-            warnings.warn("gpzoo_amd: on the un-whitened SVGP path gradients are propagated to mu and Lu only; Z and "
-                          "the kernel hyper-parameters are treated as frozen (WSVGP propagates all of them)")
         spec = kernel_spec(self.kernel, X, self._latents())
         gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
         args = (spec, X, self.Z)
@@ -161,17 +155,15 @@ class _FusedGP(nn.Module):
             return ops.svgp_forward(*args, mu, Lu_raw, float(self.jitter), self._whitened,
                                     want_chol=not self._whitened, **common)
 
-        def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel):
+        def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel, g_chol):
             return ops.svgp_backward(*args, mu, Lu_raw, float(self.jitter), self._whitened, g_mean, g_scale, scale,
-                                     kernel_grads=need_kernel and self._whitened, **common)
+                                     kernel_grads=need_kernel, g_chol=g_chol, **common)
 
         call = dict(forward=fwd, backward=bwd)
         if gparam is not None:
             call["group_chain"] = self.kernel._group_a_chain()
-        det = (lambda t: t) if self._whitened else (lambda t: t.detach())
-        mean, scale, _, chol = _QFMoments.apply(self.mu, self.Lu, det(self.Z), det(self.kernel.sigma),
-                                                det(self.kernel.lengthscale), None if gparam is None else det(gparam),
-                                                call)
+        mean, scale, _, chol = _QFMoments.apply(self.mu, self.Lu, self.Z, self.kernel.sigma, self.kernel.lengthscale,
+                                                gparam, call)
         # q(U)'s scale_tril through torch so that KL terms differentiate w.r.t. the raw parameter
         Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
         single = self.mu.dim() == 1

@@ -269,7 +269,7 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
 
 def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
                   gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0, cache: Optional[FactorCache] = None,
-                  cache_key=None, kernel_grads: bool = False):
+                  cache_key=None, kernel_grads: bool = False, g_chol=None):
     """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) (gpz_svgp_backward); with ``kernel_grads`` also
     dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
@@ -286,6 +286,10 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     grad_Lu = torch.empty((L, M, M), dtype=dt, device=dev)
     g.g_mean, g.g_scale, g.scale = gm.data_ptr(), gs.data_ptr(), sc.data_ptr()
     g.grad_mu, g.grad_Lu_raw = grad_mu.data_ptr(), grad_Lu.data_ptr()
+    if kernel_grads and g_chol is not None:
+        gc = g_chol.detach().to(dt).reshape(L, M, M).contiguous()
+        keep.append(gc)
+        g.g_chol = gc.data_ptr()
     if kernel_grads:
         gth = torch.zeros((L, 4), dtype=torch.float64, device=dev)
         gz = torch.zeros((M, 4), dtype=torch.float64, device=dev)

@@ -152,11 +152,12 @@ typedef struct gpz_svgp_grads {
   const void* scale;     /* (L,N) dtype: forward output */
   void* grad_mu;         /* (L,M) dtype */
   void* grad_Lu_raw;     /* (L,M,M) dtype, zeros above the diagonal */
-  /* optional (whitened path): gradients w.r.t. the kernel hyper-parameters and the inducing
-   * inputs -- what autograd sends through kernel.forward, cholesky and solve_triangular
-   * (kernels.py, gp.py:270-276).  NULL: frozen hyper-parameters. */
+  /* optional: gradients w.r.t. the kernel hyper-parameters and the inducing inputs -- what
+   * autograd sends through kernel.forward, cholesky and the solves (kernels.py, gp.py:213-219,
+   * 270-276).  NULL: frozen hyper-parameters. */
   double* grad_theta;    /* (L,4) fp64: d/dsigma, d/dlengthscale, d/dgroup_a (effective), 0 */
   double* grad_Z;        /* (M,4) fp64: first d columns used */
+  const void* g_chol;    /* (L,M,M) dtype or NULL: upstream dLoss/dchol (un-whitened: KL(qU||pU) uses it) */
 } gpz_svgp_grads;
 
 size_t gpz_svgp_backward_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);

@@ -144,10 +144,10 @@ def test_kernel_and_Z_gradients_match_autograd(cfg, kind):
         torch.testing.assert_close((gth[:, 2].cpu() * 2 * c["group_diff"]), leaf["group_diff"].grad, **tol)
 
 
-@pytest.mark.parametrize("name", [n for n in golden_cases() if ("wsvgp" in n)])
-def test_whitened_hyperparameter_gradients_match_reference(name):
+@pytest.mark.parametrize("name", [n for n in golden_cases() if n != "cfg1_f64"])
+def test_hyperparameter_gradients_match_reference(name):
     """Everything trainable at once (mu, Lu, Z, sigma, lengthscale, group_diff_param): loss.backward()
-    through WSVGP / MGGP_WSVGP against the reference's own autograd gradients."""
+    through all four GP classes against the reference's own autograd gradients."""
     from gpzoo.utilities import whitened_KL_batched
     c = load_case(name)
     model = build(name, c)
@@ -156,9 +156,13 @@ def test_whitened_hyperparameter_gradients_match_reference(name):
     kw = {"groupsX": c["gX"].cuda()} if "gX" in c else {}
     pY, qF, qU, pU = model(X=X, E=1, **kw)
     s = torch.nn.functional.softplus(model.noise)
-    loss = -(pY.log_prob(y).sum() - (qF.scale ** 2).sum() / (2 * s ** 2) - whitened_KL_batched(qU.mean, qU.scale_tril).sum())
+    kl = whitened_KL_batched(qU.mean, qU.scale_tril).sum() if c["whitened"] else \
+        torch.distributions.kl_divergence(qU, pU).sum()
+    loss = -(pY.log_prob(y).sum() - (qF.scale ** 2).sum() / (2 * s ** 2) - kl)
     loss.backward()
     rt = rtol_for(X.dtype)
+    if not c["whitened"] and X.dtype == torch.float32:
+        rt = 5e-3   # the reference's own fp32 un-whitened gradients carry W @ (S - Kzz) cancellation (SURVEY: 6e-5 on the ELBO)
     def close(got, ref):
         sc = float(ref.abs().max()) + 1e-30
         torch.testing.assert_close(got.cpu(), ref, rtol=rt, atol=rt * sc)
