@@ -82,6 +82,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # The HIP runtime must be the one PyTorch ships and initialises (device memory and streams come
+    # from torch): import torch first so libamdhip64's SONAME resolves to that copy.  Loading this
+    # library before torch binds /opt/rocm's runtime instead and the process then sees no device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -m gpzoo_amd.build` (hipcc, gfx950). "
