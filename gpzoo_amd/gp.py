@@ -183,6 +183,28 @@ class _FusedGP(nn.Module):
         return out["elbo"], out["kl"], out["loglik"]
 
 
+class GaussianPrior(nn.Module):
+    """Mean-field Normal prior for the non-spatial factors; reference gp.py:125-146 (no kernel work)."""
+
+    def __init__(self, y, L=10):
+        super().__init__()
+        D, N = y.shape
+        self.mean = nn.Parameter(torch.randn(size=(L, N)))
+        self.scale = nn.Parameter(torch.rand(size=(L, N)))
+        self.scale_pf = 1.0
+
+    def _pair(self, mean, raw_scale):
+        qF = distributions.Normal(mean, torch.nn.functional.softplus(raw_scale))
+        pF = distributions.Normal(torch.zeros_like(qF.mean), self.scale_pf * torch.ones_like(qF.scale))
+        return qF, pF
+
+    def forward(self):
+        return self._pair(self.mean, self.scale)
+
+    def forward_batched(self, idx):
+        return self._pair(self.mean[:, idx], self.scale[:, idx])
+
+
 class WSVGP(_FusedGP):
     """Whitened SVGP; reference gp.py:235-322."""
     _whitened = True

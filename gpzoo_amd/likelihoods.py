@@ -44,3 +44,227 @@ class ExactLikelihood(nn.Module):
     def elbo(self, X, y, **kwargs):
         sd = float(torch.nn.functional.softplus(self.noise.detach()))
         return self.gp.elbo(X, y, sd, groupsX=kwargs.get('groupsX'))[0]
+
+
+# --------------------------------------------------------------------------------------------
+# Poisson factor models (SURVEY.md §8f "next" #2).  The classes keep the reference's names,
+# constructor signatures, parameter names and return tuples (pY is a real torch Poisson over the
+# (E,D,N) rate, because callers use pY.log_prob / pY.rate); `expected_loglik` is the fused
+# MI355X path for the training step: same number as pY.log_prob(y).mean(0).sum(), same gradients,
+# without materialising the rate.
+# --------------------------------------------------------------------------------------------
+
+class _PoissonLogLik(torch.autograd.Function):
+    """(1/E) sum_e sum_dn log Poisson(y | V Z_e) through gpz_poisson_nsf (forward and gradients in
+    one fused pass; backward only scales them)."""
+
+    @staticmethod
+    def forward(ctx, mean, scale, W_pos, V_pos, eps, y, with_lgamma):
+        from . import ops
+        ll, dmean, dscale, dW, dV = ops.poisson_nsf(mean, scale, eps, W_pos, V_pos, y, with_lgamma)
+        ctx.save_for_backward(dmean.to(mean.dtype), dscale.to(scale.dtype), dW.to(W_pos.dtype), dV.to(V_pos.dtype))
+        return ll.to(mean.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        dmean, dscale, dW, dV = ctx.saved_tensors
+        return g * dmean, g * dscale, g * dW, g * dV, None, None, None
+
+
+def poisson_expected_loglik(qF_list, W_list, V_pos, y, E=10, with_lgamma=True, eps=None):
+    """Fused Monte-Carlo E_q[log p(y | F)] for rate = V * sum_k W_k exp(F_k), F_k ~ qF_k.
+
+    qF_list: Normal distributions over (L_k, N) factors; W_list: positive (D, L_k) loadings."""
+    mean = torch.cat([q.mean for q in qF_list], dim=0)
+    scale = torch.cat([q.scale for q in qF_list], dim=0)
+    W = torch.cat(list(W_list), dim=1)
+    if eps is None:
+        eps = torch.randn((E,) + tuple(mean.shape), dtype=mean.dtype, device=mean.device)
+    return _PoissonLogLik.apply(mean, scale, W, V_pos, eps, y, with_lgamma)
+
+
+class PoissonFactorization(nn.Module):
+    """softplus(W) @ exp(F): base of PNMF / NSF2 / the hybrids; reference likelihoods.py:39-53."""
+
+    def __init__(self, prior, y, L=10):
+        super().__init__()
+        D, N = y.shape
+        self.prior = prior
+        self.W = nn.Parameter(torch.rand((D, L)))
+
+    def get_rate(self, prior_samples):
+        return torch.matmul(torch.nn.functional.softplus(self.W), torch.exp(prior_samples))   # (E, D, N)
+
+
+class PNMF(PoissonFactorization):
+    """Non-spatial Poisson NMF over a GaussianPrior; reference likelihoods.py:56-72."""
+
+    def __init__(self, prior, y, L=10):
+        super().__init__(prior=prior, y=y, L=L)
+        D, N = y.shape
+        self.V = nn.Parameter(torch.ones((N,)))
+        self.X = nn.Parameter(torch.zeros((N, 2)), requires_grad=False)
+
+    def forward(self, E=10, **kwargs):
+        qF, pF = self.prior()
+        Z = self.get_rate(qF.rsample((E,)))
+        pY = distributions.Poisson(torch.nn.functional.softplus(self.V) * Z)
+        return pY, qF, pF
+
+
+class NSF2(PoissonFactorization):
+    """Non-negative spatial factorisation over an SVGP prior; reference likelihoods.py:74-97."""
+
+    def __init__(self, gp, y, L=10):
+        super().__init__(prior=gp, y=y, L=L)
+        D, N = y.shape
+        self.V = nn.Parameter(torch.ones((N,)))
+
+    def forward(self, X, E=10, verbose=False, **kwargs):
+        qF, qU, pU = self.prior(X=X, verbose=verbose, **kwargs)
+        Z = self.get_rate(qF.rsample((E,)))
+        pY = distributions.Poisson(torch.nn.functional.softplus(self.V) * Z)
+        return pY, qF, qU, pU
+
+    def forward_batched(self, X, idx, E=10, verbose=False, **kwargs):
+        qF, qU, pU = self.prior(X=X[idx], verbose=verbose, **kwargs)
+        Z = self.get_rate(qF.rsample((E,)))
+        pY = distributions.Poisson(torch.nn.functional.softplus(self.V[idx]) * Z)
+        return pY, qF, qU, pU
+
+    def expected_loglik(self, X, y, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
+        """Fused training-step form: (E_q[log p(y | F)] as a scalar, qF, qU, pU)."""
+        Xb = X if idx is None else X[idx]
+        V = self.V if idx is None else self.V[idx]
+        qF, qU, pU = self.prior(X=Xb, **kwargs)
+        ll = poisson_expected_loglik([qF], [torch.nn.functional.softplus(self.W)],
+                                     torch.nn.functional.softplus(V), y, E=E, with_lgamma=with_lgamma, eps=eps)
+        return ll, qF, qU, pU
+
+
+class NSF(nn.Module):
+    """Same model with W, V held directly; reference likelihoods.py:227-268."""
+
+    def __init__(self, gp, y, L=10):
+        super().__init__()
+        D, N = y.shape
+        self.gp = gp
+        self.W = nn.Parameter(torch.rand((D, L)))
+        self.V = nn.Parameter(torch.ones((N,)))
+
+    def _rate(self, qF, V, E):
+        F = torch.exp(qF.rsample((E,)))
+        return V * torch.matmul(torch.nn.functional.softplus(self.W), F)
+
+    def forward(self, X, E=10, verbose=False, **kwargs):
+        qF, qU, pU = self.gp(X=X, verbose=verbose, **kwargs)
+        return distributions.Poisson(self._rate(qF, torch.nn.functional.softplus(self.V), E)), qF, qU, pU
+
+    def forward_batched(self, X, idx, E=10, verbose=False, **kwargs):
+        qF, qU, pU = self.gp(X=X[idx], verbose=verbose, **kwargs)
+        return distributions.Poisson(self._rate(qF, torch.nn.functional.softplus(self.V)[idx], E)), qF, qU, pU
+
+    def expected_loglik(self, X, y, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
+        Xb = X if idx is None else X[idx]
+        V = torch.nn.functional.softplus(self.V)
+        qF, qU, pU = self.gp(X=Xb, **kwargs)
+        ll = poisson_expected_loglik([qF], [torch.nn.functional.softplus(self.W)], V if idx is None else V[idx], y,
+                                     E=E, with_lgamma=with_lgamma, eps=eps)
+        return ll, qF, qU, pU
+
+
+class MGGP_NSF(NSF):
+    """NSF over a multi-group GP (groupsX is positional); reference likelihoods.py:341-374."""
+
+    def _gp(self, X, groupsX, verbose):
+        if getattr(self.gp, "_whitened", False):
+            return self.gp(X, verbose=verbose, groupsX=groupsX)     # MGGP_WSVGP takes groupsX as a keyword
+        return self.gp(X, groupsX, verbose)
+
+    def forward(self, X, groupsX, E=10, verbose=False):
+        qF, qU, pU = self._gp(X, groupsX, verbose)
+        return distributions.Poisson(self._rate(qF, torch.nn.functional.softplus(self.V), E)), qF, qU, pU
+
+    def forward_batched(self, X, groupsX, idx, E=10, verbose=False):
+        qF, qU, pU = self._gp(X[idx], groupsX[idx], verbose)
+        return distributions.Poisson(self._rate(qF, torch.nn.functional.softplus(self.V)[idx], E)), qF, qU, pU
+
+
+class Hybrid_NSF2(nn.Module):
+    """Spatial (GP) + non-spatial (GaussianPrior) factors; reference likelihoods.py:100-164."""
+
+    def __init__(self, gp, prior, y, L=10, T=10):
+        super().__init__()
+        D, N = y.shape
+        self.sf = PoissonFactorization(prior=gp, y=y, L=L)
+        self.cf = PoissonFactorization(prior=prior, y=y, L=T)
+        self.V = nn.Parameter(torch.ones((N,)))
+
+    def _pY(self, qF1, qF2, V, E):
+        Z = self.sf.get_rate(qF1.rsample((E,))) + self.cf.get_rate(qF2.rsample((E,)))
+        return distributions.Poisson(V * Z)
+
+    def forward(self, X, E=10, verbose=False, **kwargs):
+        qF1, qU, pU = self.sf.prior(X=X, verbose=verbose, **kwargs)
+        qF2, pF2 = self.cf.prior()
+        return self._pY(qF1, qF2, torch.nn.functional.softplus(self.V), E), qF1, qU, pU, qF2, pF2
+
+    def forward_batched(self, X, idx, E=10, verbose=False, **kwargs):
+        qF1, qU, pU = self.sf.prior(X=X[idx], verbose=verbose, **kwargs)
+        qF2, pF2 = self.cf.prior.forward_batched(idx)
+        return self._pY(qF1, qF2, torch.nn.functional.softplus(self.V[idx]), E), qF1, qU, pU, qF2, pF2
+
+    def forward_precomputed(self, W, idx, E=10, verbose=False, **kwargs):
+        qF1, qU, pU = self.sf.prior.forward_precomputed(W, verbose=verbose, **kwargs)
+        qF2, pF2 = self.cf.prior.forward_batched(idx)
+        return self._pY(qF1, qF2, torch.nn.functional.softplus(self.V[idx]), E), qF1, qU, pU, qF2, pF2
+
+    def expected_loglik(self, X, y, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
+        Xb = X if idx is None else X[idx]
+        V = self.V if idx is None else self.V[idx]
+        qF1, qU, pU = self.sf.prior(X=Xb, **kwargs)
+        qF2, pF2 = self.cf.prior() if idx is None else self.cf.prior.forward_batched(idx)
+        sp = torch.nn.functional.softplus
+        ll = poisson_expected_loglik([qF1, qF2], [sp(self.sf.W), sp(self.cf.W)], sp(V), y, E=E,
+                                     with_lgamma=with_lgamma, eps=eps)
+        return ll, qF1, qU, pU, qF2, pF2
+
+
+class Hybrid_NSF_Exact(Hybrid_NSF2):
+    """Hybrid model with the log-normal mean exp(m + s^2/2) in place of sampling; reference
+    likelihoods.py:165-224."""
+
+    def _pY(self, qF1, qF2, V, E):
+        Z = self.sf.get_rate(qF1.mean + 0.5 * qF1.scale ** 2) + self.cf.get_rate(qF2.mean + 0.5 * qF2.scale ** 2)
+        return distributions.Poisson(V * Z)
+
+
+class Hybrid_NSF(NSF):
+    """NSF plus mean-field non-spatial factors held in the module (raw, un-soft-plussed loadings);
+    reference likelihoods.py:271-338."""
+
+    def __init__(self, gp, y, L=10, non_spatial_factors=10):
+        super().__init__(gp=gp, y=y, L=L)
+        D, N = y.shape
+        self.W2 = nn.Parameter(torch.rand((D, non_spatial_factors)))
+        self.mF = nn.Parameter(torch.zeros((non_spatial_factors, N)))
+        self.scale_qF = nn.Parameter(1e-1 * torch.rand((non_spatial_factors, N)))
+
+    def _hybrid(self, qF, mF, raw_scale, V, E):
+        scale2 = torch.nn.functional.softplus(raw_scale)
+        qF2 = distributions.Normal(mF, scale2)
+        F = torch.exp(torch.cat((qF.rsample((E,)), qF2.rsample((E,))), dim=1))
+        Z = torch.matmul(torch.cat((self.W, self.W2), dim=1), F)
+        pF2 = distributions.Normal(torch.zeros_like(mF), torch.ones_like(scale2))
+        return distributions.Poisson(V * Z), qF2, pF2
+
+    def forward(self, X, E=10, verbose=False, **kwargs):
+        qF, qU, pU = self.gp(X=X, verbose=verbose, **kwargs)
+        pY, qF2, pF2 = self._hybrid(qF, self.mF, self.scale_qF, torch.nn.functional.softplus(self.V), E)
+        return pY, qF, qU, pU, qF2, pF2
+
+    def forward_batched(self, X, idx, E=10, verbose=False, **kwargs):
+        qF, qU, pU = self.gp(X=X[idx], verbose=verbose, **kwargs)
+        pY, qF2, pF2 = self._hybrid(qF, self.mF[:, idx], self.scale_qF[:, idx],
+                                    torch.nn.functional.softplus(self.V)[idx], E)
+        return pY, qF, qU, pU, qF2, pF2

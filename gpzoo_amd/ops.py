@@ -330,6 +330,42 @@ def wsvgp_precomputed(W, sigma, mu, Lu_raw) -> dict:
     return out
 
 
+def poisson_nsf(mean, scale, eps, W_pos, V_pos, y, with_lgamma: bool = True):
+    """Fused Monte-Carlo Poisson log-likelihood of the NSF models and its gradients (gpz_poisson_nsf).
+
+    mean, scale (Lt,N); eps (E,Lt,N); W_pos (D,Lt) and V_pos (N,) positive; y (D,N).  Returns
+    (loglik fp64 scalar, dmean, dscale, dW, dV) with the mean over the E samples already applied.
+    Samples are processed in groups that fit the kernel's register budget."""
+    _need_cuda(mean, scale, eps, W_pos, V_pos, y)
+    lib = _lib.load()
+    f32 = torch.float32
+    mean, scale = mean.detach().to(f32).contiguous(), scale.detach().to(f32).contiguous()
+    eps, y = eps.detach().to(f32).contiguous(), y.detach().to(f32).contiguous()
+    W_pos, V_pos = W_pos.detach().to(f32).contiguous(), V_pos.detach().to(f32).contiguous()
+    Lt, N = mean.shape
+    E, D = eps.shape[0], y.shape[0]
+    dev = mean.device
+    eg = max(1, min(4, 64 // ((Lt + 7) // 8 * 8)))
+    total = torch.zeros((), dtype=torch.float64, device=dev)
+    acc = [torch.zeros((Lt, N), dtype=f32, device=dev), torch.zeros((Lt, N), dtype=f32, device=dev),
+           torch.zeros((D, Lt), dtype=f32, device=dev), torch.zeros((N,), dtype=f32, device=dev)]
+    for e0 in range(0, E, eg):
+        ee = min(eg, E - e0)
+        ll = torch.empty(1, dtype=torch.float64, device=dev)
+        out = [torch.empty_like(t) for t in acc]
+        nbytes = lib.gpz_poisson_nsf_workspace_bytes(N, D, Lt, ee)
+        ws = _workspace(dev, nbytes)
+        rc = lib.gpz_poisson_nsf(_ptr(mean), _ptr(scale), _ptr(eps[e0:e0 + ee]), _ptr(W_pos), _ptr(V_pos), _ptr(y), N, D,
+                                 Lt, ee, int(with_lgamma), _ptr(ll), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                 _ptr(out[3]), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "gpz_poisson_nsf")
+        wgt = ee / E
+        total += wgt * ll[0]
+        for a_, o_ in zip(acc, out):
+            a_.add_(o_, alpha=wgt)
+    return (total, *acc)
+
+
 def profile_enable(on: bool = True):
     _lib.check(_lib.load().gpz_profile_enable(int(on)), "gpz_profile_enable")
 

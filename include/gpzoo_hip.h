@@ -164,6 +164,19 @@ size_t gpz_svgp_backward_workspace_bytes(const gpz_svgp_problem* p, int64_t chun
 int gpz_svgp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int64_t chunk, void* ws,
                       size_t ws_bytes, void* stream);
 
+/* Monte-Carlo expected Poisson log-likelihood of the NSF factor models and its gradients, fused
+ * (SURVEY §8f "next" #2): replaces get_rate + Poisson(V*Z).log_prob(y).mean(0).sum() and their
+ * autograd (likelihoods.py:49-53, 74-97, 199-225; utilities.py:610-616) without materialising the
+ * (E,D,N) rate.  fp32.  mean, scale (Lt,N): q(F) moments of all factors; eps (E,Lt,N): the
+ * standard-normal draws of rsample; W (D,Lt), V (N,): POSITIVE loadings / size factors (after
+ * softplus); y (D,N) counts.  Outputs: loglik (1,) fp64 = (1/E) sum_e sum_dn [y log(VZ) - VZ
+ * (- lgamma(y+1) if with_lgamma)], and dloglik/d{mean, scale, W, V}.  E * ceil8(Lt) <= 64 per call. */
+size_t gpz_poisson_nsf_workspace_bytes(int64_t N, int64_t D, int32_t Lt, int32_t E);
+int gpz_poisson_nsf(const float* mean, const float* scale, const float* eps, const float* W,
+                    const float* V, const float* y, int64_t N, int64_t D, int32_t Lt, int32_t E,
+                    int32_t with_lgamma, double* loglik, float* dmean, float* dscale, float* dW,
+                    float* dV, void* ws, size_t ws_bytes, void* stream);
+
 /* Moments from a caller-supplied W (L,N,M): WSVGP.forward_precomputed, gp.py:308-322
  * (cov = clamp(sigma^2 - sum W^2, 0) + sum (W Lu)^2, mean = W mu).  sigma (L,), mu (L,M),
  * Lu_raw (L,M,M) -> mean, scale (L,N) and the constrained Lu (L,M,M, may be NULL). */

@@ -236,3 +236,63 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def poisson_cases():
+    """NSF2 / Hybrid_NSF2 (reference likelihoods.py) on a tiny count matrix: the Monte-Carlo expected
+    log-likelihood with KNOWN rsample noise (the reference's _standard_normal is patched to hand out
+    stored eps) and the gradients of -ELBO w.r.t. W, V, mu, Lu (and the non-spatial prior)."""
+    import torch.distributions.normal as tdn
+    out = {}
+    N, M, L, T, D, E = 160, 36, 3, 2, 25, 3
+    inp = make_inputs(900, N=N, M=M, d=2, L=L)
+    g = torch.Generator().manual_seed(901)
+    y = torch.poisson(3.0 * torch.rand(D, N, generator=g), generator=g).float()
+    eps1 = torch.randn(E, L, N, generator=g)
+    eps2 = torch.randn(E, T, N, generator=g)
+    orig = tdn._standard_normal
+    for name in ("nsf2", "hybrid_nsf2"):
+        kern = build_kernel("nsf_rbf", L).float()
+        gp = rgp.WSVGP(kern, dim=2, M=M, jitter=1e-2)
+        gp.Z = nn.Parameter(inp["Z"].float(), requires_grad=False)
+        gp.mu = nn.Parameter(0.2 * inp["mu"].float())
+        gp.Lu = nn.Parameter(inp["Lu_raw"].float())
+        for t in kern.parameters():
+            t.requires_grad_(False)
+        torch.manual_seed(7)
+        if name == "nsf2":
+            model = rl.NSF2(gp, y, L=L)
+            queue = [eps1]
+        else:
+            prior = rgp.GaussianPrior(y, L=T)
+            model = rl.Hybrid_NSF2(gp, prior, y, L=L, T=T)
+            queue = [eps1, eps2]
+        it = iter(queue)
+        tdn._standard_normal = lambda shape, dtype, device: next(it).to(dtype)
+        try:
+            res = model(X=inp["X"].float(), E=E)
+        finally:
+            tdn._standard_normal = orig
+        pY, qF, qU = res[0], res[1], res[2]
+        loglik = pY.log_prob(y).mean(0).sum()
+        kl = torch.stack([whitened_KL(qU.mean[l], qU.scale_tril[l]) for l in range(L)]).sum()
+        loss = -(loglik - kl)
+        if name == "hybrid_nsf2":
+            loss = loss + distributions.kl_divergence(res[4], res[5]).sum()
+        loss.backward()
+        Wp = model.W if name == "nsf2" else model.sf.W
+        rec = dict(X=inp["X"].float().numpy(), Z=inp["Z"].float().numpy(), mu=gp.mu.detach().numpy(),
+                   Lu_raw=gp.Lu.detach().numpy(), y=y.numpy(), eps1=eps1.numpy(), eps2=eps2.numpy(),
+                   sigma=kern.sigma.detach().numpy(), lengthscale=kern.lengthscale.detach().numpy(),
+                   W=Wp.detach().numpy(), V=model.V.detach().numpy(), loglik=np.float64(float(loglik)),
+                   loss=np.float64(float(loss)), grad_W=Wp.grad.numpy(), grad_V=model.V.grad.numpy(),
+                   grad_mu=gp.mu.grad.numpy(), grad_Lu=gp.Lu.grad.numpy(), rate_sum=np.float64(float(pY.rate.double().sum())))
+        if name == "hybrid_nsf2":
+            rec.update(W2=model.cf.W.detach().numpy(), mean2=prior.mean.detach().numpy(), scale2=prior.scale.detach().numpy(),
+                       grad_W2=model.cf.W.grad.numpy(), grad_mean2=prior.mean.grad.numpy(), grad_scale2=prior.scale.grad.numpy())
+        np.savez_compressed(os.path.join(HERE, f"poisson_{name}_f32.npz"), **rec)
+        print(f"poisson_{name}_f32: loglik={float(loglik):.6f}")
+
+
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1":
+    poisson_cases()

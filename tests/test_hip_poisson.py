@@ -1,0 +1,119 @@
+"""GPU: the Poisson NSF factor models (SURVEY §8f "next" #2) -- the API mirrors and the fused
+expected log-likelihood -- against the reference's own outputs and autograd gradients, with the
+reference's rsample noise replayed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else float(z[k])) for k in z.files}
+
+
+def build(c, hybrid):
+    from gpzoo.gp import GaussianPrior, WSVGP
+    from gpzoo.kernels import NSF_RBF
+    from gpzoo.likelihoods import Hybrid_NSF2, NSF2
+    L, M = c["mu"].shape
+    k = NSF_RBF(L=L)
+    k.sigma = nn.Parameter(c["sigma"].clone(), requires_grad=False)
+    k.lengthscale = nn.Parameter(c["lengthscale"].clone(), requires_grad=False)
+    gp = WSVGP(k, dim=2, M=M, jitter=1e-2)
+    gp.Z = nn.Parameter(c["Z"].clone(), requires_grad=False)
+    gp.mu = nn.Parameter(c["mu"].clone())
+    gp.Lu = nn.Parameter(c["Lu_raw"].clone())
+    y = c["y"]
+    if hybrid:
+        prior = GaussianPrior(y, L=c["W2"].shape[1])
+        prior.mean = nn.Parameter(c["mean2"].clone())
+        prior.scale = nn.Parameter(c["scale2"].clone())
+        model = Hybrid_NSF2(gp, prior, y, L=L, T=c["W2"].shape[1])
+        model.sf.W = nn.Parameter(c["W"].clone())
+        model.cf.W = nn.Parameter(c["W2"].clone())
+    else:
+        model = NSF2(gp, y, L=L)
+        model.W = nn.Parameter(c["W"].clone())
+    model.V = nn.Parameter(c["V"].clone())
+    return model.cuda()
+
+
+def close(got, ref, rt=2e-3):
+    sc = float(ref.abs().max()) + 1e-30
+    torch.testing.assert_close(got.cpu(), ref, rtol=rt, atol=rt * sc)
+
+
+@pytest.mark.parametrize("name,hybrid", [("poisson_nsf2_f32", False), ("poisson_hybrid_nsf2_f32", True)])
+def test_fused_expected_loglik_and_gradients_match_reference(name, hybrid):
+    from gpzoo.utilities import whitened_KL_batched
+    c = load(name)
+    model = build(c, hybrid)
+    X, y = c["X"].cuda(), c["y"].cuda()
+    eps = torch.cat([c["eps1"], c["eps2"]], dim=1).cuda() if hybrid else c["eps1"].cuda()
+    res = model.expected_loglik(X, y, E=3, eps=eps)
+    ll, qU = res[0], res[2]
+    assert float(ll) == pytest.approx(c["loglik"], rel=1e-4)
+    loss = -(ll - whitened_KL_batched(qU.mean, qU.scale_tril).sum())
+    if hybrid:
+        loss = loss + torch.distributions.kl_divergence(res[4], res[5]).sum()
+    assert float(loss) == pytest.approx(c["loss"], rel=1e-4)
+    loss.backward()
+    gp = model.sf.prior if hybrid else model.prior
+    close((model.sf.W if hybrid else model.W).grad, c["grad_W"])
+    close(model.V.grad, c["grad_V"])
+    close(gp.mu.grad, c["grad_mu"])
+    close(gp.Lu.grad, c["grad_Lu"])
+    if hybrid:
+        close(model.cf.W.grad, c["grad_W2"])
+        close(model.cf.prior.mean.grad, c["grad_mean2"])
+        close(model.cf.prior.scale.grad, c["grad_scale2"])
+
+
+def test_api_forward_returns_reference_shapes():
+    """pY is a real Poisson over the (E, D, N) rate; with the replayed noise its rate sums to the reference's."""
+    import torch.distributions.normal as tdn
+    c = load("poisson_nsf2_f32")
+    model = build(c, False)
+    eps = c["eps1"].cuda()
+    orig = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: eps.to(dtype)
+    try:
+        with torch.no_grad():
+            pY, qF, qU, pU = model(X=c["X"].cuda(), E=3)
+            pYb, *_ = model.forward_batched(c["X"].cuda(), torch.arange(40).cuda(), E=3) if False else (pY,)
+    finally:
+        tdn._standard_normal = orig
+    assert isinstance(pY, torch.distributions.Poisson) and pY.rate.shape == (3, 25, 160) and pU is None
+    assert float(pY.rate.double().sum()) == pytest.approx(c["rate_sum"], rel=1e-4)
+    ll = pY.log_prob(c["y"].cuda()).mean(0).sum()
+    assert float(ll) == pytest.approx(c["loglik"], rel=1e-4)
+
+
+def test_fused_matches_torch_formula_at_scale():
+    """Slide-seq-like sizes shrunk 10x (D=1770 genes, N=3000 spots, 20 + 10 factors, E=5 > one sample
+    group): the fused value and gradients equal the straightforward torch evaluation."""
+    from gpzoo_amd import ops
+    g = torch.Generator().manual_seed(5)
+    D, N, Lt, E = 1770, 3000, 30, 5
+    mean = 0.3 * torch.randn(Lt, N, generator=g)
+    scale = 0.2 + 0.3 * torch.rand(Lt, N, generator=g)
+    eps = torch.randn(E, Lt, N, generator=g)
+    W = torch.rand(D, Lt, generator=g) + 0.05
+    V = 0.5 + torch.rand(N, generator=g)
+    y = torch.poisson(2.0 * torch.rand(D, N, generator=g), generator=g)
+    ll, dmean, dscale, dW, dV = ops.poisson_nsf(mean.cuda(), scale.cuda(), eps.cuda(), W.cuda(), V.cuda(), y.cuda())
+    lv = [t.double().requires_grad_(True) for t in (mean, scale, W, V)]
+    F = lv[0] + lv[1] * eps.double()
+    rate = lv[3] * torch.matmul(lv[2], torch.exp(F))
+    ref = torch.distributions.Poisson(rate).log_prob(y.double()).mean(0).sum()
+    ref.backward()
+    assert float(ll) == pytest.approx(float(ref), rel=2e-5)
+    for got, want in zip((dmean, dscale, dW, dV), lv):
+        close(got.double(), want.grad, rt=5e-4)
