@@ -7,7 +7,7 @@
 // them in loss.backward():
 //   F[e,l,n]   = mean[l,n] + scale[l,n] * eps[e,l,n]            (rsample with the caller's eps)
 //   Z[e,d,n]   = sum_l W[d,l] exp(F[e,l,n]),   rate = V[n] Z[e,d,n]
-//   loglik     = (1/E) sum_{e,d,n} ( y[d,n] log rate - rate - lgamma(y[d,n] + 1) )
+//   loglik[0]  = (1/E) sum_{e,d,n} ( y[d,n] log rate - rate ),   loglik[1] = sum_{d,n} lgamma(y[d,n] + 1)
 //   dW[d,l]    = (1/E) sum_{e,n} (y/Z - V) expF,     dexpF[e,l,n] = (1/E) sum_d (y/Z - V) W[d,l]
 //   dV[n]      = (1/E) sum_{e,d} (y/V - Z),          dmean = sum_e dexpF expF,  dscale = sum_e dexpF expF eps
 // W and V are the POSITIVE (already soft-plussed) factors; the chain through softplus stays in torch.
@@ -31,7 +31,7 @@ struct PoissonArgs {
   const float* mean; const float* scale; const float* eps;   // (Lt,N), (Lt,N), (E,Lt,N)
   const float* W; const float* V; const float* y;            // (D,Lt) positive, (N,) positive, (D,N)
   float* expF;                                               // (E,Lt,N) scratch
-  float* dexp_slab; float* dV_slab; double* ll_slab;          // [S][E][Lt][N], [S][N], [S][nblk]
+  float* dexp_slab; float* dV_slab; double* ll_slab;          // [S][E][Lt][N], [S][N], [2][S][nblk]
   float* dW; float* dmean; float* dscale; float* dV; double* loglik;
   int64_t N, D;
   int Lt, E, S, with_lgamma;
@@ -77,10 +77,11 @@ __global__ __launch_bounds__(256) void spot_kernel(PoissonArgs a) {
     }
   const float Vn = live ? a.V[n] : 1.f;
   const float inv_e = 1.f / (float)E;
+  const float inv_v = __builtin_amdgcn_rcpf(Vn);
   const int64_t dper = (a.D + a.S - 1) / a.S;
   const int64_t d_lo = s * dper, d_hi = (d_lo + dper < a.D) ? d_lo + dper : a.D;
-  double ll = 0.0;
-  float dv = 0.f;
+  double ll = 0.0, lg = 0.0;
+  float dv = 0.f, llf = 0.f, llg = 0.f;   // fp32 partials over one 64-gene refill, folded into fp64
   for (int64_t d0 = d_lo; d0 < d_hi; d0 += WCH) {
     __syncthreads();
     for (int i = threadIdx.x; i < WCH * LT; i += 256) {
@@ -89,26 +90,37 @@ __global__ __launch_bounds__(256) void spot_kernel(PoissonArgs a) {
     }
     __syncthreads();
     const int rows = (int)((d_hi - d0 < WCH) ? d_hi - d0 : WCH);
-    for (int r = 0; r < rows; ++r) {
-      const float yv = live ? a.y[(d0 + r) * a.N + n] : 0.f;
-      float lsum = 0.f;
+    constexpr int RB = 8;                 // y rows fetched ahead of their use (hides the global-load latency)
+    for (int r0 = 0; r0 < rows; r0 += RB) {
+      float yb[RB];
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        float z = 0.f;
+      for (int k = 0; k < RB; ++k) yb[k] = (live && r0 + k < rows) ? a.y[(d0 + r0 + k) * a.N + n] : 0.f;
 #pragma unroll
-        for (int l = 0; l < LT; ++l) z = fmaf(sW[r][l], ef[e][l], z);
-        const float rate = Vn * z;
-        lsum += yv * __logf(rate) - rate;
-        const float g = (yv / z - Vn) * inv_e;
-        dv += (yv / Vn - z) * inv_e;
+      for (int k = 0; k < RB; ++k) {
+        const int r = r0 + k;
+        if (r < rows) {
+          const float yv = yb[k];
+          float lsum = 0.f;
 #pragma unroll
-        for (int l = 0; l < LT; ++l) de[e][l] = fmaf(g, sW[r][l], de[e][l]);
-      }
-      if (live) {
-        ll += (double)(lsum * inv_e);
-        if (a.with_lgamma) ll -= lgamma((double)yv + 1.0);
+          for (int e = 0; e < E; ++e) {
+            float z = 0.f;
+#pragma unroll
+            for (int l = 0; l < LT; ++l) z = fmaf(sW[r][l], ef[e][l], z);
+            const float rate = Vn * z;
+            lsum += yv * __logf(rate) - rate;
+            const float g = (yv * __builtin_amdgcn_rcpf(z) - Vn) * inv_e;
+            dv += (yv * inv_v - z) * inv_e;
+#pragma unroll
+            for (int l = 0; l < LT; ++l) de[e][l] = fmaf(g, sW[r][l], de[e][l]);
+          }
+          llf += lsum;
+          if (a.with_lgamma) llg += lgammaf(yv + 1.f);
+        }
       }
     }
+    ll += (double)(llf * inv_e);
+    lg += (double)llg;
+    llf = 0.f; llg = 0.f;
   }
   if (live) {
 #pragma unroll
@@ -119,23 +131,29 @@ __global__ __launch_bounds__(256) void spot_kernel(PoissonArgs a) {
     a.dV_slab[(int64_t)s * a.N + n] = dv;
   }
   const double t = block_sum_d(live ? ll : 0.0, sh);
-  if (threadIdx.x == 0) a.ll_slab[(int64_t)s * gridDim.x + blockIdx.x] = t;
+  const double tg = block_sum_d(live ? lg : 0.0, sh);
+  if (threadIdx.x == 0) {
+    a.ll_slab[(int64_t)s * gridDim.x + blockIdx.x] = t;
+    a.ll_slab[((int64_t)a.S + s) * gridDim.x + blockIdx.x] = tg;
+  }
 }
 
-// grid (ceil(D/4)): wave = gene; lanes sweep the spots in tiles of 64 staged in LDS
+// grid (ceil(D/(4*GPW))): each wave owns GPW genes; lanes sweep the spots in tiles of 64 staged in LDS
+constexpr int GPW = 4;
 template <int LT, int E>
 __global__ __launch_bounds__(256) void gene_kernel(PoissonArgs a) {
   __shared__ float sF[E][LT][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t d = (int64_t)blockIdx.x * 4 + wave;
-  const bool live = d < a.D;
+  const int64_t dbase = ((int64_t)blockIdx.x * 4 + wave) * GPW;
   const int64_t per = (int64_t)a.Lt * a.N;
-  float w[LT], acc[LT];
+  float w[GPW][LT], acc[GPW][LT];
 #pragma unroll
-  for (int l = 0; l < LT; ++l) {
-    w[l] = (live && l < a.Lt) ? a.W[d * a.Lt + l] : 0.f;
-    acc[l] = 0.f;
-  }
+  for (int gq = 0; gq < GPW; ++gq)
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      w[gq][l] = (dbase + gq < a.D && l < a.Lt) ? a.W[(dbase + gq) * a.Lt + l] : 0.f;
+      acc[gq][l] = 0.f;
+    }
   const float inv_e = 1.f / (float)E;
   for (int64_t n0 = 0; n0 < a.N; n0 += 64) {
     __syncthreads();
@@ -145,25 +163,36 @@ __global__ __launch_bounds__(256) void gene_kernel(PoissonArgs a) {
     }
     __syncthreads();
     const int64_t n = n0 + lane;
-    if (live && n < a.N) {
-      const float yv = a.y[d * a.N + n], Vn = a.V[n];
+    if (n < a.N) {
+      const float Vn = a.V[n];
+      float yv[GPW];
+#pragma unroll
+      for (int gq = 0; gq < GPW; ++gq) yv[gq] = (dbase + gq < a.D) ? a.y[(dbase + gq) * a.N + n] : 0.f;
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        float z = 0.f;
+        float f[LT];
 #pragma unroll
-        for (int l = 0; l < LT; ++l) z = fmaf(w[l], sF[e][l][lane], z);
-        const float g = (yv / z - Vn) * inv_e;
+        for (int l = 0; l < LT; ++l) f[l] = sF[e][l][lane];
 #pragma unroll
-        for (int l = 0; l < LT; ++l) acc[l] = fmaf(g, sF[e][l][lane], acc[l]);
+        for (int gq = 0; gq < GPW; ++gq) {
+          float z = 0.f;
+#pragma unroll
+          for (int l = 0; l < LT; ++l) z = fmaf(w[gq][l], f[l], z);
+          const float g = (dbase + gq < a.D) ? (yv[gq] * __builtin_amdgcn_rcpf(z) - Vn) * inv_e : 0.f;
+#pragma unroll
+          for (int l = 0; l < LT; ++l) acc[gq][l] = fmaf(g, f[l], acc[gq][l]);
+        }
       }
     }
   }
 #pragma unroll
-  for (int l = 0; l < LT; ++l) {
-    float v = acc[l];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if (lane == 0 && live && l < a.Lt) a.dW[d * a.Lt + l] = v;
-  }
+  for (int gq = 0; gq < GPW; ++gq)
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+      float v = acc[gq][l];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+      if (lane == 0 && dbase + gq < a.D && l < a.Lt) a.dW[(dbase + gq) * a.Lt + l] = v;
+    }
 }
 
 // dmean, dscale (Lt,N) and dV (N) from the gene-slice slabs; log-lik total
@@ -189,10 +218,11 @@ __global__ __launch_bounds__(256) void poisson_finish_kernel(PoissonArgs a, int 
     a.dV[i] = dv;
   }
   if (blockIdx.x == 0) {
-    double v = 0.0;
-    for (int j = threadIdx.x; j < a.S * nblk_spot; j += 256) v += a.ll_slab[j];
+    double v = 0.0, vg = 0.0;
+    for (int j = threadIdx.x; j < a.S * nblk_spot; j += 256) { v += a.ll_slab[j]; vg += a.ll_slab[a.S * nblk_spot + j]; }
     const double t = block_sum_d(v, sh);
-    if (threadIdx.x == 0) *a.loglik = t;
+    const double tg = block_sum_d(vg, sh);
+    if (threadIdx.x == 0) { a.loglik[0] = t; a.loglik[1] = tg; }
   }
 }
 
@@ -211,7 +241,7 @@ static PoissonPlan poisson_plan(int64_t N, int64_t D, int Lt, int E, void* ws) {
   pl.expF = c.take<float>((int64_t)E * Lt * N);
   pl.dexp = c.take<float>((int64_t)pl.S * E * Lt * N);
   pl.dVs = c.take<float>((int64_t)pl.S * N);
-  pl.ll = c.take<double>((int64_t)pl.S * pl.nblk);
+  pl.ll = c.take<double>((int64_t)2 * pl.S * pl.nblk);
   pl.bytes = c.used();
   return pl;
 }
@@ -247,7 +277,7 @@ extern "C" int gpz_poisson_nsf(const float* mean, const float* scale, const floa
   const int64_t tot = (int64_t)E * Lt * N;
   hipLaunchKernelGGL(expf_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a);
   GPZ_LAUNCH_OK();
-  const dim3 gs((unsigned)pl.nblk, (unsigned)pl.S), gg((unsigned)((D + 3) / 4));
+  const dim3 gs((unsigned)pl.nblk, (unsigned)pl.S), gg((unsigned)((D + 4 * GPW - 1) / (4 * GPW)));
 #define GPZ_PO(LT, EE)                                                         \
   do {                                                                         \
     hipLaunchKernelGGL((spot_kernel<LT, EE>), gs, dim3(256), 0, s, a);         \

@@ -351,16 +351,18 @@ def poisson_nsf(mean, scale, eps, W_pos, V_pos, y, with_lgamma: bool = True):
            torch.zeros((D, Lt), dtype=f32, device=dev), torch.zeros((N,), dtype=f32, device=dev)]
     for e0 in range(0, E, eg):
         ee = min(eg, E - e0)
-        ll = torch.empty(1, dtype=torch.float64, device=dev)
+        ll = torch.empty(2, dtype=torch.float64, device=dev)
         out = [torch.empty_like(t) for t in acc]
         nbytes = lib.gpz_poisson_nsf_workspace_bytes(N, D, Lt, ee)
         ws = _workspace(dev, nbytes)
         rc = lib.gpz_poisson_nsf(_ptr(mean), _ptr(scale), _ptr(eps[e0:e0 + ee]), _ptr(W_pos), _ptr(V_pos), _ptr(y), N, D,
-                                 Lt, ee, int(with_lgamma), _ptr(ll), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                 Lt, ee, int(with_lgamma and e0 == 0), _ptr(ll), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
                                  _ptr(out[3]), _ptr(ws), ws.numel(), _stream())
         _lib.check(rc, "gpz_poisson_nsf")
         wgt = ee / E
         total += wgt * ll[0]
+        if with_lgamma and e0 == 0:
+            total -= ll[1]          # the parameter-free lgamma(y+1) term is evaluated once
         for a_, o_ in zip(acc, out):
             a_.add_(o_, alpha=wgt)
     return (total, *acc)
