@@ -47,5 +47,49 @@ def main():
             print(f"{cls.__name__:6s} cache={cache!s:5s} step = {1e3 * min(times[1:]):7.2f} ms  (loss {loss.item():.1f})")
 
 
+def nsf_main():
+    """NSF2 (Poisson) minibatch step: Slideseq_NSF_newest_version.ipynb shape -- D=17702 genes, N_b=7000,
+    M=3000, L=20, E=3 -- through the fused GP pass and the fused Poisson expected log-likelihood."""
+    from gpzoo.likelihoods import NSF2
+    from gpzoo.utilities import whitened_KL_batched
+    torch.manual_seed(0)
+    N, Nb, M, L, D, E = 20000, 7000, 3000, 20, 17702, 3
+    dev = torch.device("cuda")
+    X = (torch.rand(N, 2) * 200 - 100).to(dev)
+    y = torch.poisson(2.0 * torch.rand(D, N)).to(dev)
+    gp = WSVGP(NSF_RBF(sigma=1.0, lengthscale=8.0, L=L), dim=2, M=M, jitter=1e-1)
+    gp.Z = nn.Parameter(X[torch.randperm(N)[:M]].clone().cpu(), requires_grad=False)
+    gp.mu = nn.Parameter(torch.zeros(L, M))
+    gp.Lu = nn.Parameter(0.01 * torch.randn(L, M, M))
+    for t in gp.kernel.parameters():
+        t.requires_grad_(False)
+    model = NSF2(gp, y.cpu()[:, :8], L=L)
+    model.V = nn.Parameter(torch.ones(N))
+    model = model.to(dev)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    for fused in (False, True):
+        times = []
+        for it in range(5):
+            idx = torch.randperm(N, device=dev)[:Nb]
+            yb = y[:, idx]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            if fused:
+                ll, qF, qU, pU = model.expected_loglik(X, yb, idx=idx, E=E)
+            else:
+                pY, qF, qU, pU = model.forward_batched(X, idx, E=E)
+                ll = pY.log_prob(yb).mean(0).sum()
+            loss = -(ll - whitened_KL_batched(qU.mean, qU.scale_tril).sum())
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        print(f"NSF2 Poisson step, fused log-lik={fused!s:5s}: {1e3 * min(times[1:]):7.2f} ms  (loss {loss.item():.4g})")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "nsf":
+        nsf_main()
+    else:
+        main()
