@@ -183,6 +183,32 @@ class _FusedGP(nn.Module):
         return out["elbo"], out["kl"], out["loglik"]
 
 
+class VNNGP(nn.Module):
+    """Nearest-neighbour variational GP; reference gp.py:7-122 (forward only, RBF-family kernels: the
+    ones with ``return_distance``).  The reference's scalar-``RBF`` path raises (gp.py:83 repeats the
+    neighbour table N times instead of L); here a scalar kernel returns ``(N,)`` moments."""
+
+    def __init__(self, kernel, dim=1, M=50, K=3, jitter=1e-4):
+        super().__init__()
+        self.kernel = kernel
+        self.jitter = jitter
+        self.K = K
+        self.Z = nn.Parameter(torch.randn((M, dim)))
+        self.Lu = nn.Parameter(torch.randn((M, M)))
+        self.mu = nn.Parameter(torch.zeros((M,)))
+        self.constraint = constraints.lower_cholesky
+
+    def forward(self, X, verbose=False):
+        nlat = 1 if self.mu.dim() == 1 else int(self.mu.shape[0])
+        spec = kernel_spec(self.kernel, X, nlat)
+        out = ops.vnngp_forward(spec, X, self.Z, self.mu, self.Lu, float(self.jitter), int(self.K))
+        pick = (lambda t: t[0]) if self.mu.dim() == 1 else (lambda t: t)
+        qF = distributions.Normal(pick(out["mean"]), pick(out["scale"]))
+        qU = distributions.MultivariateNormal(self.mu, scale_tril=pick(out["Lu"]))
+        pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(out["chol"]))
+        return qF, qU, pU
+
+
 class GaussianPrior(nn.Module):
     """Mean-field Normal prior for the non-spatial factors; reference gp.py:125-146 (no kernel work)."""
 

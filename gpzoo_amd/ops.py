@@ -330,6 +330,42 @@ def wsvgp_precomputed(W, sigma, mu, Lu_raw) -> dict:
     return out
 
 
+def knn(X, Z, K: int) -> torch.Tensor:
+    """(N,K) int64 indices of the K nearest rows of Z per row of X, ties to the lower index."""
+    _need_cuda(X, Z)
+    lib = _lib.load()
+    X = X.detach().contiguous()
+    Z = Z.detach().to(X.dtype).contiguous()
+    idx = torch.empty((X.shape[0], K), dtype=torch.int64, device=X.device)
+    rc = lib.gpz_knn(_ptr(X), X.shape[0], _ptr(Z), Z.shape[0], X.shape[1], K, _dt(X), _ptr(idx), _stream())
+    _lib.check(rc, "gpz_knn")
+    return idx
+
+
+def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, clamp_min: float = 5e-2,
+                  check_info: bool = True) -> dict:
+    """VNNGP forward (gpz_vnngp_forward): mean, scale (L,N), Lu, chol (L,M,M), idx (N,K)."""
+    _need_cuda(X, Z, mu, Lu_raw)
+    lib = _lib.load()
+    keep: list = []
+    p, (L, M, N, dt, dev) = _problem(spec, X, Z, mu, Lu_raw, jitter, False, None, None, clamp_min, keep)
+    out = {"mean": torch.empty((L, N), dtype=dt, device=dev), "scale": torch.empty((L, N), dtype=dt, device=dev),
+           "Lu": torch.empty((L, M, M), dtype=dt, device=dev), "chol": torch.empty((L, M, M), dtype=dt, device=dev)}
+    info = torch.empty(L, dtype=torch.int32, device=dev)
+    p.mean, p.scale, p.Lu, p.chol = (out[k].data_ptr() for k in ("mean", "scale", "Lu", "chol"))
+    p.info = info.data_ptr()
+    out["idx"] = knn(X, Z, K)
+    nbytes = lib.gpz_vnngp_workspace_bytes(C.byref(p), K)
+    if nbytes == 0:
+        _lib.check(-1, "gpz_vnngp_workspace_bytes")
+    ws = _workspace(dev, nbytes)
+    rc = lib.gpz_vnngp_forward(C.byref(p), K, _ptr(out["idx"]), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "gpz_vnngp_forward")
+    if check_info and bool(info.any()):
+        _raise_not_pd(info, "linalg.cholesky")
+    return out
+
+
 def poisson_nsf(mean, scale, eps, W_pos, V_pos, y, with_lgamma: bool = True):
     """Fused Monte-Carlo Poisson log-likelihood of the NSF models and its gradients (gpz_poisson_nsf).
 

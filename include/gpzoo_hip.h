@@ -178,6 +178,19 @@ int gpz_poisson_nsf(const float* mean, const float* scale, const float* eps, con
                     int32_t with_lgamma, double* loglik, float* dmean, float* dscale, float* dW,
                     float* dV, void* ws, size_t ws_bytes, void* stream);
 
+/* K nearest rows of Z for every row of X, ascending by (Euclidean distance, index): the neighbour
+ * bookkeeping of VNNGP, argsort(cdist(X, Z))[:, :K] (gp.py:31, 64).  idx (N,K) int64.  K <= 32. */
+int gpz_knn(const void* X, int64_t N, const void* Z, int64_t M, int32_t d, int32_t K, int32_t dtype,
+            int64_t* idx, void* stream);
+
+/* VNNGP.forward (gp.py:21-122), RBF family only (the kernels with return_distance).  Uses the
+ * problem's X, Z, kernel, mu, Lu_raw, jitter, var_clamp_min (the reference clamps at 5e-2) and
+ * writes mean, scale (L,N), optionally Lu and chol, and info.  idx: (N,K) neighbour lists from
+ * gpz_knn, or NULL to compute them here. */
+size_t gpz_vnngp_workspace_bytes(const gpz_svgp_problem* p, int32_t K);
+int gpz_vnngp_forward(const gpz_svgp_problem* p, int32_t K, const int64_t* idx, void* ws,
+                      size_t ws_bytes, void* stream);
+
 /* Moments from a caller-supplied W (L,N,M): WSVGP.forward_precomputed, gp.py:308-322
  * (cov = clamp(sigma^2 - sum W^2, 0) + sum (W Lu)^2, mean = W mu).  sigma (L,), mu (L,M),
  * Lu_raw (L,M,M) -> mean, scale (L,N) and the constrained Lu (L,M,M, may be NULL). */

@@ -217,3 +217,37 @@ def elbo_eval(kind: str, whitened: bool, X, y, Z, sigma, lengthscale, mu, Lu_raw
         mean, scale, Lu, chol = svgp_moments(Kxx, Kzx, Kzz, mu, Lu_raw, clamp_min)
         kl = mvn_kl(mu, Lu, chol)
     return gaussian_elbo(y, mean, scale, noise_sd, kl), mean, scale
+
+
+# --------------------------------------------------------------------------
+# VNNGP: K nearest inducing points per datum (gp.py:7-122)
+# --------------------------------------------------------------------------
+
+def vnngp_moments(X, Z, sigma, lengthscale, mu, Lu_raw, jitter: float, K: int):
+    """q(F) of the nearest-neighbour variational GP (gp.py:21-122): for every x the K nearest
+    inducing points (argsort of torch.cdist, gp.py:31,64), the K x K blocks of L L^T = Kzz + jitter I
+    (jittered once more in place, gp.py:68-77), W = k_xz[idx] inv(block), S block from Lu[idx],
+    then svgp_forward (utilities.py:382-397) and clamp(cov, 5e-2) (gp.py:117).
+    Returns mean, scale (L,N) or (N,), the neighbour indices (N,K), Lu, chol."""
+    batched = sigma.dim() > 0
+    s = sigma.reshape(-1, 1, 1)
+    ell = lengthscale.reshape(-1, 1, 1)
+    dist = torch.cdist(X, Z)
+    Kxz = s ** 2 * torch.exp(-0.5 * dist ** 2 / ell ** 2)                      # (L,N,M)
+    Kzz = s ** 2 * torch.exp(-0.5 * torch.cdist(Z, Z) ** 2 / ell ** 2)
+    Lq = lower_cholesky_param(Lu_raw).reshape(-1, Z.shape[0], Z.shape[0])
+    chol = torch.linalg.cholesky(add_jitter_(Kzz.contiguous(), jitter))
+    idx = torch.argsort(dist, dim=1)[:, :K]                                     # (N,K)
+    lL = chol[:, idx]                                                           # (L,N,K,M)
+    lK = lL @ lL.transpose(-2, -1)
+    lK = add_jitter_(lK.reshape(-1, K, K).contiguous(), jitter).reshape(lK.shape)
+    W = (torch.gather(Kxz, 2, idx.expand(Kxz.shape[0], -1, -1))[:, :, None, :] @ torch.inverse(lK))  # (L,N,1,K)
+    lmu = mu.reshape(-1, Z.shape[0])[:, idx]                                    # (L,N,K)
+    lLu = Lq[:, idx]
+    lS = lLu @ lLu.transpose(-2, -1)
+    mean = (W @ lmu[..., None]).squeeze(-1).squeeze(-1)
+    cov = s.reshape(-1, 1) ** 2 + ((W @ (lS - lK)) * W).sum(-1).squeeze(-1)
+    scale = cov.clamp(min=5e-2) ** 0.5
+    if not batched:
+        mean, scale = mean[0], scale[0]
+    return mean, scale, idx, lower_cholesky_param(Lu_raw), chol if batched else chol[0]

@@ -294,5 +294,34 @@ def poisson_cases():
         print(f"poisson_{name}_f32: loglik={float(loglik):.6f}")
 
 
+def vnngp_cases():
+    """VNNGP (reference gp.py:7-122; its unconditional prints are swallowed) with NSF_RBF.  With a
+    scalar-parameter RBF the reference raises (indexes.repeat(Kxx_shape[0], 1) uses N for L, gp.py:83),
+    so only the per-latent kernel has reference vectors."""
+    import contextlib
+    import io
+    for kind, L in (("nsf_rbf", 3), ("nsf_rbf", 2)):
+        for dtype, tag in ((torch.float64, f"L{L}_f64"), (torch.float32, f"L{L}_f32")):
+            inp = make_inputs(700 + L, N=160, M=36, d=2, L=L)
+            kern = build_kernel(kind, L)
+            gp = rgp.VNNGP(kern, dim=2, M=36, K=5, jitter=1e-2)
+            gp.Z = nn.Parameter(inp["Z"].clone())
+            gp.mu = nn.Parameter(inp["mu"].clone())
+            gp.Lu = nn.Parameter(inp["Lu_raw"].clone())
+            gp = gp.double() if dtype == torch.float64 else gp.float()
+            X = inp["X"].to(dtype)
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                qF, qU, pU = gp(X)
+                _, dist = kern(X, gp.Z, return_distance=True)
+            idx = torch.argsort(dist, dim=1)[:, :5]
+            rec = dict(X=X.numpy(), Z=gp.Z.detach().numpy(), mu=gp.mu.detach().numpy(), Lu_raw=gp.Lu.detach().numpy(),
+                       sigma=kern.sigma.detach().numpy(), lengthscale=kern.lengthscale.detach().numpy(),
+                       mean=qF.mean.numpy(), scale=qF.scale.numpy(), idx=idx.numpy(), Lu=qU.scale_tril.numpy(),
+                       chol=pU.scale_tril.numpy(), jitter=np.float64(1e-2), K=np.int64(5))
+            np.savez_compressed(os.path.join(HERE, f"vnngp_{kind}_{tag}.npz"), **rec)
+            print(f"vnngp_{kind}_{tag}: mean[0..2]={qF.mean.reshape(-1)[:3].tolist()}")
+
+
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1":
     poisson_cases()
+    vnngp_cases()

@@ -1,0 +1,73 @@
+"""GPU: VNNGP (SURVEY §8f "next" #4): bit-exact neighbour bookkeeping and the q(F) moments against
+the reference's own outputs; larger cases against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["vnngp_nsf_rbf_L3_f64", "vnngp_nsf_rbf_L3_f32", "vnngp_nsf_rbf_L2_f64", "vnngp_nsf_rbf_L2_f32"]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k].item()) for k in z.files}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_module_matches_reference(name):
+    from gpzoo.gp import VNNGP
+    from gpzoo.kernels import NSF_RBF
+    from gpzoo_amd import ops
+    c = load(name)
+    L = c["sigma"].shape[0]
+    k = NSF_RBF(L=L)
+    k.sigma = nn.Parameter(c["sigma"].clone()); k.lengthscale = nn.Parameter(c["lengthscale"].clone())
+    gp = VNNGP(k, dim=2, M=c["Z"].shape[0], K=int(c["K"]), jitter=float(c["jitter"]))
+    gp.Z = nn.Parameter(c["Z"].clone()); gp.mu = nn.Parameter(c["mu"].clone()); gp.Lu = nn.Parameter(c["Lu_raw"].clone())
+    gp = gp.cuda()
+    X = c["X"].cuda()
+    idx = ops.knn(X, gp.Z, int(c["K"]))
+    assert torch.equal(idx.cpu(), c["idx"])                       # bit-exact index bookkeeping
+    with torch.no_grad():
+        qF, qU, pU = gp(X)
+    rt = 1e-5 if X.dtype == torch.float64 else 1e-3
+    torch.testing.assert_close(qF.mean.cpu(), c["mean"], rtol=rt, atol=rt * 1e-1)
+    torch.testing.assert_close(qF.scale.cpu(), c["scale"], rtol=rt, atol=rt * 1e-1)
+    torch.testing.assert_close(qU.scale_tril.cpu(), c["Lu"], rtol=rt, atol=rt * 1e-2)
+    torch.testing.assert_close(pU.scale_tril.cpu(), c["chol"], rtol=rt, atol=rt * 1e-2)
+
+
+@pytest.mark.parametrize("N,M,K,L", [(3000, 300, 10, 4), (500, 40, 32, 2), (64, 5, 5, 1), (1000, 130, 1, 3)])
+def test_against_oracle_at_scale(N, M, K, L):
+    from gpzoo_amd import _lib, ops
+    from gpzoo_amd.ops import KernelSpec
+    from oracle import svgp_oracle as O
+    g = torch.Generator().manual_seed(N + K)
+    X = (torch.rand(N, 2, generator=g, dtype=torch.float64) - 0.5) * 40
+    Z = (torch.rand(M, 2, generator=g, dtype=torch.float64) - 0.5) * 40
+    sig = 0.7 + torch.rand(L, generator=g, dtype=torch.float64)
+    ell = 2.0 + 4 * torch.rand(L, generator=g, dtype=torch.float64)
+    mu = torch.randn(L, M, generator=g, dtype=torch.float64)
+    Lu = 0.1 * torch.randn(L, M, M, generator=g, dtype=torch.float64)
+    mean, scale, idx, _, chol = O.vnngp_moments(X, Z, sig, ell, mu, Lu, 1e-2, K)
+    out = ops.vnngp_forward(KernelSpec(_lib.KERNEL_RBF, sig.cuda(), ell.cuda(), True), X.cuda(), Z.cuda(), mu.cuda(),
+                            Lu.cuda(), 1e-2, K)
+    assert torch.equal(out["idx"].cpu(), idx)
+    torch.testing.assert_close(out["mean"].cpu(), mean, rtol=1e-7, atol=1e-9)
+    torch.testing.assert_close(out["scale"].cpu(), scale, rtol=1e-7, atol=1e-9)
+    torch.testing.assert_close(out["chol"].cpu(), chol.reshape(L, M, M), rtol=1e-8, atol=1e-10)
+
+
+def test_knn_ties_resolve_to_lower_index():
+    """Equidistant inducing points (a regular grid around the datum): stable ascending order."""
+    from gpzoo_amd import ops
+    Z = torch.tensor([[1.0, 0.0], [0.0, 1.0], [-1.0, 0.0], [0.0, -1.0], [2.0, 0.0], [0.0, 0.0]], dtype=torch.float64)
+    X = torch.zeros(3, 2, dtype=torch.float64)
+    idx = ops.knn(X.cuda(), Z.cuda(), 4).cpu()
+    assert idx.tolist() == [[5, 0, 1, 2]] * 3

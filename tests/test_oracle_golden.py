@@ -71,3 +71,16 @@ def test_embedding_default_distances():
     emb = O.embed_group_distances(torch.ones(G, G) - torch.eye(G))
     d2 = O.sqdist_direct(emb, emb)
     torch.testing.assert_close(d2, (torch.ones(G, G) - torch.eye(G)), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["vnngp_nsf_rbf_L3_f64", "vnngp_nsf_rbf_L3_f32", "vnngp_nsf_rbf_L2_f64", "vnngp_nsf_rbf_L2_f32"])
+def test_oracle_vnngp(name):
+    z = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, name + ".npz"))
+    t = {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+    mean, scale, idx, Lu, chol = O.vnngp_moments(t["X"], t["Z"], t["sigma"], t["lengthscale"], t["mu"], t["Lu_raw"],
+                                                 t["jitter"], int(t["K"]))
+    assert torch.equal(idx, t["idx"])                      # neighbour bookkeeping is bit-exact
+    tol = dict(rtol=1e-9, atol=1e-11) if t["X"].dtype == torch.float64 else dict(rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(mean, t["mean"], **tol)
+    torch.testing.assert_close(scale, t["scale"], **tol)
+    torch.testing.assert_close(chol.reshape(t["chol"].shape), t["chol"], **tol)
