@@ -70,6 +70,9 @@ _SIGNATURES = {
                           C.c_void_p]),
     "gpz_vnngp_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int32]),
     "gpz_vnngp_forward": (C.c_int, [C.POINTER(SvgpProblem), C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gpz_vnngp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int32]),
+    "gpz_vnngp_backward": (C.c_int, [C.POINTER(SvgpProblem), C.POINTER(SvgpGrads), C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     "gpz_wsvgp_precomputed_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "gpz_wsvgp_precomputed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

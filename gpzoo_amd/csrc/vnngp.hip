@@ -1,4 +1,4 @@
-// vnngp.hip -- nearest-neighbour variational GP forward (SURVEY.md §8f "next" #4).
+// vnngp.hip -- nearest-neighbour variational GP, forward and backward (SURVEY.md §8f "next" #4).
 //
 // Replaces VNNGP.forward (reference gp.py:21-122): for every x_n the K nearest inducing points
 // (argsort(cdist(X, Z))[:, :K], gp.py:31,64), the K x K blocks of Kzz + jitter I (jittered once more,
@@ -15,8 +15,16 @@
 //   vnngp_point_kernel thread = (latent, datum): gathers the K x K blocks, Cholesky-solves for W in
 //                     fp64 and evaluates mean = W mu[idx], cov = s^2 + W S W^T - W k.  Per-thread
 //                     matrices sit in a [element][thread] global scratch so every access is coalesced.
+//   vnngp_point_bwd_kernel  same thread mapping: recomputes the point's solve and pushes dLoss/dmean,
+//                     dLoss/dscale back to mu[idx], the S and Kzz blocks and k_xz[idx].  The K-sparse
+//                     contributions are scattered with hardware fp64 atomics into dense (L,M) / (L,M,M)
+//                     accumulators (sums of doubles in arbitrary order: reproducible to rounding, not
+//                     bitwise); the dense tails -- dS -> dLu, Cholesky backward of dLoss/dchol, the
+//                     contraction with dKzz/d(sigma, lengthscale, Z) -- reuse the fp64 GEMM and kgrad.hip.
 #include "common.h"
 #include "gemm.h"
+
+#include <algorithm>
 
 namespace gpz {
 
@@ -25,6 +33,20 @@ int kfill_padded(const gpz_kernel_desc* k, const void* A, int64_t nA, int64_t pA
                  double jitter, int pad_identity, int out_dtype, hipStream_t s);
 int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
                  int32_t* info, hipStream_t s);
+int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* Dinv, double* Linv, int64_t Mp,
+                 int64_t batch, double* T, hipStream_t s);
+
+struct KgradArgs {   // kgrad.hip
+  const void* Kbar; int64_t ld, stride;
+  const void* Z; const void* X;
+  const int64_t* gZ; const int64_t* gX;
+  const void* sigma; const void* ell; const void* ga; const void* gr2;
+  double gpow, scalar_scale;
+  int64_t M, ncols, Mp;
+  int d, G;
+  double* acc;
+};
+int kgrad_launch(int dtype, int kind, const KgradArgs& a, int L, hipStream_t s);
 
 constexpr int KNN_MAX = 32;
 
@@ -81,18 +103,13 @@ struct VnnArgs {
   double jitter, clamp_min;
 };
 
+// Per-point forward state left in the thread's scratch columns: A = Cholesky factor of the jittered
+// K x K block (lower), kx = k(x, z_idx), w = A^{-1} kx, sw = S_block w.  Returns mean and the unclamped cov.
 template <typename T>
-__global__ __launch_bounds__(256) void vnngp_point_kernel(VnnArgs<T> a) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)a.L * a.N;
-  if (t >= total) return;
-  const int l = (int)(t / a.N);
-  const int64_t n = t - (int64_t)l * a.N;
+__device__ __forceinline__ void vnn_point_solve(const VnnArgs<T>& a, int64_t t, int64_t total, int l, int64_t n,
+                                                const int64_t* id, double* A, double* kx, double* w, double* sw,
+                                                double& mean, double& cov) {
   const int K = a.K;
-  const int64_t* id = a.idx + n * K;
-  double* A = a.scratch + t;                               // A[p*K+q] at A[(p*K+q) * total]
-  double* kx = a.scratch + (int64_t)K * K * total + t;     // kx[p] at kx[p * total]
-  double* w = kx + (int64_t)K * total;
   const double* Kl = a.Kzz + (int64_t)l * a.Mp * a.Mp;
   const double* Sl = a.S + (int64_t)l * a.Mp * a.Mp;
   const double sg = (double)a.sigma[l], el = (double)a.ell[l];
@@ -126,19 +143,113 @@ __global__ __launch_bounds__(256) void vnngp_point_kernel(VnnArgs<T> a) {
     for (int k = i + 1; k < K; ++k) v -= A[(int64_t)(k * K + i) * total] * w[k * total];
     w[i * total] = v / A[(int64_t)(i * K + i) * total];
   }
-  double mean = 0.0, wk = 0.0, wsw = 0.0;
+  double wk = 0.0, wsw = 0.0;
+  mean = 0.0;
   for (int p = 0; p < K; ++p) {
     const double wp = w[p * total];
     mean += wp * (double)a.mu[(int64_t)l * a.M + id[p]];
     wk += wp * kx[p * total];                     // W (Kzz block) W^T = W k
     double row = 0.0;
     for (int q = 0; q < K; ++q) row += Sl[id[p] * a.Mp + id[q]] * w[q * total];
+    if (sw) sw[p * total] = row;
     wsw += wp * row;
   }
-  double cov = s2 + wsw - wk;
+  cov = s2 + wsw - wk;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vnngp_point_kernel(VnnArgs<T> a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)a.L * a.N;
+  if (t >= total) return;
+  const int l = (int)(t / a.N);
+  const int64_t n = t - (int64_t)l * a.N;
+  const int K = a.K;
+  double* A = a.scratch + t;                               // A[p*K+q] at A[(p*K+q) * total]
+  double* kx = a.scratch + (int64_t)K * K * total + t;     // kx[p] at kx[p * total]
+  double* w = kx + (int64_t)K * total;
+  double mean, cov;
+  vnn_point_solve<T>(a, t, total, l, n, a.idx + n * K, A, kx, w, nullptr, mean, cov);
   if (!(cov > a.clamp_min)) cov = a.clamp_min;
   a.mean[t] = (T)mean;
   a.scale[t] = (T)sqrt(cov);
+}
+
+template <typename T>
+struct VnnBwdArgs {
+  VnnArgs<T> f;                 // scratch holds (K*K + 4K) columns here
+  const T* g_mean; const T* g_scale;
+  double* gmu;                  // (L,Mp)
+  double* gS;                   // (L,Mp,Mp)  dLoss/dS, symmetric
+  double* gK;                   // (L,Mp,Mp)  dLoss/d(Kzz + jitter I) from the K x K blocks, or null
+  double* kacc;                 // (L,Mp,8)   dz0..3, dsigma, dlengthscale (kgrad.hip layout), or null
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void vnngp_point_bwd_kernel(VnnBwdArgs<T> b) {
+  const VnnArgs<T>& a = b.f;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)a.L * a.N;
+  if (t >= total) return;
+  const int l = (int)(t / a.N);
+  const int64_t n = t - (int64_t)l * a.N;
+  const int K = a.K;
+  const int64_t* id = a.idx + n * K;
+  double* A = a.scratch + t;
+  double* kx = a.scratch + (int64_t)K * K * total + t;
+  double* w = kx + (int64_t)K * total;
+  double* sw = w + (int64_t)K * total;
+  double* v = sw + (int64_t)K * total;
+  double mean, cov;
+  vnn_point_solve<T>(a, t, total, l, n, id, A, kx, w, sw, mean, cov);
+  const double gm = (double)b.g_mean[t];
+  // scale = sqrt(clamp(cov, min)): no gradient through a clamped variance (gp.py:117)
+  const double gcov = (cov > a.clamp_min) ? 0.5 * (double)b.g_scale[t] / sqrt(cov) : 0.0;
+  // dLoss/dW with W free, then through W = A^{-1} k:  v = A^{-1} gW,  dk = v - gcov W,  dA = -v W^T
+  for (int p = 0; p < K; ++p)
+    v[p * total] = gm * (double)a.mu[(int64_t)l * a.M + id[p]] + gcov * (2.0 * sw[p * total] - kx[p * total]);
+  for (int i = 0; i < K; ++i) {
+    double r = v[i * total];
+    for (int k = 0; k < i; ++k) r -= A[(int64_t)(i * K + k) * total] * v[k * total];
+    v[i * total] = r / A[(int64_t)(i * K + i) * total];
+  }
+  for (int i = K - 1; i >= 0; --i) {
+    double r = v[i * total];
+    for (int k = i + 1; k < K; ++k) r -= A[(int64_t)(k * K + i) * total] * v[k * total];
+    v[i * total] = r / A[(int64_t)(i * K + i) * total];
+  }
+  double* gmu = b.gmu + (int64_t)l * a.Mp;
+  double* gS = b.gS + (int64_t)l * a.Mp * a.Mp;
+  double* gK = b.gK ? b.gK + (int64_t)l * a.Mp * a.Mp : nullptr;
+  const double sg = (double)a.sigma[l], el = (double)a.ell[l], il2 = 1.0 / (el * el);
+  double dsig = gcov * 2.0 * sg, dell = 0.0;
+  for (int p = 0; p < K; ++p) {
+    const int64_t ip = id[p];
+    const double wp = w[p * total], vp = v[p * total];
+    if (gm != 0.0) unsafeAtomicAdd(gmu + ip, gm * wp);
+    for (int q = 0; q < K; ++q) {
+      const double wq = w[q * total];
+      if (gcov != 0.0) unsafeAtomicAdd(gS + ip * a.Mp + id[q], gcov * wp * wq);
+      if (gK) unsafeAtomicAdd(gK + ip * a.Mp + id[q], -vp * wq);
+    }
+    if (b.kacc) {
+      const double kv = kx[p * total], gk = (vp - gcov * wp) * kv;   // dLoss/dk_p * k_p
+      double d2 = 0.0;
+      double* acc = b.kacc + ((int64_t)l * a.Mp + ip) * 8;
+      for (int k = 0; k < a.d; ++k) {
+        const double df = (double)a.X[n * a.d + k] - (double)a.Z[ip * a.d + k];
+        d2 += df * df;
+        unsafeAtomicAdd(acc + k, gk * df * il2);                     // dk/dz = k (x - z) / l^2
+      }
+      dsig += gk * 2.0 / sg;
+      dell += gk * d2 * il2 / el;
+    }
+  }
+  if (b.kacc) {
+    double* acc = b.kacc + ((int64_t)l * a.Mp + id[0]) * 8;
+    unsafeAtomicAdd(acc + 4, dsig);
+    unsafeAtomicAdd(acc + 5, dell);
+  }
 }
 
 // (L,Mp,Mp) fp64 symmetric copy of the lower triangle (the fill wrote the full matrix already; this
@@ -167,9 +278,15 @@ __global__ void vnn_chol_out_kernel(const double* __restrict__ Lc, int64_t Mp, i
   out[(int64_t)l * M * M + i * M + j] = (j <= i) ? (T)Lc[(int64_t)l * Mp * Mp + i * Mp + j] : (T)0;
 }
 
-struct VnnPlan { int64_t L, N, M, Mp; int K; size_t bytes; double *Kzz, *Kfac, *Dinv, *LuD, *S, *scratch; int64_t* idx; };
+struct VnnPlan {
+  int64_t L, N, M, Mp; int K; size_t bytes;
+  double *Kzz, *Kfac, *Dinv, *LuD, *S, *scratch; int64_t* idx;
+  // backward only
+  double *gmu, *gS, *gK, *kacc, *G, *Linv, *Tmp, *D1, *D2; void* PS;
+};
 
-static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws) {
+static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws, int bwd = 0, bool kernel_grads = false,
+                        bool with_chol = false) {
   VnnPlan pl;
   pl.L = p->k.n_latent; pl.N = p->N; pl.M = p->M; pl.Mp = pad_up(p->M); pl.K = K;
   const int64_t mm = pl.L * pl.Mp * pl.Mp;
@@ -179,8 +296,26 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
   pl.Dinv = c.take<double>(pl.L * (pl.Mp / 128) * 128 * 128);
   pl.LuD = c.take<double>(mm);
   pl.S = c.take<double>(mm);
-  pl.scratch = c.take<double>((int64_t)(K * K + 2 * K) * pl.L * pl.N);
+  pl.scratch = c.take<double>((int64_t)(K * K + (bwd ? 4 : 2) * K) * pl.L * pl.N);
   pl.idx = own_idx ? c.take<int64_t>(pl.N * K) : nullptr;
+  pl.gmu = pl.gS = pl.gK = pl.kacc = pl.G = pl.Linv = pl.Tmp = pl.D1 = pl.D2 = nullptr;
+  pl.PS = nullptr;
+  if (bwd) {
+    pl.gmu = c.take<double>(pl.L * pl.Mp);
+    pl.gS = c.take<double>(mm);
+    pl.G = c.take<double>(mm);
+    if (kernel_grads) {
+      pl.gK = c.take<double>(mm);
+      pl.kacc = c.take<double>(pl.L * pl.Mp * 8);
+      pl.PS = c.take<double>(mm);       // holds T; sized for fp64
+      if (with_chol) {
+        pl.Linv = c.take<double>(mm);
+        pl.Tmp = c.take<double>(mm / 2);
+        pl.D1 = c.take<double>(mm);
+        pl.D2 = c.take<double>(mm);
+      }
+    }
+  }
   pl.bytes = c.used();
   return pl;
 }
@@ -190,22 +325,19 @@ static int knn_t(const void* X, int64_t N, const void* Z, int64_t M, int d, int 
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
 #define GPZ_KNN(KM) hipLaunchKernelGGL((knn_kernel<T, KM>), grid, block, 0, s, static_cast<const T*>(X), N, \
                                        static_cast<const T*>(Z), M, d, K, idx)
-  // the sorted list must hold exactly K entries (see the note above), so KM == K is instantiated per size class
-  // by padding with +inf sentinels: a list of KM >= K entries keeps the K smallest in its first K slots
+  // a sorted list of KM >= K entries keeps the K smallest in its first K slots
   if (K <= 4) GPZ_KNN(4); else if (K <= 8) GPZ_KNN(8); else if (K <= 16) GPZ_KNN(16); else GPZ_KNN(32);
 #undef GPZ_KNN
   GPZ_LAUNCH_OK();
   return 0;
 }
 
+// Kzz + jitter I, its Cholesky factor, S = Lu Lu^T and the neighbour table: shared by forward and backward
 template <typename T>
-static int vnngp_t(const gpz_svgp_problem* p, int K, const int64_t* idx_in, void* ws, size_t ws_bytes, hipStream_t s) {
-  VnnPlan pl = vnn_plan(p, K, idx_in == nullptr, ws);
-  GPZ_REQUIRE(ws_bytes >= pl.bytes, "gpz_vnngp_forward: workspace too small");
+static int vnn_prepare(const gpz_svgp_problem* p, VnnPlan& pl, const int64_t* idx_in, VnnArgs<T>& a, hipStream_t s) {
   const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, N = pl.N, mm = Mp * Mp;
   const int L32 = (int)L;
   const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
-  // Kzz + jitter I (fp64, symmetric, identity padded) and its Cholesky factor (for pU)
   if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, nullptr, nullptr, pl.Kzz, Mp, mm, p->jitter, 1, GPZ_F64, s))
     return rc;
   GPZ_HIP_OK(hipMemcpyAsync(pl.Kfac, pl.Kzz, sizeof(double) * L * mm, hipMemcpyDeviceToDevice, s));
@@ -225,16 +357,205 @@ static int vnngp_t(const gpz_svgp_problem* p, int K, const int64_t* idx_in, void
   if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
   const int64_t* idx = idx_in;
   if (!idx) {
-    if (int rc = knn_t<T>(p->X, N, p->Z, M, p->d, K, pl.idx, s)) return rc;
+    if (int rc = knn_t<T>(p->X, N, p->Z, M, p->d, pl.K, pl.idx, s)) return rc;
     idx = pl.idx;
   }
-  VnnArgs<T> a;
   a.X = static_cast<const T*>(p->X); a.Z = static_cast<const T*>(p->Z);
   a.sigma = static_cast<const T*>(p->k.sigma); a.ell = static_cast<const T*>(p->k.lengthscale);
   a.mu = static_cast<const T*>(p->mu); a.Kzz = pl.Kzz; a.S = pl.S; a.idx = idx; a.scratch = pl.scratch;
   a.mean = static_cast<T*>(p->mean); a.scale = static_cast<T*>(p->scale);
-  a.N = N; a.M = M; a.Mp = Mp; a.d = p->d; a.K = K; a.L = L32; a.jitter = p->jitter; a.clamp_min = p->var_clamp_min;
-  hipLaunchKernelGGL((vnngp_point_kernel<T>), dim3((unsigned)((L * N + 255) / 256)), dim3(256), 0, s, a);
+  a.N = N; a.M = M; a.Mp = Mp; a.d = p->d; a.K = pl.K; a.L = L32; a.jitter = p->jitter; a.clamp_min = p->var_clamp_min;
+  return 0;
+}
+
+template <typename T>
+static int vnngp_t(const gpz_svgp_problem* p, int K, const int64_t* idx_in, void* ws, size_t ws_bytes, hipStream_t s) {
+  VnnPlan pl = vnn_plan(p, K, idx_in == nullptr, ws);
+  GPZ_REQUIRE(ws_bytes >= pl.bytes, "gpz_vnngp_forward: workspace too small");
+  VnnArgs<T> a;
+  if (int rc = vnn_prepare<T>(p, pl, idx_in, a, s)) return rc;
+  hipLaunchKernelGGL((vnngp_point_kernel<T>), dim3((unsigned)((pl.L * pl.N + 255) / 256)), dim3(256), 0, s, a);
+  GPZ_LAUNCH_OK();
+  return 0;
+}
+
+// ---- backward tails -----------------------------------------------------------------------------
+template <typename T>
+__global__ void vnn_mu_out_kernel(const double* __restrict__ gmu, int64_t Mp, int64_t M, T* __restrict__ out) {
+  const int l = blockIdx.y;
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m < M) out[(int64_t)l * M + m] = (T)gmu[(int64_t)l * Mp + m];
+}
+
+// chain rule of Lu = tril(raw, -1) + diag(exp(diag raw)) applied to G = dLoss/dLu (fp64, padded)
+template <typename T>
+__global__ void vnn_lu_grad_kernel(const double* __restrict__ G, int64_t Mp, int64_t M, const T* __restrict__ raw,
+                                   T* __restrict__ out) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  const double g = G[(int64_t)l * Mp * Mp + i * Mp + j];
+  double v = 0.0;
+  if (j < i) v = g;
+  else if (j == i) v = g * exp((double)raw[(int64_t)l * M * M + i * M + i]);
+  out[(int64_t)l * M * M + i * M + j] = (T)v;
+}
+
+// dst (L,Mp,Mp) fp64 = tril(src (L,M,M)), zero padded
+template <typename T>
+__global__ void vnn_tril_in_kernel(const T* __restrict__ src, int64_t M, int64_t Mp, double* __restrict__ dst) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  dst[(int64_t)l * Mp * Mp + i * Mp + j] = (i < M && j <= i) ? (double)src[(int64_t)l * M * M + i * M + j] : 0.0;
+}
+
+// dst = transpose(tril(src)), (L,Mp,Mp) fp64
+__global__ __launch_bounds__(256) void vnn_tril_transpose_kernel(const double* __restrict__ src, int64_t Mp,
+                                                                double* __restrict__ dst) {
+  __shared__ double tile[32][33];
+  const int l = blockIdx.z;
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t i = i0 + rr, j = j0 + tx;
+    tile[rr][tx] = (j <= i) ? src[(int64_t)l * Mp * Mp + i * Mp + j] : 0.0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) dst[(int64_t)l * Mp * Mp + (j0 + rr) * Mp + i0 + tx] = tile[tx][rr];
+}
+
+// Phi of the Cholesky backward: keep the lower triangle, halve the diagonal
+__global__ void vnn_phi_kernel(double* __restrict__ A, int64_t Mp) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  double& v = A[(int64_t)l * Mp * Mp + i * Mp + j];
+  if (j > i) v = 0.0;
+  else if (j == i) v *= 0.5;
+}
+
+// dst = (P + P^T) [+ (Q + Q^T)] cast to T
+template <typename T>
+__global__ __launch_bounds__(256) void vnn_sym_cast_kernel(const double* __restrict__ P, const double* __restrict__ Q,
+                                                          int64_t Mp, T* __restrict__ dst) {
+  __shared__ double tile[32][33];
+  const int l = blockIdx.z;
+  const int64_t i0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t base = (int64_t)l * Mp * Mp;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t o = base + (j0 + rr) * Mp + i0 + tx;
+    tile[rr][tx] = P[o] + (Q ? Q[o] : 0.0);
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t o = base + (i0 + rr) * Mp + j0 + tx;
+    dst[o] = (T)(P[o] + (Q ? Q[o] : 0.0) + tile[tx][rr]);
+  }
+}
+
+// grad_Z[m][k] = sum_l acc[l][m][k];  grad_theta[l][q] = sum_m acc[l][m][4+q]
+__global__ __launch_bounds__(256) void vnn_kgrad_finish_kernel(const double* __restrict__ acc, int L, int64_t Mp, int64_t M,
+                                                              int d, double* __restrict__ grad_Z,
+                                                              double* __restrict__ grad_theta) {
+  __shared__ double sh[256];
+  if (blockIdx.y == 0) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < M && grad_Z)
+      for (int k = 0; k < 4; ++k) {
+        double t = 0.0;
+        if (k < d)
+          for (int l = 0; l < L; ++l) t += acc[((int64_t)l * Mp + m) * 8 + k];
+        grad_Z[m * 4 + k] = t;
+      }
+  } else if ((int)blockIdx.x < L && grad_theta) {
+    const int l = blockIdx.x;
+    for (int q = 0; q < 2; ++q) {
+      double v = 0.0;
+      for (int64_t m = threadIdx.x; m < M; m += 256) v += acc[((int64_t)l * Mp + m) * 8 + 4 + q];
+      __syncthreads();
+      sh[threadIdx.x] = v;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) grad_theta[l * 4 + q] = sh[0];
+    }
+    if (threadIdx.x == 0) grad_theta[l * 4 + 2] = grad_theta[l * 4 + 3] = 0.0;
+  }
+}
+
+template <typename T>
+static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int K, const int64_t* idx_in, void* ws,
+                            size_t ws_bytes, hipStream_t s) {
+  const bool kgrads = g->grad_theta != nullptr || g->grad_Z != nullptr;
+  const bool with_chol = kgrads && g->g_chol != nullptr;
+  VnnPlan pl = vnn_plan(p, K, idx_in == nullptr, ws, 1, kgrads, with_chol);
+  GPZ_REQUIRE(ws_bytes >= pl.bytes, "gpz_vnngp_backward: workspace too small");
+  const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, mm = Mp * Mp;
+  const int L32 = (int)L;
+  gpz_svgp_problem q = *p;           // forward-only outputs are not produced again
+  q.chol = nullptr; q.Lu = nullptr;
+  VnnBwdArgs<T> b;
+  if (int rc = vnn_prepare<T>(&q, pl, idx_in, b.f, s)) return rc;
+  GPZ_HIP_OK(hipMemsetAsync(pl.gmu, 0, sizeof(double) * L * Mp, s));
+  GPZ_HIP_OK(hipMemsetAsync(pl.gS, 0, sizeof(double) * L * mm, s));
+  if (kgrads) {
+    GPZ_HIP_OK(hipMemsetAsync(pl.gK, 0, sizeof(double) * L * mm, s));
+    GPZ_HIP_OK(hipMemsetAsync(pl.kacc, 0, sizeof(double) * L * Mp * 8, s));
+  }
+  b.g_mean = static_cast<const T*>(g->g_mean); b.g_scale = static_cast<const T*>(g->g_scale);
+  b.gmu = pl.gmu; b.gS = pl.gS; b.gK = pl.gK; b.kacc = pl.kacc;
+  hipLaunchKernelGGL((vnngp_point_bwd_kernel<T>), dim3((unsigned)((L * pl.N + 255) / 256)), dim3(256), 0, s, b);
+  GPZ_LAUNCH_OK();
+  const dim3 g32((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32);
+  const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
+  auto dgemm = [&](const double* A, const double* B, double* C, int flags, double alpha) -> int {
+    GemmParams<double> d;
+    d.A = A; d.lda = Mp; d.sA0 = mm; d.B = B; d.ldb = Mp; d.sB0 = mm; d.C = C; d.ldc = Mp; d.sC0 = mm;
+    d.nb0 = L32; d.mt = d.nt = (int)(Mp / 128); d.K = (int)Mp; d.flags = flags; d.alpha = alpha;
+    return gemm_launch(d, EPI_STORE, s);
+  };
+  hipLaunchKernelGGL((vnn_mu_out_kernel<T>), dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, pl.gmu, Mp, M,
+                     static_cast<T*>(g->grad_mu));
+  GPZ_LAUNCH_OK();
+  // S = Lu Lu^T, dS symmetric: dLoss/dLu = tril(2 dS Lu)
+  GPZ_HIP_OK(hipMemsetAsync(pl.G, 0, sizeof(double) * L * mm, s));
+  if (int rc = dgemm(pl.gS, pl.LuD, pl.G, GF_B_LOWER | GF_TILES_LOWER, 2.0)) return rc;
+  hipLaunchKernelGGL((vnn_lu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)M, L32), dim3(256), 0, s, pl.G,
+                     Mp, M, static_cast<const T*>(p->Lu_raw), static_cast<T*>(g->grad_Lu_raw));
+  GPZ_LAUNCH_OK();
+  if (!kgrads) return 0;
+  const double* P = nullptr;
+  if (with_chol) {
+    // Cholesky backward (Murray 2016) of the upstream dLoss/dchol: P = Linv^T Phi(L^T Lbar) Linv
+    if (int rc = trtri_padded(pl.Kfac, Mp, mm, pl.Dinv, pl.Linv, Mp, L, pl.Tmp, s)) return rc;
+    hipLaunchKernelGGL((vnn_tril_in_kernel<T>), gm, dim3(256), 0, s, static_cast<const T*>(g->g_chol), M, Mp, pl.D1);
+    GPZ_LAUNCH_OK();                                                                          // D1 = Lbar
+    hipLaunchKernelGGL(vnn_tril_transpose_kernel, g32, dim3(256), 0, s, pl.Kfac, Mp, pl.G);   // G  = L^T
+    GPZ_LAUNCH_OK();
+    if (int rc = dgemm(pl.G, pl.D1, pl.D2, GF_A_UPPER | GF_B_LOWER, 1.0)) return rc;          // D2 = L^T Lbar
+    hipLaunchKernelGGL(vnn_phi_kernel, gm, dim3(256), 0, s, pl.D2, Mp);
+    GPZ_LAUNCH_OK();
+    GPZ_HIP_OK(hipMemsetAsync(pl.D1, 0, sizeof(double) * L * mm, s));
+    if (int rc = dgemm(pl.D2, pl.Linv, pl.D1, GF_A_LOWER | GF_B_LOWER | GF_TILES_LOWER, 1.0)) return rc;   // D1 = Phi Linv
+    hipLaunchKernelGGL(vnn_tril_transpose_kernel, g32, dim3(256), 0, s, pl.Linv, Mp, pl.G);  // G  = Linv^T
+    GPZ_LAUNCH_OK();
+    if (int rc = dgemm(pl.G, pl.D1, pl.D2, GF_A_UPPER | GF_B_LOWER, 1.0)) return rc;          // D2 = P
+    P = pl.D2;
+  }
+  hipLaunchKernelGGL((vnn_sym_cast_kernel<T>), g32, dim3(256), 0, s, pl.gK, P, Mp, static_cast<T*>(pl.PS));
+  GPZ_LAUNCH_OK();
+  KgradArgs ka;
+  ka.Kbar = pl.PS; ka.ld = Mp; ka.stride = mm; ka.Z = p->Z; ka.X = p->Z; ka.gZ = nullptr; ka.gX = nullptr;
+  ka.sigma = p->k.sigma; ka.ell = p->k.lengthscale; ka.ga = nullptr; ka.gr2 = nullptr;
+  ka.gpow = 0.0; ka.scalar_scale = 0.5; ka.M = M; ka.ncols = M; ka.Mp = Mp; ka.d = p->d; ka.G = 0; ka.acc = pl.kacc;
+  if (int rc = kgrad_launch(p->dtype, GPZ_KERNEL_RBF, ka, L32, s)) return rc;
+  const unsigned fx = (unsigned)std::max<int64_t>((M + 255) / 256, L);
+  hipLaunchKernelGGL(vnn_kgrad_finish_kernel, dim3(fx, 2), dim3(256), 0, s, pl.kacc, L32, Mp, M, p->d, g->grad_Z,
+                     g->grad_theta);
   GPZ_LAUNCH_OK();
   return 0;
 }
@@ -253,7 +574,7 @@ extern "C" int gpz_knn(const void* X, int64_t N, const void* Z, int64_t M, int32
 }
 
 static int vnn_check(const gpz_svgp_problem* p, int K) {
-  GPZ_REQUIRE(p && p->X && p->Z && p->mu && p->Lu_raw && p->info && p->mean && p->scale, "gpz_vnngp: null pointer");
+  GPZ_REQUIRE(p && p->X && p->Z && p->mu && p->Lu_raw && p->info, "gpz_vnngp: null pointer");
   GPZ_REQUIRE(p->dtype == GPZ_F32 || p->dtype == GPZ_F64, "gpz_vnngp: bad dtype");
   GPZ_REQUIRE(p->k.kind == GPZ_KERNEL_RBF, "gpz_vnngp: only the RBF family supports return_distance (kernels.py:118-126)");
   GPZ_REQUIRE(p->k.n_latent >= 1 && p->N >= 1 && p->M >= 1 && p->d >= 1 && p->d <= 4, "gpz_vnngp: bad extents");
@@ -269,7 +590,22 @@ extern "C" size_t gpz_vnngp_workspace_bytes(const gpz_svgp_problem* p, int32_t K
 extern "C" int gpz_vnngp_forward(const gpz_svgp_problem* p, int32_t K, const int64_t* idx, void* ws, size_t ws_bytes,
                                  void* stream) {
   if (int rc = vnn_check(p, K)) return rc;
-  GPZ_REQUIRE(ws, "gpz_vnngp_forward: null workspace");
+  GPZ_REQUIRE(ws && p->mean && p->scale, "gpz_vnngp_forward: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
   return p->dtype == GPZ_F32 ? vnngp_t<float>(p, K, idx, ws, ws_bytes, s) : vnngp_t<double>(p, K, idx, ws, ws_bytes, s);
+}
+
+extern "C" size_t gpz_vnngp_backward_workspace_bytes(const gpz_svgp_problem* p, int32_t K) {
+  if (vnn_check(p, K)) return 0;
+  return vnn_plan(p, K, true, nullptr, 1, true, true).bytes;
+}
+
+extern "C" int gpz_vnngp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int32_t K, const int64_t* idx,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = vnn_check(p, K)) return rc;
+  GPZ_REQUIRE(ws && g, "gpz_vnngp_backward: null pointer");
+  GPZ_REQUIRE(g->g_mean && g->g_scale && g->grad_mu && g->grad_Lu_raw, "gpz_vnngp_backward: null gradient buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return p->dtype == GPZ_F32 ? vnngp_backward_t<float>(p, g, K, idx, ws, ws_bytes, s)
+                             : vnngp_backward_t<double>(p, g, K, idx, ws, ws_bytes, s);
 }

@@ -183,10 +183,37 @@ class _FusedGP(nn.Module):
         return out["elbo"], out["kl"], out["loglik"]
 
 
+class _VNNMoments(torch.autograd.Function):
+    """(mean, scale, chol) of VNNGP as a differentiable function of mu, the raw Lu, Z, sigma and
+    lengthscale: forward = gpz_vnngp_forward, backward = gpz_vnngp_backward.  The neighbour table is a
+    constant of the graph, exactly as argsort is in the reference's."""
+
+    @staticmethod
+    def forward(ctx, mu, Lu_raw, Z, sigma, lengthscale, call):
+        out = call["forward"](mu, Lu_raw)
+        ctx.call, ctx.idx = call, out["idx"]
+        ctx.save_for_backward(mu, Lu_raw, Z, sigma, lengthscale)
+        return out["mean"], out["scale"], out["chol"]
+
+    @staticmethod
+    def backward(ctx, g_mean, g_scale, g_chol):
+        mu, Lu_raw, Z, sigma, lengthscale = ctx.saved_tensors
+        need_kernel = any(ctx.needs_input_grad[2:5])
+        res = ctx.call["backward"](mu, Lu_raw, ctx.idx, g_mean, g_scale, need_kernel, g_chol if need_kernel else None)
+        grads = [res[0].reshape(mu.shape), res[1].reshape(Lu_raw.shape), None, None, None, None]
+        if need_kernel:
+            grads[2] = res[3].to(Z.dtype)
+            grads[3] = _like(res[2][:, 0], sigma)
+            grads[4] = _like(res[2][:, 1], lengthscale)
+        return tuple(grads)
+
+
 class VNNGP(nn.Module):
-    """Nearest-neighbour variational GP; reference gp.py:7-122 (forward only, RBF-family kernels: the
-    ones with ``return_distance``).  The reference's scalar-``RBF`` path raises (gp.py:83 repeats the
-    neighbour table N times instead of L); here a scalar kernel returns ``(N,)`` moments."""
+    """Nearest-neighbour variational GP; reference gp.py:7-122 (RBF-family kernels: the ones with
+    ``return_distance``).  The reference's scalar-``RBF`` path raises (gp.py:83 repeats the neighbour
+    table N times instead of L); here a scalar kernel returns ``(N,)`` moments.  Differentiable w.r.t.
+    ``mu``, ``Lu``, ``Z``, ``sigma`` and ``lengthscale``."""
+    _clamp_min = 5e-2
 
     def __init__(self, kernel, dim=1, M=50, K=3, jitter=1e-4):
         super().__init__()
@@ -201,11 +228,29 @@ class VNNGP(nn.Module):
     def forward(self, X, verbose=False):
         nlat = 1 if self.mu.dim() == 1 else int(self.mu.shape[0])
         spec = kernel_spec(self.kernel, X, nlat)
-        out = ops.vnngp_forward(spec, X, self.Z, self.mu, self.Lu, float(self.jitter), int(self.K))
+        jitter, K = float(self.jitter), int(self.K)
         pick = (lambda t: t[0]) if self.mu.dim() == 1 else (lambda t: t)
-        qF = distributions.Normal(pick(out["mean"]), pick(out["scale"]))
-        qU = distributions.MultivariateNormal(self.mu, scale_tril=pick(out["Lu"]))
-        pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(out["chol"]))
+        params = (self.mu, self.Lu, self.Z, self.kernel.sigma, self.kernel.lengthscale)
+        if not (torch.is_grad_enabled() and any(t.requires_grad for t in params)):
+            out = ops.vnngp_forward(spec, X, self.Z, self.mu, self.Lu, jitter, K, self._clamp_min)
+            mean, scale, Lu, chol = out["mean"], out["scale"], out["Lu"], out["chol"]
+        else:
+            def fwd(mu, Lu_raw):
+                return ops.vnngp_forward(spec, X, self.Z, mu, Lu_raw, jitter, K, self._clamp_min)
+
+            def bwd(mu, Lu_raw, idx, g_mean, g_scale, need_kernel, g_chol):
+                z = torch.zeros((nlat, X.shape[0]), dtype=X.dtype, device=X.device)
+                return ops.vnngp_backward(spec, X, self.Z, mu, Lu_raw, jitter, K, idx, z if g_mean is None else g_mean,
+                                          z if g_scale is None else g_scale, clamp_min=self._clamp_min,
+                                          kernel_grads=need_kernel, g_chol=g_chol)
+
+            mean, scale, chol = _VNNMoments.apply(*params, dict(forward=fwd, backward=bwd))
+            # q(U)'s scale_tril through torch so that KL terms differentiate w.r.t. the raw parameter
+            Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
+            Lu = Lu.reshape(-1, Lu.shape[-2], Lu.shape[-1])
+        qF = distributions.Normal(pick(mean), pick(scale))
+        qU = distributions.MultivariateNormal(self.mu, scale_tril=pick(Lu))
+        pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(chol))
         return qF, qU, pU
 
 

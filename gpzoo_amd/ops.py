@@ -343,7 +343,7 @@ def knn(X, Z, K: int) -> torch.Tensor:
 
 
 def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, clamp_min: float = 5e-2,
-                  check_info: bool = True) -> dict:
+                  check_info: bool = True, idx=None) -> dict:
     """VNNGP forward (gpz_vnngp_forward): mean, scale (L,N), Lu, chol (L,M,M), idx (N,K)."""
     _need_cuda(X, Z, mu, Lu_raw)
     lib = _lib.load()
@@ -354,7 +354,7 @@ def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, cla
     info = torch.empty(L, dtype=torch.int32, device=dev)
     p.mean, p.scale, p.Lu, p.chol = (out[k].data_ptr() for k in ("mean", "scale", "Lu", "chol"))
     p.info = info.data_ptr()
-    out["idx"] = knn(X, Z, K)
+    out["idx"] = knn(X, Z, K) if idx is None else idx
     nbytes = lib.gpz_vnngp_workspace_bytes(C.byref(p), K)
     if nbytes == 0:
         _lib.check(-1, "gpz_vnngp_workspace_bytes")
@@ -364,6 +364,43 @@ def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, cla
     if check_info and bool(info.any()):
         _raise_not_pd(info, "linalg.cholesky")
     return out
+
+
+def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, idx, g_mean, g_scale, *,
+                   clamp_min: float = 5e-2, kernel_grads: bool = False, g_chol=None):
+    """dLoss/dmu (L,M), dLoss/dLu_raw (L,M,M) of VNNGP (gpz_vnngp_backward); with ``kernel_grads`` also
+    dLoss/d(sigma, lengthscale) (L,2) and dLoss/dZ (M,d), both fp64."""
+    _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale, idx)
+    lib = _lib.load()
+    keep: list = []
+    p, (L, M, N, dt, dev) = _problem(spec, X, Z, mu, Lu_raw, jitter, False, None, None, clamp_min, keep)
+    info = torch.empty(L, dtype=torch.int32, device=dev)
+    p.info = info.data_ptr()
+    g = _lib.SvgpGrads()
+    gm = g_mean.detach().to(dt).reshape(L, N).contiguous()
+    gs = g_scale.detach().to(dt).reshape(L, N).contiguous()
+    grad_mu = torch.empty((L, M), dtype=dt, device=dev)
+    grad_Lu = torch.empty((L, M, M), dtype=dt, device=dev)
+    g.g_mean, g.g_scale = gm.data_ptr(), gs.data_ptr()
+    g.grad_mu, g.grad_Lu_raw = grad_mu.data_ptr(), grad_Lu.data_ptr()
+    if kernel_grads and g_chol is not None:
+        gc = g_chol.detach().to(dt).reshape(L, M, M).contiguous()
+        keep.append(gc)
+        g.g_chol = gc.data_ptr()
+    if kernel_grads:
+        gth = torch.zeros((L, 4), dtype=torch.float64, device=dev)
+        gz = torch.zeros((M, 4), dtype=torch.float64, device=dev)
+        g.grad_theta, g.grad_Z = gth.data_ptr(), gz.data_ptr()
+    idx = idx.contiguous()
+    nbytes = lib.gpz_vnngp_backward_workspace_bytes(C.byref(p), K)
+    if nbytes == 0:
+        _lib.check(-1, "gpz_vnngp_backward_workspace_bytes")
+    ws = _workspace(dev, nbytes)
+    rc = lib.gpz_vnngp_backward(C.byref(p), C.byref(g), K, _ptr(idx), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "gpz_vnngp_backward")
+    if kernel_grads:
+        return grad_mu, grad_Lu, gth[:, :2], gz[:, :X.shape[1]]
+    return grad_mu, grad_Lu
 
 
 def poisson_nsf(mean, scale, eps, W_pos, V_pos, y, with_lgamma: bool = True):

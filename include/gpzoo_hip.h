@@ -191,6 +191,17 @@ size_t gpz_vnngp_workspace_bytes(const gpz_svgp_problem* p, int32_t K);
 int gpz_vnngp_forward(const gpz_svgp_problem* p, int32_t K, const int64_t* idx, void* ws,
                       size_t ws_bytes, void* stream);
 
+/* Backward of VNNGP.forward as loss.backward() runs it through the reference's autograd graph
+ * (utilities.py:485 over gp.py:21-122): given dLoss/dmean, dLoss/dscale (and, for the kernel
+ * hyper-parameters, dLoss/dchol from KL(qU || pU)) writes grad_mu, grad_Lu_raw and, when
+ * grad_theta / grad_Z are non-NULL, the gradients w.r.t. (sigma, lengthscale) per latent and Z.
+ * The neighbour table is a constant of the graph (argsort has no gradient).  `scale` of
+ * gpz_svgp_grads is unused (the variance is recomputed).  The K-sparse terms are accumulated with
+ * fp64 atomics: results are reproducible to rounding, not bitwise. */
+size_t gpz_vnngp_backward_workspace_bytes(const gpz_svgp_problem* p, int32_t K);
+int gpz_vnngp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int32_t K,
+                       const int64_t* idx, void* ws, size_t ws_bytes, void* stream);
+
 /* Moments from a caller-supplied W (L,N,M): WSVGP.forward_precomputed, gp.py:308-322
  * (cov = clamp(sigma^2 - sum W^2, 0) + sum (W Lu)^2, mean = W mu).  sigma (L,), mu (L,M),
  * Lu_raw (L,M,M) -> mean, scale (L,N) and the constrained Lu (L,M,M, may be NULL). */

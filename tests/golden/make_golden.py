@@ -234,7 +234,7 @@ def main():
     print(f"cfg1_f64: elbo={float(out['elbo']):.10f}")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not os.environ.get("GPZ_GOLDEN_ONLY"):
     main()
 
 
@@ -314,14 +314,27 @@ def vnngp_cases():
                 qF, qU, pU = gp(X)
                 _, dist = kern(X, gp.Z, return_distance=True)
             idx = torch.argsort(dist, dim=1)[:, :5]
-            rec = dict(X=X.numpy(), Z=gp.Z.detach().numpy(), mu=gp.mu.detach().numpy(), Lu_raw=gp.Lu.detach().numpy(),
+            # gradients of the negative Gaussian ELBO through the reference's own autograd graph
+            y, noise_sd = inp["y"].to(dtype), 0.5
+            with contextlib.redirect_stdout(io.StringIO()):
+                qF_g, qU_g, pU_g = gp(X)
+            loss = -(distributions.Normal(qF_g.mean, noise_sd).log_prob(y).sum()
+                     - (qF_g.scale ** 2).sum() / (2 * noise_sd ** 2) - distributions.kl_divergence(qU_g, pU_g).sum())
+            loss.backward()
+            grads = dict(y=y.numpy(), noise_sd=np.float64(noise_sd), loss=np.float64(float(loss)),
+                         grad_mu=gp.mu.grad.numpy(), grad_Lu=gp.Lu.grad.numpy(), grad_Z=gp.Z.grad.numpy(),
+                         grad_sigma=kern.sigma.grad.numpy(), grad_lengthscale=kern.lengthscale.grad.numpy(),
+                         n_clamped=np.int64(int((qF.scale ** 2 <= 5e-2 * (1 + 1e-9)).sum())))
+            rec = dict(**grads, X=X.numpy(), Z=gp.Z.detach().numpy(), mu=gp.mu.detach().numpy(), Lu_raw=gp.Lu.detach().numpy(),
                        sigma=kern.sigma.detach().numpy(), lengthscale=kern.lengthscale.detach().numpy(),
                        mean=qF.mean.numpy(), scale=qF.scale.numpy(), idx=idx.numpy(), Lu=qU.scale_tril.numpy(),
                        chol=pU.scale_tril.numpy(), jitter=np.float64(1e-2), K=np.int64(5))
             np.savez_compressed(os.path.join(HERE, f"vnngp_{kind}_{tag}.npz"), **rec)
-            print(f"vnngp_{kind}_{tag}: mean[0..2]={qF.mean.reshape(-1)[:3].tolist()}")
+            print(f"vnngp_{kind}_{tag}: mean[0..2]={qF.mean.reshape(-1)[:3].tolist()} clamped={int(grads['n_clamped'])}"
+                  f" loss={float(loss):.6f}")
 
 
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1":
-    poisson_cases()
+    if os.environ.get("GPZ_GOLDEN_ONLY", "") != "vnngp":
+        poisson_cases()
     vnngp_cases()

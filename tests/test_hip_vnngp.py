@@ -71,3 +71,89 @@ def test_knn_ties_resolve_to_lower_index():
     X = torch.zeros(3, 2, dtype=torch.float64)
     idx = ops.knn(X.cuda(), Z.cuda(), 4).cpu()
     assert idx.tolist() == [[5, 0, 1, 2]] * 3
+
+
+def _module(c, dtype_cuda=True):
+    from gpzoo.gp import VNNGP
+    from gpzoo.kernels import NSF_RBF
+    L = c["sigma"].shape[0]
+    k = NSF_RBF(L=L)
+    k.sigma = nn.Parameter(c["sigma"].clone()); k.lengthscale = nn.Parameter(c["lengthscale"].clone())
+    gp = VNNGP(k, dim=2, M=c["Z"].shape[0], K=int(c["K"]), jitter=float(c["jitter"]))
+    gp.Z = nn.Parameter(c["Z"].clone()); gp.mu = nn.Parameter(c["mu"].clone()); gp.Lu = nn.Parameter(c["Lu_raw"].clone())
+    return gp.cuda(), k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_backward_matches_reference_autograd(name):
+    """loss.backward() through the module == the reference's own autograd gradients of the same loss."""
+    from torch import distributions
+    c = load(name)
+    gp, k = _module(c)
+    X, y, s = c["X"].cuda(), c["y"].cuda(), float(c["noise_sd"])
+    qF, qU, pU = gp(X)
+    loss = -(distributions.Normal(qF.mean, s).log_prob(y).sum() - (qF.scale ** 2).sum() / (2 * s ** 2)
+             - distributions.kl_divergence(qU, pU).sum())
+    loss.backward()
+    f64 = X.dtype == torch.float64
+    rt = 1e-5 if f64 else 1e-3
+    torch.testing.assert_close(float(loss.detach()), float(c["loss"]), rtol=rt, atol=0)
+    for got, key in ((gp.mu.grad, "grad_mu"), (gp.Lu.grad, "grad_Lu"), (gp.Z.grad, "grad_Z"), (k.sigma.grad, "grad_sigma"),
+                     (k.lengthscale.grad, "grad_lengthscale")):
+        ref = c[key]
+        torch.testing.assert_close(got.cpu(), ref, rtol=rt, atol=rt * float(ref.abs().max()), msg=lambda m: f"{key}: {m}")
+
+
+@pytest.mark.parametrize("frozen", [False, True])
+def test_backward_against_oracle_autograd_with_clamped_points(frozen):
+    """Larger case with a share of variances at the 5e-2 clamp (no gradient through those), against
+    torch autograd over the oracle; ``frozen`` = kernel hyper-parameters and Z without gradients."""
+    from gpzoo_amd import _lib, ops
+    from gpzoo_amd.ops import KernelSpec
+    from oracle import svgp_oracle as O
+    N, M, K, L = 2000, 200, 8, 3
+    g = torch.Generator().manual_seed(77)
+    X = (torch.rand(N, 2, generator=g, dtype=torch.float64) - 0.5) * 30
+    Z = ((torch.rand(M, 2, generator=g, dtype=torch.float64) - 0.5) * 30).requires_grad_(not frozen)
+    sig = (0.25 + 0.2 * torch.rand(L, generator=g, dtype=torch.float64)).requires_grad_(not frozen)
+    ell = (2.0 + 3 * torch.rand(L, generator=g, dtype=torch.float64)).requires_grad_(not frozen)
+    mu = torch.randn(L, M, generator=g, dtype=torch.float64).requires_grad_()
+    Lu = (0.05 * torch.randn(L, M, M, generator=g, dtype=torch.float64) - 1.5 * torch.eye(M, dtype=torch.float64)).requires_grad_()
+    a = torch.randn(L, N, generator=g, dtype=torch.float64)
+    b = torch.randn(L, N, generator=g, dtype=torch.float64)
+    gc = torch.randn(L, M, M, generator=g, dtype=torch.float64).tril()
+    mean, scale, idx, _, chol = O.vnngp_moments(X, Z, sig, ell, mu, Lu, 1e-2, K)
+    n_clamped = int((scale.detach() ** 2 <= 5e-2 * (1 + 1e-9)).sum())
+    assert 0 < n_clamped < L * N
+    loss = (a * mean).sum() + (b * scale).sum() + (gc * chol.reshape(L, M, M)).sum()
+    loss.backward()
+    spec = KernelSpec(_lib.KERNEL_RBF, sig.detach().cuda(), ell.detach().cuda(), True)
+    res = ops.vnngp_backward(spec, X.cuda(), Z.detach().cuda(), mu.detach().cuda(), Lu.detach().cuda(), 1e-2, K, idx.cuda(),
+                             a.cuda(), b.cuda(), kernel_grads=not frozen, g_chol=None if frozen else gc.cuda())
+    def close(got, ref, name):
+        torch.testing.assert_close(got.cpu(), ref, rtol=1e-7, atol=1e-9 * float(ref.abs().max()), msg=lambda m: f"{name}: {m}")
+    close(res[0], mu.grad, "grad_mu")
+    close(res[1], Lu.grad, "grad_Lu")
+    if not frozen:
+        close(res[2][:, 0], sig.grad, "grad_sigma")
+        close(res[2][:, 1], ell.grad, "grad_lengthscale")
+        close(res[3], Z.grad, "grad_Z")
+
+
+def test_vnngp_trains():
+    """A few Adam steps on the Gaussian ELBO lower the loss (the notebooks' training loop shape)."""
+    from torch import distributions
+    c = load("vnngp_nsf_rbf_L2_f32")
+    gp, k = _module(c)
+    X, y = c["X"].cuda(), c["y"].cuda()
+    opt = torch.optim.Adam(gp.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        qF, qU, pU = gp(X)
+        loss = -(distributions.Normal(qF.mean, 0.5).log_prob(y).sum() - (qF.scale ** 2).sum() / 0.5
+                 - distributions.kl_divergence(qU, pU).sum())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
