@@ -110,6 +110,9 @@ def pmc_traffic(cfg_id, N, M, L, chunk):
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 as `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
@@ -217,13 +220,14 @@ def main():
             "finalize_ms_per_eval": prof["finalize"][0] / a.steps,
         }
         res = {
-            "metric": "ELBO evals/sec (L=32-latent evaluations, all GPUs) at M=%d inducing, N=%d, L=%d per GPU" % (M, N, Lper),
+            "metric": "ELBO evals/sec (L=%d-latent evaluations, all GPUs) at M=%d inducing, N=%d, L=%d per GPU"
+                      % (Lper, M, N, Lper),
             "value": a.steps * world / t, "unit": "ELBO evals/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dname, "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %s, N=%d spots, M=%d, L=%d latents/GPU x %d GPU(s), %s, %s"
-                                   % (cfg_id - 1, "Slide-seq-shaped synthetic" if cfg_id >= 3 else "2-D synthetic spatial",
-                                      N, M, Lper, world, c["kind"], dname),
+                                   % (cfg_id - 1, {2: "2-D synthetic spatial", 5: "MGGP multi-group synthetic (4 groups)"}.get(
+                                       cfg_id, "Slide-seq-shaped synthetic"), N, M, Lper, world, c["kind"], dname),
                        "whitened": bool(c["whitened"]), "chunk": a.chunk, "factor_dtype": "f64"},
             "elbo": elbo, "roofline": roof, "kernels": sub,
         }

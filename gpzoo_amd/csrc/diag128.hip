@@ -12,7 +12,8 @@
 //     MFMA; the accumulator tile of C*A is fed straight back as the B operand of -B*(C*A) (the f64
 //     C/D layout row = (lane>>4) + 4*reg makes register g of a tile exactly k-step g's operand).
 // Storage: S[128][129] doubles.  L lives row-major in the lower triangle; the inverse X is kept
-// transposed and shifted one column right, X[i][c] at S[c][i+1], which is free space.
+// transposed and shifted one column right, X[i][c] at S[c][i+1], which is free space.  A compact
+// [32][32] column buffer and the reciprocal diagonal of the sub-block in flight follow S.
 #include "common.h"
 
 namespace gpz {
@@ -34,48 +35,98 @@ __device__ __forceinline__ d4 mma(double a, double b, d4 c) {
 // X[i][c], i >= c, of the inverse
 __device__ __forceinline__ double& XT(double* S, int c, int i) { return S[c * DP + i + 1]; }
 
-// One wave: Cholesky of the 32x32 block at offset o.  Lane i (and its twin i+32) holds row i in
-// registers; only the pivot crosses lanes through v_readlane.  Each finished column is written to
-// LDS and the multipliers l_kj come back as uniform-address (broadcast) reads.
-__device__ __forceinline__ void factor32(double* S, int o, int lane, int32_t* info, int64_t gbase, int64_t m_real) {
-  const int i = lane & 31;
+// A zero the compiler cannot see through, held in a VGPR: added to a uniform LDS address it keeps the
+// broadcast loads in vector registers (otherwise every loaded value is moved to an SGPR pair with
+// v_readlane and the 500 live multipliers spill).
+__device__ __forceinline__ int vzero() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+
+// 1/sqrt(d) in fp64: hardware seed + Newton steps (r <- r (1.5 - 0.5 d r^2)); ~25 instructions less
+// than sqrt followed by a division, and it sits on the critical path of every column.
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const double t = r * r;
+    r = r * fma(-h, t, 1.5);
+  }
+  return r;
+}
+
+// One wave: right-looking Cholesky of the 32x32 block at offset o.  Lane i (and its twin i+32) holds
+// row i in registers.  The running diagonal a_ii - sum_k l_ik^2 is carried separately, so the next
+// pivot (v_readlane) and its reciprocal square root do not wait for the LDS round trip of the
+// finished column; the multipliers l_kj come back from the compact column buffer CB[j][k] as
+// uniform-address (broadcast) reads.  RI[j] = 1 / l_jj for the inverse.
+__device__ __forceinline__ void factor32(double* S, double* CBu, double* RI, int o, int lane, int32_t* info,
+                                         int64_t gbase, int64_t m_real) {
+  const int zz = vzero();          // also keeps the 32 lane-compare masks from being hoisted out of the caller's loop
+  const int i = (lane & 31) + zz;
+  const double* CB = CBu + zz;
   double a[32];
 #pragma unroll
   for (int k = 0; k < 32; ++k) a[k] = S[(o + i) * DP + o + k];
+  double diag = S[(o + i) * DP + o + i];
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
-    double d = bcast(a[j], j);
+    double d = bcast(diag, j);
     if (!(d > 0.0)) {
       if (lane == 0 && gbase + j < m_real) atomicCAS(info, 0, (int)(gbase + j + 1));
       d = 1.0;
     }
-    const double r = 1.0 / sqrt(d);
-    a[j] = (i == j) ? d * r : a[j] * r;
-    if (i >= j) S[(o + i) * DP + o + j] = a[j];
-    // registers above the diagonal (k > i) accumulate garbage that is never stored or read back
+    const double r = rsqrt_nr(d);
+    double sq = d * r;
+    sq = fma(0.5 * r, fma(-sq, sq, d), sq);          // sqrt(d), one correction step
+    const double lj = (i == j) ? sq : a[j] * r;      // rows i < j carry garbage that is never read back
+    diag = fma(-lj, lj, diag);
+    if (lane < 32) {
+      CBu[j * 32 + i] = lj;
+      if (i >= j) S[(o + i) * DP + o + j] = lj;
+      if (i == j) RI[j] = r;
+    }
 #pragma unroll
-    for (int k = j + 1; k < 32; ++k) a[k] = fma(-a[j], S[(o + k) * DP + o + j], a[k]);
-    __builtin_amdgcn_sched_barrier(0);   // one column step at a time: keeps the broadcast reads short-lived
+    for (int k = j + 1; k < 32; ++k) a[k] = fma(-lj, CB[j * 32 + k], a[k]);
+    // pin the updates to this column: LLVM otherwise sinks each one to the column that consumes it and keeps
+    // all 496 broadcast values alive until then (spills)
+#pragma unroll
+    for (int k = j + 1; k < 32; ++k) asm volatile("" : "+v"(a[k]));
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// One wave: inverse of the factored 32x32 lower-triangular block at offset o by forward
-// substitution; lane c owns column c (x[k] == 0 for k < c by construction), L[ii][k] is a broadcast read.
-__device__ __forceinline__ void invert32(double* S, int o, int lane) {
-  const int c = lane & 31;
-  double x[32];
+// Inverse-only mode: the column buffer and reciprocal diagonal of an already factored block.
+__device__ __forceinline__ void stage32(const double* S, double* CB, double* RI, int o, int lane) {
+  const int i = lane & 31;
+  if (lane < 32) {
+    for (int k = 0; k <= i; ++k) CB[k * 32 + i] = S[(o + i) * DP + o + k];
+    RI[i] = 1.0 / S[(o + i) * DP + o + i];
+  }
+}
+
+// One wave: inverse of the factored 32x32 lower-triangular block by column-oriented forward
+// substitution; lane c owns column c of the inverse, x_ii = acc_ii / l_ii, then acc_m -= l_m,ii x_ii
+// (independent FMAs fed by broadcast reads of column ii).
+__device__ __forceinline__ void invert32(double* S, const double* CBu, const double* RIu, int o, int lane) {
+  const int z = vzero();
+  const int c = (lane & 31) + z;
+  const double* CB = CBu + z;
+  const double* RI = RIu + z;
+  double acc[32];
+#pragma unroll
+  for (int m = 0; m < 32; ++m) acc[m] = (m == c) ? 1.0 : 0.0;
 #pragma unroll
   for (int ii = 0; ii < 32; ++ii) {
-    double acc = (ii == c) ? 1.0 : 0.0;
+    const double x = acc[ii] * RI[ii];
+    if (lane < 32 && ii >= c) XT(S, o + c, o + ii) = x;
 #pragma unroll
-    for (int k = 0; k < ii; ++k) acc = fma(-S[(o + ii) * DP + o + k], x[k], acc);
-    x[ii] = acc / S[(o + ii) * DP + o + ii];
+    for (int m = ii + 1; m < 32; ++m) acc[m] = fma(-CB[ii * 32 + m], x, acc[m]);
+#pragma unroll
+    for (int m = ii + 1; m < 32; ++m) asm volatile("" : "+v"(acc[m]));
     __builtin_amdgcn_sched_barrier(0);
-  }
-  if (lane < 32) {
-#pragma unroll
-    for (int ii = 0; ii < 32; ++ii)
-      if (ii >= c) XT(S, o + c, o + ii) = x[ii];
   }
 }
 }  // namespace
@@ -83,7 +134,9 @@ __device__ __forceinline__ void invert32(double* S, int o, int lane) {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void diag128_kernel(double* __restrict__ A, int64_t lda, int64_t stride, int bk,
                                                      double* __restrict__ Dinv, int64_t dinv_stride,
                                                      int32_t* __restrict__ info, int64_t m_real, int factor) {
-  extern __shared__ __attribute__((aligned(16))) double S[];  // [128][129]
+  extern __shared__ __attribute__((aligned(16))) double S[];  // [128][129] + column buffer [32][32] + 1/diag [32]
+  double* CB = S + 128 * DP;
+  double* RI = CB + 32 * 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int b = blockIdx.x;
@@ -99,8 +152,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int s = 0; s < 4; ++s) {
     const int o = 32 * s;
     if (w == 0) {
-      if (factor) factor32(S, o, lane, info + b, (int64_t)bk * 128 + o, m_real);
-      invert32(S, o, lane);
+      if (factor) factor32(S, CB, RI, o, lane, info + b, (int64_t)bk * 128 + o, m_real);
+      else stage32(S, CB, RI, o, lane);
+      invert32(S, CB, RI, o, lane);
     }
     __syncthreads();
     if (!factor || s == 3) continue;
@@ -182,6 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const double bv = (k >= j) ? XT(S, oA + j, oA + k) : 0.0;              // A^-1[k][j]
         T[it] = mma(av, bv, T[it]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -195,6 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const double av = (k <= i) ? XT(S, oB + k, oB + i) : 0.0;            // B^-1[i][k]
           X[it] = mma(-av, T[kt][g], X[it]);
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it)
@@ -216,6 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const double bv = (k >= j) ? XT(S, j, k) : 0.0;                        // A^-1[k][j], A = X[0:64][0:64]
         T[kt] = mma(av, bv, T[kt]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -229,6 +286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const double av = (k <= i) ? XT(S, 64 + k, 64 + i) : 0.0;            // B^-1[i][k], B = X[64:][64:]
           X[it] = mma(-av, T[kt][g], X[it]);
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it)

@@ -25,6 +25,7 @@ namespace gpz {
 
 constexpr int NB = 128;        // panel width == GEMM tile
 constexpr int P2 = NB + 1;     // LDS pitch (doubles)
+constexpr size_t DIAG_LDS_BYTES = ((size_t)NB * P2 + 32 * 32 + 32) * sizeof(double);  // diag128_kernel: S + CB + RI
 
 // csrc/diag128.hip: factor (optional) + inverse of the diagonal 128-block(s), one workgroup each.
 __global__ void diag128_kernel(double* __restrict__ A, int64_t lda, int64_t stride, int bk, double* __restrict__ Dinv,
@@ -48,7 +49,7 @@ int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t bat
   GPZ_REQUIRE(Mp % NB == 0 && Mp > 0, "potrf: padded order %lld is not a multiple of %d", (long long)Mp, NB);
   const int nblk = (int)(Mp / NB);
   const int64_t dstride = (int64_t)nblk * NB * NB;
-  const size_t lds = (size_t)NB * P2 * sizeof(double);
+  const size_t lds = DIAG_LDS_BYTES;
   if (!g_diag_attr_set) {
     GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(diag128_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -239,7 +240,7 @@ extern "C" int gpz_trsm_lln_batched(const double* Lc, int64_t ldl, int64_t strid
   dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp, (unsigned)batch);
   hipLaunchKernelGGL(pad_copy_in_kernel, grid, dim3(256), 0, s, Lc, ldl, stride_l, M, Lp, Mp, 1);
   GPZ_LAUNCH_OK();
-  const size_t lds = (size_t)NB * P2 * sizeof(double);
+  const size_t lds = DIAG_LDS_BYTES;
   if (!g_diag_attr_set) {
     GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(diag128_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

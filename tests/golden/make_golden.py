@@ -334,7 +334,58 @@ def vnngp_cases():
                   f" loss={float(loss):.6f}")
 
 
-if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1":
+def state_dict_cases():
+    """state_dict keys + shapes of every reference model class (checkpoint-name compatibility,
+    SURVEY.md §8f #4): data only -- names, shapes, dtypes."""
+    import json
+    y = torch.ones(7, 11)
+    def gp_of(cls, kern, **kw):
+        return cls(kern, dim=2, M=6, **kw)
+    builders = {
+        "RBF": lambda: rk.RBF(), "NSF_RBF": lambda: rk.NSF_RBF(L=3), "batched_RBF": lambda: rk.batched_RBF(),
+        "batched_Matern32": lambda: rk.batched_Matern32(), "MGGP_RBF": lambda: rk.MGGP_RBF(n_groups=3),
+        "MGGP_NSF_RBF": lambda: rk.MGGP_NSF_RBF(L=3, n_groups=3), "batched_MGGP_RBF": lambda: rk.batched_MGGP_RBF(n_groups=3),
+        "VNNGP": lambda: gp_of(rgp.VNNGP, rk.NSF_RBF(L=3), K=2), "SVGP": lambda: gp_of(rgp.SVGP, rk.RBF()),
+        "WSVGP": lambda: gp_of(rgp.WSVGP, rk.NSF_RBF(L=3)),
+        "MGGP_SVGP": lambda: gp_of(rgp.MGGP_SVGP, rk.MGGP_RBF(n_groups=3), n_groups=3),
+        "MGGP_WSVGP": lambda: gp_of(rgp.MGGP_WSVGP, rk.MGGP_NSF_RBF(L=3, n_groups=3), n_groups=3),
+        "GaussianPrior": lambda: rgp.GaussianPrior(y, L=3),
+        "GaussianLikelihood": lambda: rl.GaussianLikelihood(gp_of(rgp.SVGP, rk.RBF())),
+        "ExactLikelihood": lambda: rl.ExactLikelihood(gp_of(rgp.WSVGP, rk.RBF())),
+        "PNMF": lambda: rl.PNMF(rgp.GaussianPrior(y, L=3), y, L=3),
+        "NSF2": lambda: rl.NSF2(gp_of(rgp.WSVGP, rk.NSF_RBF(L=3)), y, L=3),
+        "NSF": lambda: rl.NSF(gp_of(rgp.WSVGP, rk.NSF_RBF(L=3)), y, L=3),
+        "MGGP_NSF": lambda: rl.MGGP_NSF(gp_of(rgp.MGGP_WSVGP, rk.MGGP_NSF_RBF(L=3, n_groups=3), n_groups=3), y, L=3),
+        "Hybrid_NSF2": lambda: rl.Hybrid_NSF2(gp_of(rgp.WSVGP, rk.NSF_RBF(L=3)), rgp.GaussianPrior(y, L=2), y, L=3, T=2),
+        "Hybrid_NSF_Exact": lambda: rl.Hybrid_NSF_Exact(gp_of(rgp.WSVGP, rk.NSF_RBF(L=3)), rgp.GaussianPrior(y, L=2), y, L=3, T=2),
+        "Hybrid_NSF": lambda: rl.Hybrid_NSF(gp_of(rgp.WSVGP, rk.NSF_RBF(L=3)), y, L=3, non_spatial_factors=2),
+    }
+    table = {}
+    for name, make in builders.items():
+        torch.manual_seed(0)
+        m = make()
+        table[name] = {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+        print(f"state_dict {name}: {list(table[name])}")
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    # a checkpoint written by the reference (plain state_dict of tensors; loads with weights_only=True)
+    torch.manual_seed(5)
+    L, M, N = 3, 24, 90
+    gp = rgp.WSVGP(rk.NSF_RBF(sigma=1.1, lengthscale=2.5, L=L), dim=2, M=M, jitter=1e-2)
+    gp.Z = nn.Parameter(4 * torch.randn(M, 2)); gp.mu = nn.Parameter(torch.randn(L, M)); gp.Lu = nn.Parameter(0.1 * torch.randn(L, M, M))
+    model = rl.ExactLikelihood(gp, noise=0.3).double()
+    X = 4 * torch.randn(N, 2, dtype=torch.float64)
+    with torch.no_grad():
+        pY, qF, qU, _ = model(X=X)
+    torch.save(model.state_dict(), os.path.join(HERE, "ref_checkpoint_exact_wsvgp.pt"))
+    np.savez_compressed(os.path.join(HERE, "ref_checkpoint_exact_wsvgp_out.npz"), X=X.numpy(), mean=qF.mean.numpy(),
+                        scale=qF.scale.numpy(), pY_scale=pY.scale.numpy(), jitter=np.float64(1e-2))
+
+
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "state_dict"):
+    state_dict_cases()
+
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1" and os.environ.get("GPZ_GOLDEN_ONLY", "") != "state_dict":
     if os.environ.get("GPZ_GOLDEN_ONLY", "") != "vnngp":
         poisson_cases()
     vnngp_cases()

@@ -83,3 +83,47 @@ def test_shard_latents_partition():
         assert sum(len(b) for b in blocks) == L
         assert [i for b in blocks for i in b] == list(range(L))
     assert len(shard_latents(256, 8, 3)) == 32 and len(shard_latents(256, 2, 1)) == 128
+
+
+def _state_dict_builders():
+    import torch
+    import gpzoo.gp as g
+    import gpzoo.kernels as k
+    import gpzoo.likelihoods as li
+    y = torch.ones(7, 11)
+    gp_of = lambda cls, kern, **kw: cls(kern, dim=2, M=6, **kw)  # noqa: E731
+    return {
+        "RBF": lambda: k.RBF(), "NSF_RBF": lambda: k.NSF_RBF(L=3), "batched_RBF": lambda: k.batched_RBF(),
+        "batched_Matern32": lambda: k.batched_Matern32(), "MGGP_RBF": lambda: k.MGGP_RBF(n_groups=3),
+        "MGGP_NSF_RBF": lambda: k.MGGP_NSF_RBF(L=3, n_groups=3), "batched_MGGP_RBF": lambda: k.batched_MGGP_RBF(n_groups=3),
+        "VNNGP": lambda: gp_of(g.VNNGP, k.NSF_RBF(L=3), K=2), "SVGP": lambda: gp_of(g.SVGP, k.RBF()),
+        "WSVGP": lambda: gp_of(g.WSVGP, k.NSF_RBF(L=3)),
+        "MGGP_SVGP": lambda: gp_of(g.MGGP_SVGP, k.MGGP_RBF(n_groups=3), n_groups=3),
+        "MGGP_WSVGP": lambda: gp_of(g.MGGP_WSVGP, k.MGGP_NSF_RBF(L=3, n_groups=3), n_groups=3),
+        "GaussianPrior": lambda: g.GaussianPrior(y, L=3),
+        "GaussianLikelihood": lambda: li.GaussianLikelihood(gp_of(g.SVGP, k.RBF())),
+        "ExactLikelihood": lambda: li.ExactLikelihood(gp_of(g.WSVGP, k.RBF())),
+        "PNMF": lambda: li.PNMF(g.GaussianPrior(y, L=3), y, L=3),
+        "NSF2": lambda: li.NSF2(gp_of(g.WSVGP, k.NSF_RBF(L=3)), y, L=3),
+        "NSF": lambda: li.NSF(gp_of(g.WSVGP, k.NSF_RBF(L=3)), y, L=3),
+        "MGGP_NSF": lambda: li.MGGP_NSF(gp_of(g.MGGP_WSVGP, k.MGGP_NSF_RBF(L=3, n_groups=3), n_groups=3), y, L=3),
+        "Hybrid_NSF2": lambda: li.Hybrid_NSF2(gp_of(g.WSVGP, k.NSF_RBF(L=3)), g.GaussianPrior(y, L=2), y, L=3, T=2),
+        "Hybrid_NSF_Exact": lambda: li.Hybrid_NSF_Exact(gp_of(g.WSVGP, k.NSF_RBF(L=3)), g.GaussianPrior(y, L=2), y, L=3, T=2),
+        "Hybrid_NSF": lambda: li.Hybrid_NSF(gp_of(g.WSVGP, k.NSF_RBF(L=3)), y, L=3, non_spatial_factors=2),
+    }
+
+
+def test_state_dict_names_shapes_match_reference():
+    """A checkpoint saved by the reference loads here and vice versa: same state_dict keys, shapes and
+    dtypes for every model class (fixture written from the reference by tests/golden/make_golden.py)."""
+    import json
+    import os
+    from helpers import GOLDEN
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
+        ref = json.load(f)
+    builders = _state_dict_builders()
+    assert sorted(builders) == sorted(ref)
+    for name, make in builders.items():
+        sd = make().state_dict()
+        got = {k: [list(v.shape), str(v.dtype)] for k, v in sd.items()}
+        assert got == ref[name], f"{name}: {got} != {ref[name]}"

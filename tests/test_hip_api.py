@@ -177,3 +177,29 @@ def test_factor_cache_reuse_and_invalidation():
         gp.jitter = 5e-2
         f = gp(X)
         assert not torch.equal(d[0].scale, f[0].scale)
+
+
+@pytest.mark.gpu
+def test_reference_checkpoint_loads_and_reproduces_outputs():
+    """A state_dict written by the reference (fixture, loaded with weights_only=True) drops into the
+    same-named classes here and reproduces the reference's q(F)."""
+    import os
+    import numpy as np
+    import torch.nn as nn
+    from helpers import GOLDEN
+    from gpzoo.gp import WSVGP
+    from gpzoo.kernels import NSF_RBF
+    from gpzoo.likelihoods import ExactLikelihood
+    sd = torch.load(os.path.join(GOLDEN, "ref_checkpoint_exact_wsvgp.pt"), weights_only=True)
+    out = np.load(os.path.join(GOLDEN, "ref_checkpoint_exact_wsvgp_out.npz"))
+    L, M = sd["gp.mu"].shape
+    gp = WSVGP(NSF_RBF(L=L), dim=2, M=M, jitter=float(out["jitter"]))
+    gp.mu = nn.Parameter(torch.zeros(L, M)); gp.Lu = nn.Parameter(torch.zeros(L, M, M))   # notebooks re-shape these
+    model = ExactLikelihood(gp).double()
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda()
+    with torch.no_grad():
+        pY, qF, qU, pU = model(X=torch.from_numpy(out["X"]).cuda())
+    torch.testing.assert_close(qF.mean.cpu(), torch.from_numpy(out["mean"]), rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(qF.scale.cpu(), torch.from_numpy(out["scale"]), rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(pY.scale.cpu().expand(out["pY_scale"].shape), torch.from_numpy(out["pY_scale"]), rtol=1e-12, atol=0)
