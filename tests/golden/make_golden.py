@@ -382,10 +382,46 @@ def state_dict_cases():
                         scale=qF.scale.numpy(), pY_scale=pY.scale.numpy(), jitter=np.float64(1e-2))
 
 
+def trajectory_case():
+    """Twelve Adam steps of the reference's own `utilities.train` (utilities.py:471-493) on SVGP +
+    NSF_RBF + GaussianLikelihood with every parameter trainable and the rsample noise replayed from
+    stored eps: losses per step and the final parameters (end-to-end forward + backward + optimiser)."""
+    import contextlib
+    import io
+    import torch.distributions.normal as tdn
+    from gpzoo.utilities import train as ref_train
+    steps, E, L, N, M = 12, 4, 3, 120, 20
+    inp = make_inputs(900, N=N, M=M, d=2, L=L)
+    eps = torch.randn(steps, E, L, N, generator=torch.Generator().manual_seed(901), dtype=torch.float64)
+    kern = rk.NSF_RBF(sigma=1.2, lengthscale=2.5, L=L)
+    gp = rgp.SVGP(kern, dim=2, M=M, jitter=1e-2)
+    gp.Z = nn.Parameter(inp["Z"].clone()); gp.mu = nn.Parameter(inp["mu"].clone()); gp.Lu = nn.Parameter(inp["Lu_raw"].clone())
+    model = rl.GaussianLikelihood(gp, noise=0.3).double()
+    init = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+    queue = [e for e in eps]
+    orig = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: queue.pop(0).to(dtype)
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        with contextlib.redirect_stderr(io.StringIO()):
+            losses = ref_train(model, opt, inp["X"], inp["y"], torch.device("cpu"), steps=steps, E=E)
+    finally:
+        tdn._standard_normal = orig
+    rec = {"init." + k: v for k, v in init.items()}
+    rec.update({"final." + k: v.detach().numpy() for k, v in model.state_dict().items()})
+    np.savez_compressed(os.path.join(HERE, "ref_trajectory_svgp_f64.npz"), X=inp["X"].numpy(), y=inp["y"].numpy(),
+                        eps=eps.numpy(), losses=np.array(losses), lr=np.float64(1e-2), jitter=np.float64(1e-2),
+                        noise0=np.float64(0.3), **rec)
+    print("trajectory losses:", [round(v, 4) for v in losses])
+
+
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "trajectory"):
+    trajectory_case()
+
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "state_dict"):
     state_dict_cases()
 
-if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1" and os.environ.get("GPZ_GOLDEN_ONLY", "") != "state_dict":
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1" and os.environ.get("GPZ_GOLDEN_ONLY", "") not in ("state_dict", "trajectory"):
     if os.environ.get("GPZ_GOLDEN_ONLY", "") != "vnngp":
         poisson_cases()
     vnngp_cases()
