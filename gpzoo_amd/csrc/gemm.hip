@@ -15,6 +15,8 @@
 // flop is spent on known-zero blocks.
 #include "gemm.h"
 
+#include <type_traits>
+
 namespace gpz {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -120,7 +122,10 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  // Waves 0..WN-1 sit on different SIMDs than waves WN..2WN-1 in every workgroup, and with a triangular A
+  // one row half of the tile has less MFMA work than the other (zero skipping below).  Alternating which
+  // half a wave takes from tile to tile keeps the four MFMA pipes of a CU equally loaded.
+  const int wm = (wave / WN) ^ ((p.flags & (GF_A_LOWER | GF_A_UPPER)) ? ((ti ^ tj) & 1) : 0), wn = wave % WN;
   const int r = lane & 15, q = lane >> 4;
 
   // ---------------- staging maps (16 bytes per thread per load) ----------------
@@ -177,14 +182,16 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc_t{0, 0, 0, 0};
 
-  // One staged tile of MFMAs.  In each 64-byte k-chunk lane (r, q) owns k = VEC*q + j, j < VEC.
-  auto compute = [&](int buf) {
+  // One staged tile of MFMAs over the 16-row sub-tiles MI_LO..MI_HI of this wave (compile-time range).
+  // In each 64-byte k-chunk lane (r, q) owns k = VEC*q + j, j < VEC.
+  auto compute = [&](int buf, auto lo_c, auto hi_c) {
+    constexpr int MI_LO = decltype(lo_c)::value, MI_HI = decltype(hi_c)::value;
 #pragma unroll
     for (int kc = 0; kc < KV; ++kc) {
       const int ko = kc * 4 * VEC;
       vec_t fa[4];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = MI_LO; mi <= MI_HI; ++mi)
         fa[mi] = *reinterpret_cast<const vec_t*>(sA(buf) + (wm * 64 + mi * 16 + r) * LDR + ko + q * VEC);
       if (BT) {
         vec_t fb[NI];
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
+          for (int mi = MI_LO; mi <= MI_HI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni][j], acc[mi][ni]);
       } else {
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) fb[ni] = sB(buf)[(ko + q * VEC + j) * LDN + wn * 16 * NI + ni * 16 + r];
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
+          for (int mi = MI_LO; mi <= MI_HI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni], acc[mi][ni]);
         }
@@ -212,37 +219,57 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
     }
   };
 
-  // In the diagonal 128-block of a triangular A, a wave whose 64 rows x 16 k lie entirely in the
-  // zero triangle skips that k-tile's MFMAs (a quarter of the block's work) but still stages and
-  // syncs.  The skipped tiles are a prefix (A upper, lower-half waves) or a suffix (A lower,
-  // upper-half waves) of the k-range, so the loop is split in three straight-line loops instead
-  // of branching around the MFMAs (hipcc shuffles all accumulators through VGPRs otherwise).
+  // Zero skipping in the diagonal 128-block of a triangular A, without branching around MFMAs (hipcc
+  // shuffles all accumulators through VGPRs when they are individually conditional): the k-loop is a
+  // sequence of straight-line loops.
+  //   * a wave whose 64 rows x BK k lie entirely in the zero triangle stages and syncs but issues no
+  //     MFMA: a prefix (A upper, lower-half waves) or a suffix (A lower, upper-half waves) of PT tiles;
+  //   * inside the wave's own 64 x 64 diagonal sub-block the 16-row sub-tiles drop out one by one: PT
+  //     tiles in four phases with a compile-time sub-tile range (mi >= u for A lower, mi <= u for A upper).
+  constexpr int PT = 64 / BK;               // staged tiles per 64 k
+  constexpr int PH = 16 / BK;               // staged tiles per 16 k (one phase)
   const int nk = (k_end - k_begin) / BK;
   const int wm_s = __builtin_amdgcn_readfirstlane(wm);
   int n_pre = 0, n_post = 0;
-  if ((p.flags & GF_A_LOWER) && wm_s == 0 && k_end == (ti + 1) * 128) n_post = min(nk, 64 / BK);
-  if ((p.flags & GF_A_UPPER) && wm_s == 1 && k_begin == ti * 128) n_pre = min(nk, 64 / BK);
+  bool part_lo = false, part_hi = false;
+  if ((p.flags & GF_A_LOWER) && k_end == (ti + 1) * 128 && k_begin <= ti * 128) { part_lo = true; n_post = wm_s == 0 ? PT : 0; }
+  if ((p.flags & GF_A_UPPER) && k_begin == ti * 128 && k_end >= (ti + 1) * 128) { part_hi = true; n_pre = wm_s == 1 ? PT : 0; }
   if (nk > 0) {
     gload();
     sstore(0);
   }
   __syncthreads();
   int t = 0;
-  for (; t < n_pre; ++t) {
+  auto idle = [&]() {
     if (t + 1 < nk) { gload(); sstore((t & 1) ^ 1); }
     __syncthreads();
-  }
-  for (; t < nk - n_post; ++t) {
+    ++t;
+  };
+  auto work = [&](auto lo_c, auto hi_c) {
     const int buf = t & 1;
     if (t + 1 < nk) gload();
-    compute(buf);
+    compute(buf, lo_c, hi_c);
     if (t + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
+    ++t;
+  };
+  using std::integral_constant;
+  while (t < n_pre) idle();
+  if (part_hi) {
+    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 2>{});
+    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 3>{});
   }
-  for (; t < nk; ++t) {
-    if (t + 1 < nk) { gload(); sstore((t & 1) ^ 1); }
-    __syncthreads();
+  const int t_main_end = nk - n_post - (part_lo ? PT : 0);
+  while (t < t_main_end) work(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+  if (part_lo) {
+    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+    for (int h = 0; h < PH; ++h) work(integral_constant<int, 1>{}, integral_constant<int, 3>{});
+    for (int h = 0; h < PH; ++h) work(integral_constant<int, 2>{}, integral_constant<int, 3>{});
+    for (int h = 0; h < PH; ++h) work(integral_constant<int, 3>{}, integral_constant<int, 3>{});
   }
+  while (t < nk) idle();
 
   // ---------------- epilogue ----------------
   const int64_t crow0 = (int64_t)ti * 128 + wm * 64;
