@@ -337,7 +337,8 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               strip[(mm * 16 + M::crow(q, g)) * LDE + ni * 16 + r] = cs[ni] * acc[pass * MPP + mm][ni][g];
-        __syncthreads();
+        // the strip is private to this wave and a wave's LDS operations complete in order: no block barrier
+        __builtin_amdgcn_wave_barrier();
         constexpr int LPR = WC / VEC;             // lanes per row of the strip
         constexpr int RPI = 64 / LPR;             // rows per wave instruction
 #pragma unroll
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
           }
           *reinterpret_cast<vec_t*>(Cg + grow * p.ldc + ccol0 + c4) = v;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }
