@@ -382,7 +382,7 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   const bool bt = (p.flags & GF_B_TRANS) != 0;
   if (epilogue != EPI_STORE) GPZ_REQUIRE(!bt, "gemm: stats / column-scale epilogues are NN only");
   if (epilogue == EPI_STORE_COLSCALE) GPZ_REQUIRE(p.colscale && p.beta == (T)0, "gemm: column-scale epilogue needs factors and beta = 0");
-  constexpr int KV = 1;
+  constexpr int KV = sizeof(T) == 4 ? 1 : 2;   // staged k-depth 16 for both precisions
   constexpr int NI = sizeof(T) == 4 ? 4 : 2;
   dim3 grid((unsigned)nblocks), block(1024 / NI);
   auto launch = [&](auto kernel, size_t lds) -> int {
