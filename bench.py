@@ -180,11 +180,12 @@ def main():
             for rep in range(2):
                 ev0.record()
                 o = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
-                                     chunk=a.chunk, want_Lu=False, **extra)
+                                     chunk=a.chunk, want_Lu=False, retain_wt=1.0 / 3, **extra)   # Wt stays in HBM
                 gmean = (o["mean"] - g["y"]) / c["noise_sd"] ** 2      # d(-ELBO)/dmean of the Gaussian closed form
                 gscale = o["scale"] / c["noise_sd"] ** 2                 # d(-ELBO)/dscale
                 ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], gmean,
-                                  gscale, o["scale"], chunk=a.chunk, kernel_grads=kg, **extra)
+                                  gscale, o["scale"], chunk=a.chunk, kernel_grads=kg, wt_cache=o.pop("wt_cache", None),
+                                  **extra)
                 ev1.record()
                 torch.cuda.synchronize()
                 train_ms[mode] = ev0.elapsed_time(ev1)

@@ -36,6 +36,7 @@ class SvgpProblem(C.Structure):
         ("mean", C.c_void_p), ("scale", C.c_void_p), ("Lu", C.c_void_p), ("chol", C.c_void_p),
         ("kl", C.c_void_p), ("loglik", C.c_void_p), ("elbo", C.c_void_p), ("info", C.c_void_p),
         ("factor_cache", C.c_void_p), ("factor_cache_valid", C.c_int64),
+        ("wt_cache", C.c_void_p), ("wt_cache_valid", C.c_int64),
     ]
 
 
@@ -58,6 +59,7 @@ _SIGNATURES = {
     "gpz_trsm_lln_batched": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                        C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpz_svgp_factor_cache_bytes": (C.c_size_t, [C.POINTER(SvgpProblem)]),
+    "gpz_svgp_wt_cache_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
     "gpz_svgp_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
     "gpz_svgp_forward": (C.c_int, [C.POINTER(SvgpProblem), C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpz_svgp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),

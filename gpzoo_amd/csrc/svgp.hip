@@ -346,6 +346,22 @@ static FactorCache<T> carve_cache(const Plan& pl, void* mem) {
   return f;
 }
 
+// Retained Wt (training): every chunk's Wt block and its colsum(Wt^2) partials, one full-width slot per chunk.
+template <typename T>
+struct WtCache {
+  T* base; int64_t wt_slot, ps_slot, nchunks;
+  T* wt(int64_t ci) const { return base + ci * wt_slot; }
+  T* ps1(int64_t ci) const { return base + nchunks * wt_slot + ci * ps_slot; }
+  size_t bytes() const { return sizeof(T) * (size_t)(nchunks * (wt_slot + ps_slot)); }
+};
+template <typename T>
+static WtCache<T> wt_cache_of(const Plan& pl, void* mem) {
+  WtCache<T> w;
+  w.base = static_cast<T*>(mem); w.nchunks = pl.nchunks;
+  w.wt_slot = pl.L * pl.Mp * pl.nc; w.ps_slot = pl.L * pl.nblk * pl.nc;
+  return w;
+}
+
 template <typename T>
 static Buffers<T> carve(const Plan& pl, bool whitened, void* ws) {
   Buffers<T> b;
@@ -453,11 +469,14 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
   // 3. chunks of columns
   static const int super_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 16; }();
   const int64_t esz = sizeof(T);
+  const WtCache<T> wtc = wt_cache_of<T>(pl, p->wt_cache);
   for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
     const int64_t n0 = ci * pl.nc;
     const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
     const int64_t ncp = pad_up(nreal);  // columns computed this chunk
     const int nt = (int)(ncp / NB);
+    T* const Wc = p->wt_cache ? wtc.wt(ci) : b.Wc;      // retained for the backward pass when asked for
+    T* const ps1 = p->wt_cache ? wtc.ps1(ci) : b.ps1;
     prof_begin(PROF_KFILL, s);
     if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
                               p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
@@ -467,22 +486,22 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     GemmParams<T> g1;  // Wt = Linv * Kzx, with colsum(Wt^2) and muE^T Wt
     g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
     g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
-    g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
+    g1.C = Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
     g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
-    g1.super_cols = super_cols; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
+    g1.super_cols = super_cols; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
     prof_begin(PROF_STAGE1, s);
     if (int rc = gemm_launch(g1, EPI_STORE_STATS, s)) return rc;
     prof_end(PROF_STAGE1, s);
     GemmParams<T> g2;  // colsum((LuE^T Wt)^2)
     g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
-    g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+    g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
     g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
     g2.super_cols = super_cols; g2.ps_sq = b.ps2; g2.ncols = ncp;
     prof_begin(PROF_STAGE2, s);
     if (int rc = gemm_launch(g2, EPI_STATS, s)) return rc;
     prof_end(PROF_STAGE2, s);
     FinalizeArgs<T> f;
-    f.ps1 = b.ps1; f.pm1 = b.pm1; f.ps2 = b.ps2; f.sigma = static_cast<const T*>(p->k.sigma);
+    f.ps1 = ps1; f.pm1 = b.pm1; f.ps2 = b.ps2; f.sigma = static_cast<const T*>(p->k.sigma);
     f.y = static_cast<const T*>(p->y); f.mean = static_cast<T*>(p->mean); f.scale = static_cast<T*>(p->scale);
     f.part = b.ll_part; f.N = N; f.n0 = n0; f.nc = ncp; f.nfb_total = pl.nfb_total; f.fb0 = ci * pl.nfb_chunk;
     f.mt = f.mt1 = (int)pl.nblk; f.whitened = wh; f.clamp_min = p->var_clamp_min; f.noise_sd = p->noise_sd;
@@ -906,42 +925,51 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   }
   static const int super_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 16; }();
   const int64_t esz = sizeof(T);
+  const bool have_wt = p->wt_cache != nullptr && p->wt_cache_valid != 0;
+  const WtCache<T> wtc = wt_cache_of<T>(pl, p->wt_cache);
   for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
     const int64_t n0 = ci * pl.nc;
     const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
     const int64_t ncp = pad_up(nreal);
     const int nt = (int)(ncp / NB);
     const void* Xc = static_cast<const char*>(p->X) + n0 * p->d * esz;
-    if (int rc = kfill_padded(&p->k, p->Z, M, Mp, Xc, nreal, ncp, p->d, p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp,
-                              Mp * ncp, 0.0, 0, pl.f32 ? GPZ_F32 : GPZ_F64, s))
-      return rc;
-    GemmParams<T> g1;  // W = Linv * Kzx (column sums of W^2 only when the clamp mask is needed)
-    g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
-    g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
-    g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
-    g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
-    g1.super_cols = super_cols; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
-    if (int rc = gemm_launch(g1, full ? EPI_STORE_STATS : EPI_STORE, s)) return rc;
+    T* Wc = b.Wc;
+    T* ps1 = b.ps1;
+    if (have_wt) {   // the forward pass kept Wt and its column sums: nothing to rebuild
+      Wc = wtc.wt(ci);
+      ps1 = wtc.ps1(ci);
+    } else {
+      if (int rc = kfill_padded(&p->k, p->Z, M, Mp, Xc, nreal, ncp, p->d, p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp,
+                                Mp * ncp, 0.0, 0, pl.f32 ? GPZ_F32 : GPZ_F64, s))
+        return rc;
+      GemmParams<T> g1;  // W = Linv * Kzx (column sums of W^2 only when the clamp mask is needed)
+      g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
+      g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
+      g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
+      g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
+      g1.super_cols = super_cols; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
+      if (int rc = gemm_launch(g1, full ? EPI_STORE_STATS : EPI_STORE, s)) return rc;
+    }
     hipLaunchKernelGGL((colscale_kernel<T>), dim3((unsigned)((ncp + 255) / 256), L32), dim3(256), 0, s,
                        static_cast<const T*>(g->g_scale), static_cast<const T*>(g->scale), N, n0, ncp, (int)wh,
-                       p->var_clamp_min, w.cs, static_cast<const T*>(g->g_mean), (const T*)b.ps1, (int)pl.nblk,
+                       p->var_clamp_min, w.cs, static_cast<const T*>(g->g_mean), (const T*)ps1, (int)pl.nblk,
                        static_cast<const T*>(p->k.sigma), w.csc, w.gmc);
     GPZ_LAUNCH_OK();
     GemmParams<T> g2;  // Pbar = (LuE^T W) diag(gv2)
     g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
-    g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+    g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
     g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
     g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
     g2.super_cols = super_cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
     if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
     GemmParams<T> g3;  // G += W Pbar^T  (lower tiles)
-    g3.A = b.Wc; g3.lda = ncp; g3.sA0 = Mp * ncp;
+    g3.A = Wc; g3.lda = ncp; g3.sA0 = Mp * ncp;
     g3.B = w.Pc; g3.ldb = ncp; g3.sB0 = Mp * ncp;
     g3.C = w.G; g3.ldc = Mp; g3.sC0 = mm;
     g3.nb0 = L32; g3.mt = g3.nt = (int)pl.nblk; g3.K = (int)ncp; g3.flags = GF_B_TRANS | GF_TILES_LOWER;
     g3.alpha = 1; g3.beta = 1;
     if (int rc = gemm_launch(g3, EPI_STORE, s)) return rc;
-    hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Wc, Mp, ncp,
+    hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, Wc, Mp, ncp,
                        static_cast<const T*>(g->g_mean), N, n0, w.mu_part, pl.nchunks, ci);
     GPZ_LAUNCH_OK();
     if (full) {
@@ -952,7 +980,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       g4.C = b.Kc; g4.ldc = ncp; g4.sC0 = Mp * ncp;
       g4.nb0 = L32; g4.mt = (int)pl.nblk; g4.nt = nt; g4.K = (int)Mp; g4.flags = GF_A_LOWER | GF_GROUP_COLS;
       g4.super_cols = super_cols; g4.colscale = w.csc; g4.colvec = w.gmc; g4.sCs = ncp; g4.rowvec = b.muE; g4.sRv = Mp;
-      g4.aux = b.Wc; g4.ncols = ncp;
+      g4.aux = Wc; g4.ncols = ncp;
       if (int rc = gemm_launch(g4, EPI_WBAR, s)) return rc;
       // Kbar_x = Linv^T Wbar                                   (into the Pbar buffer)
       GemmParams<T> g5;
@@ -964,7 +992,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       if (int rc = gemm_launch(g5, EPI_STORE, s)) return rc;
       // GL += Kbar_x W^T  (lower tiles):  dLoss/dL = -tril(GL)
       GemmParams<T> g6 = g3;
-      g6.A = w.Pc; g6.B = b.Wc; g6.C = w.GL;
+      g6.A = w.Pc; g6.B = Wc; g6.C = w.GL;
       if (int rc = gemm_launch(g6, EPI_STORE, s)) return rc;
       // kernel hyper-parameter and Z gradients from Kbar_x
       KgradArgs ka;
@@ -1119,6 +1147,12 @@ extern "C" int gpz_svgp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads
   hipStream_t s = static_cast<hipStream_t>(stream);
   return p->dtype == GPZ_F32 ? svgp_backward_t<float>(p, g, chunk, ws, ws_bytes, s)
                              : svgp_backward_t<double>(p, g, chunk, ws, ws_bytes, s);
+}
+
+extern "C" size_t gpz_svgp_wt_cache_bytes(const gpz_svgp_problem* p, int64_t chunk) {
+  if (check_problem(p)) return 0;
+  const Plan pl = make_plan(p, chunk);
+  return p->dtype == GPZ_F32 ? wt_cache_of<float>(pl, nullptr).bytes() : wt_cache_of<double>(pl, nullptr).bytes();
 }
 
 extern "C" size_t gpz_svgp_factor_cache_bytes(const gpz_svgp_problem* p) {

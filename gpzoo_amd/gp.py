@@ -151,13 +151,18 @@ class _FusedGP(nn.Module):
         args = (spec, X, self.Z)
         common = dict(clamp_min=self._clamp_min, **self._cache_args(spec, X), **gk)
 
+        kept = {}
+
         def fwd(mu, Lu_raw):
-            return ops.svgp_forward(*args, mu, Lu_raw, float(self.jitter), self._whitened,
-                                    want_chol=not self._whitened, **common)
+            # Wt of every chunk stays in HBM for the backward pass when it fits (a third of the free memory)
+            out = ops.svgp_forward(*args, mu, Lu_raw, float(self.jitter), self._whitened,
+                                   want_chol=not self._whitened, retain_wt=getattr(self, "retain_wt", 1.0 / 3), **common)
+            kept["wt"] = out.pop("wt_cache", None)
+            return out
 
         def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel, g_chol):
             return ops.svgp_backward(*args, mu, Lu_raw, float(self.jitter), self._whitened, g_mean, g_scale, scale,
-                                     kernel_grads=need_kernel, g_chol=g_chol, **common)
+                                     kernel_grads=need_kernel, g_chol=g_chol, wt_cache=kept.pop("wt", None), **common)
 
         call = dict(forward=fwd, backward=bwd)
         if gparam is not None:

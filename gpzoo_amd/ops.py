@@ -223,9 +223,12 @@ def _problem(spec: KernelSpec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp
 def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, *, gX=None, gZ=None,
                  y=None, noise_sd: Optional[float] = None, clamp_min: float = 1e-6, chunk: int = 0,
                  want_moments: bool = True, want_Lu: bool = True, want_chol: bool = False,
-                 check_info: bool = True, cache: Optional[FactorCache] = None, cache_key=None) -> dict:
+                 check_info: bool = True, cache: Optional[FactorCache] = None, cache_key=None,
+                 retain_wt: float = 0.0) -> dict:
     """One fused forward pass (gpz_svgp_forward).  Returns a dict with mean, scale
-    (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars."""
+    (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars.
+    ``retain_wt`` > 0: keep Wt of every chunk for ``svgp_backward(wt_cache=out["wt_cache"])`` when it fits
+    in that fraction of the free device memory (288 GB HBM: 52 GB at N=200k, M=2048, L=32, fp32)."""
     _need_cuda(X, Z, mu, Lu_raw)
     lib = _lib.load()
     keep: list = []
@@ -250,6 +253,11 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     p.info = info.data_ptr()
     if cache is not None:
         cache.attach(lib, p, cache_key, dev)
+    if retain_wt > 0:
+        need = lib.gpz_svgp_wt_cache_bytes(C.byref(p), int(chunk))
+        if 0 < need <= retain_wt * torch.cuda.mem_get_info(dev)[0]:
+            out["wt_cache"] = torch.empty(need, dtype=torch.uint8, device=dev)
+            p.wt_cache = out["wt_cache"].data_ptr()
     nbytes = lib.gpz_svgp_workspace_bytes(C.byref(p), int(chunk))
     if nbytes == 0:
         _lib.check(-1, "gpz_svgp_workspace_bytes")
@@ -269,9 +277,10 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
 
 def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
                   gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0, cache: Optional[FactorCache] = None,
-                  cache_key=None, kernel_grads: bool = False, g_chol=None):
+                  cache_key=None, kernel_grads: bool = False, g_chol=None, wt_cache=None):
     """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) (gpz_svgp_backward); with ``kernel_grads`` also
-    dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64."""
+    dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64.
+    ``wt_cache``: the buffer a forward pass on the same inputs and ``chunk`` returned under "wt_cache"."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
     lib = _lib.load()
     keep: list = []
@@ -296,6 +305,10 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
         g.grad_theta, g.grad_Z = gth.data_ptr(), gz.data_ptr()
     if cache is not None:
         cache.attach(lib, p, cache_key, dev)
+    if wt_cache is not None:
+        if wt_cache.numel() != lib.gpz_svgp_wt_cache_bytes(C.byref(p), int(chunk)):
+            raise ValueError("wt_cache does not belong to this problem / chunking")
+        p.wt_cache, p.wt_cache_valid = wt_cache.data_ptr(), 1
     nbytes = lib.gpz_svgp_backward_workspace_bytes(C.byref(p), int(chunk))
     if nbytes == 0:
         _lib.check(-1, "gpz_svgp_backward_workspace_bytes")

@@ -132,9 +132,16 @@ typedef struct gpz_svgp_problem {
    * Z / sigma / lengthscale / group parameters / jitter change (SURVEY §8f "next" #3). */
   void* factor_cache;
   int64_t factor_cache_valid;
+  /* Optional retained Wt = Linv Kzx of every N-chunk plus its column-sum partials, for training:
+   * non-NULL (gpz_svgp_wt_cache_bytes bytes, caller owned) makes gpz_svgp_forward write them there;
+   * gpz_svgp_backward with wt_cache_valid != 0 (same inputs, same `chunk`) reads them instead of
+   * rebuilding Kzx and repeating the first triangular product (one of its three big GEMMs). */
+  void* wt_cache;
+  int64_t wt_cache_valid;
 } gpz_svgp_problem;
 
 size_t gpz_svgp_factor_cache_bytes(const gpz_svgp_problem* p);
+size_t gpz_svgp_wt_cache_bytes(const gpz_svgp_problem* p, int64_t chunk);
 
 size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
 int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes,

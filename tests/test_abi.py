@@ -45,5 +45,5 @@ def test_argument_errors_do_not_touch_the_gpu():
 def test_struct_layout_matches_header():
     from gpzoo_amd import _lib
     assert ctypes.sizeof(_lib.KernelDesc) == 56
-    assert ctypes.sizeof(_lib.SvgpProblem) == 56 + 16 + 16 + 8 * 6 + 16 + 16 + 8 * 8 + 16
+    assert ctypes.sizeof(_lib.SvgpProblem) == 56 + 16 + 16 + 8 * 6 + 16 + 16 + 8 * 8 + 16 + 16
     assert ctypes.sizeof(_lib.SvgpGrads) == 64

@@ -211,3 +211,28 @@ def test_training_trajectory_matches_reference():
     torch.testing.assert_close(torch.tensor(losses, dtype=torch.float64), t("losses"), rtol=1e-7, atol=0)
     for k, v in model.state_dict().items():
         torch.testing.assert_close(v.cpu(), t("final." + k), rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("whitened,kernel_grads", [(True, False), (True, True), (False, True)])
+def test_retained_wt_gives_identical_gradients(whitened, kernel_grads):
+    """Training keeps Wt of every chunk in HBM between forward and backward (gpz_svgp_problem.wt_cache):
+    the gradients are bitwise those of the recomputing path, over several ragged chunks."""
+    from gpzoo_amd import ops
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(2, N=5000, M=300, L=3)
+    g = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
+    spec, extra = spec_for_config(g)
+    args = (spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], whitened)
+    out = ops.svgp_forward(*args, chunk=2048, retain_wt=0.5, want_chol=not whitened, **extra)
+    ref = ops.svgp_forward(*args, chunk=2048, want_chol=not whitened, **extra)
+    assert "wt_cache" in out and torch.equal(out["mean"], ref["mean"]) and torch.equal(out["scale"], ref["scale"])
+    gen = torch.Generator().manual_seed(5)
+    gm = torch.randn(out["mean"].shape, generator=gen).cuda()
+    gs = torch.randn(out["scale"].shape, generator=gen).cuda()
+    a = ops.svgp_backward(*args, gm, gs, out["scale"], chunk=2048, kernel_grads=kernel_grads, wt_cache=out["wt_cache"], **extra)
+    b = ops.svgp_backward(*args, gm, gs, out["scale"], chunk=2048, kernel_grads=kernel_grads, **extra)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        ops.svgp_backward(*args, gm, gs, out["scale"], chunk=1024, wt_cache=out["wt_cache"], **extra)
