@@ -1,4 +1,5 @@
-"""CPU, world_size 2, gloo: latent sharding + scalar all-reduce reproduce the single-rank ELBO.
+"""CPU, world_size 2, gloo: latent sharding (L >= ranks) or spot sharding (L < ranks) + scalar
+all-reduce reproduce the single-rank ELBO.
 The per-rank evaluator is injected (the oracle stands in for the HIP pass, which needs a GPU)."""
 import os
 import socket
@@ -18,13 +19,25 @@ def _oracle_eval(p):
     return e
 
 
+def _oracle_terms(p):
+    """(log-lik sum, KL sum): ELBO of the slice with and without its data term."""
+    from oracle import svgp_oracle as O
+    Kxx = O.kernel_diag(p["sigma"], p["X"].shape[0])
+    Kzx = O.kernel_matrix(p["kind"], p["Z"], p["X"], p["sigma"], p["lengthscale"])
+    Kzz = O.add_jitter_(O.kernel_matrix(p["kind"], p["Z"], p["Z"], p["sigma"], p["lengthscale"]).contiguous(), p["jitter"])
+    mean, scale, Lu, chol = O.wsvgp_moments(Kxx, Kzx, Kzz, p["mu"], p["Lu_raw"])
+    kl = O.whitened_kl(p["mu"], Lu)
+    zero = torch.zeros_like(kl)
+    return O.gaussian_elbo(p["y"], mean, scale, p["noise_sd"], zero), kl.sum()
+
+
 def _worker(rank, world, port, L, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gpzoo_amd.parallel import sharded_elbo
     torch.set_num_threads(2)
     full = make_config(2, N=400, M=48, L=L, dtype=torch.float64)
-    e = sharded_elbo(full, L, local_eval=_oracle_eval)
+    e = sharded_elbo(full, L, local_eval=_oracle_eval, local_terms=_oracle_terms)   # L < world: spots shard
     # a rank may also draw only its own block (what bench.py does): same numbers, same sum
     from gpzoo_amd.synthetic import shard_latents
     own = make_config(2, N=400, M=48, L=L, latents=shard_latents(L, world, rank), dtype=torch.float64)
