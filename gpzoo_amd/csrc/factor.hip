@@ -40,7 +40,18 @@ __global__ void scatter_diag_kernel(const double* __restrict__ Dinv, int64_t din
   for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) dst[(int64_t)(e >> 7) * ld + (e & 127)] = src[e];
 }
 
-static bool g_diag_attr_set = false;
+static bool g_diag_attr_set[64] = {};   // per device
+
+static int diag_lds_attr() {
+  int dev = 0;
+  GPZ_HIP_OK(hipGetDevice(&dev));
+  if (!g_diag_attr_set[dev & 63]) {
+    GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(diag128_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS_BYTES));
+    g_diag_attr_set[dev & 63] = true;
+  }
+  return 0;
+}
 
 // In-place Cholesky of `batch` padded (Mp,Mp) fp64 matrices; Dinv receives the inverse of
 // every diagonal 128-block: (batch, Mp/128, 128, 128).
@@ -50,11 +61,7 @@ int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t bat
   const int nblk = (int)(Mp / NB);
   const int64_t dstride = (int64_t)nblk * NB * NB;
   const size_t lds = DIAG_LDS_BYTES;
-  if (!g_diag_attr_set) {
-    GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(diag128_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    g_diag_attr_set = true;
-  }
+  if (int rc = diag_lds_attr()) return rc;
   GPZ_HIP_OK(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, s));
   prof_begin(PROF_POTRF_ALL, s);
   auto diag = [&](int k) -> int {
@@ -241,11 +248,7 @@ extern "C" int gpz_trsm_lln_batched(const double* Lc, int64_t ldl, int64_t strid
   hipLaunchKernelGGL(pad_copy_in_kernel, grid, dim3(256), 0, s, Lc, ldl, stride_l, M, Lp, Mp, 1);
   GPZ_LAUNCH_OK();
   const size_t lds = DIAG_LDS_BYTES;
-  if (!g_diag_attr_set) {
-    GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(diag128_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    g_diag_attr_set = true;
-  }
+  if (int rc = diag_lds_attr()) return rc;
   hipLaunchKernelGGL(diag128_kernel, dim3((unsigned)batch, nblk), dim3(256), lds, s, Lp, Mp, Mp * Mp, -1, Dinv,
                      (int64_t)nblk * NB * NB, (int32_t*)nullptr, M, 0);
   GPZ_LAUNCH_OK();

@@ -15,6 +15,7 @@
 // flop is spent on known-zero blocks.
 #include "gemm.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace gpz {
@@ -53,11 +54,13 @@ constexpr size_t gemm_lds_bytes() {
   return sizeof(T) * 2 * (128 * LDR + (BT ? 128 * LDR : BK * LDN));
 }
 
-// KV = number of 64-byte k-chunks per staged tile (1: 16-deep f32 / 8-deep f64 tiles, 37 KB of LDS).
+// KV = number of 64-byte k-chunks per staged tile (2 in production: 32-deep f32 / 16-deep f64 tiles,
+// 70 / 74 KB of LDS for the two buffers; with one chunk the one-tile prefetch distance of the fp64
+// kernel was shorter than the memory latency).
 // NI = 16-column sub-tiles per wave: 4 gives 4 waves (2x2) of 64x64, 2 gives 8 waves (2x4) of
-// 64x32.  fp64 MFMAs only reach their rate with >= 3 waves per SIMD (36 TF with one wave, 49 TF
-// with three or more, measured), which the 128 accumulator registers of a 64x64 fp64 wave tile
-// rule out; 64x32 halves them.
+// 64x32 (production).  fp64 MFMAs only reach their rate with >= 3 waves per SIMD (36 TF with one wave,
+// 49 TF with three or more, measured), which the 128 accumulator registers of a 64x64 fp64 wave tile
+// rule out; 64x32 halves them and leaves 4 waves per SIMD in both precisions.
 template <typename T, int KV, int NI, bool BT, int EPI>
 __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(const GemmParams<T> p) {
   constexpr int WN = 8 / NI;                // waves along N
@@ -227,7 +230,6 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
   //   * inside the wave's own 64 x 64 diagonal sub-block the 16-row sub-tiles drop out one by one: PT
   //     tiles in four phases with a compile-time sub-tile range (mi >= u for A lower, mi <= u for A upper).
   constexpr int PT = 64 / BK;               // staged tiles per 64 k
-  constexpr int PH = 16 / BK;               // staged tiles per 16 k (one phase)
   const int nk = (k_end - k_begin) / BK;
   const int wm_s = __builtin_amdgcn_readfirstlane(wm);
   int n_pre = 0, n_post = 0;
@@ -253,21 +255,27 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
     __syncthreads();
     ++t;
   };
+  // tile u of the diagonal sub-block covers k in [u*BK, (u+1)*BK): it needs the 16-row sub-tiles
+  // mi >= u*BK/16 when A is lower triangular, mi <= ((u+1)*BK-1)/16 when it is upper triangular
   using std::integral_constant;
   while (t < n_pre) idle();
   if (part_hi) {
-    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 0>{});
-    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 1>{});
-    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 2>{});
-    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+    auto phases = [&](auto self, auto u_c) -> void {
+      constexpr int U = decltype(u_c)::value;
+      work(integral_constant<int, 0>{}, integral_constant<int, ((U + 1) * BK - 1) / 16>{});
+      if constexpr (U + 1 < PT) self(self, integral_constant<int, U + 1>{});
+    };
+    phases(phases, integral_constant<int, 0>{});
   }
   const int t_main_end = nk - n_post - (part_lo ? PT : 0);
   while (t < t_main_end) work(integral_constant<int, 0>{}, integral_constant<int, 3>{});
   if (part_lo) {
-    for (int h = 0; h < PH; ++h) work(integral_constant<int, 0>{}, integral_constant<int, 3>{});
-    for (int h = 0; h < PH; ++h) work(integral_constant<int, 1>{}, integral_constant<int, 3>{});
-    for (int h = 0; h < PH; ++h) work(integral_constant<int, 2>{}, integral_constant<int, 3>{});
-    for (int h = 0; h < PH; ++h) work(integral_constant<int, 3>{}, integral_constant<int, 3>{});
+    auto phases = [&](auto self, auto u_c) -> void {
+      constexpr int U = decltype(u_c)::value;
+      work(integral_constant<int, (U * BK) / 16>{}, integral_constant<int, 3>{});
+      if constexpr (U + 1 < PT) self(self, integral_constant<int, U + 1>{});
+    };
+    phases(phases, integral_constant<int, 0>{});
   }
   while (t < nk) idle();
 
@@ -382,32 +390,40 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   const bool bt = (p.flags & GF_B_TRANS) != 0;
   if (epilogue != EPI_STORE) GPZ_REQUIRE(!bt, "gemm: stats / column-scale epilogues are NN only");
   if (epilogue == EPI_STORE_COLSCALE) GPZ_REQUIRE(p.colscale && p.beta == (T)0, "gemm: column-scale epilogue needs factors and beta = 0");
-  constexpr int KV = sizeof(T) == 4 ? 1 : 2;   // staged k-depth 16 for both precisions
-  constexpr int NI = sizeof(T) == 4 ? 4 : 2;
-  dim3 grid((unsigned)nblocks), block(1024 / NI);
-  auto launch = [&](auto kernel, size_t lds) -> int {
-    static bool attr_set = false;   // one flag per instantiation of this lambda's call operator
-    if (!attr_set && lds > 64 * 1024) {
-      GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-      attr_set = true;
+  // Tile configuration (KV 64-byte k-chunks per staged tile, NI 16-column sub-tiles per wave): both
+  // precisions run 8 waves of 64x32 on two-chunk tiles (32-deep fp32, 16-deep fp64), 4 waves per SIMD.
+  // Measured against 4 waves of 64x64 on one-chunk tiles in fp32: +0.6 % at M=2048, +4 % at M=512.
+  auto run = [&](auto kv_c, auto ni_c) -> int {
+    constexpr int KV = decltype(kv_c)::value, NI = decltype(ni_c)::value;
+    dim3 grid((unsigned)nblocks), block(1024 / NI);
+    auto launch = [&](auto kernel, size_t lds) -> int {
+      static bool attr_set[64] = {};  // per device; one table per instantiation of this lambda's call operator
+      int dev = 0;
+      GPZ_HIP_OK(hipGetDevice(&dev));
+      if (!attr_set[dev & 63] && lds > 64 * 1024) {
+        GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+        attr_set[dev & 63] = true;
+      }
+      hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
+      GPZ_LAUNCH_OK();
+      return 0;
+    };
+    if (epilogue == EPI_STORE)
+      return bt ? launch(gemm128_kernel<T, KV, NI, true, EPI_STORE>, gemm_lds_bytes<T, KV, true>())
+                : launch(gemm128_kernel<T, KV, NI, false, EPI_STORE>, gemm_lds_bytes<T, KV, false>());
+    if (epilogue == EPI_WBAR) {
+      GPZ_REQUIRE(p.colscale && p.colvec && p.rowvec && p.aux && p.beta == (T)0, "gemm: W-bar epilogue needs its operands");
+      return launch(gemm128_kernel<T, KV, NI, false, EPI_WBAR>, gemm_lds_bytes<T, KV, false>());
     }
-    hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
-    GPZ_LAUNCH_OK();
-    return 0;
+    if (epilogue == EPI_STORE_COLSCALE)
+      return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_COLSCALE>, gemm_lds_bytes<T, KV, false>());
+    if (epilogue == EPI_STORE_STATS)
+      return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_STATS>, gemm_lds_bytes<T, KV, false>());
+    return launch(gemm128_kernel<T, KV, NI, false, EPI_STATS>, gemm_lds_bytes<T, KV, false>());
   };
-  if (epilogue == EPI_STORE)
-    return bt ? launch(gemm128_kernel<T, KV, NI, true, EPI_STORE>, gemm_lds_bytes<T, KV, true>())
-              : launch(gemm128_kernel<T, KV, NI, false, EPI_STORE>, gemm_lds_bytes<T, KV, false>());
-  if (epilogue == EPI_WBAR) {
-    GPZ_REQUIRE(p.colscale && p.colvec && p.rowvec && p.aux && p.beta == (T)0, "gemm: W-bar epilogue needs its operands");
-    return launch(gemm128_kernel<T, KV, NI, false, EPI_WBAR>, gemm_lds_bytes<T, KV, false>());
-  }
-  if (epilogue == EPI_STORE_COLSCALE)
-    return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_COLSCALE>, gemm_lds_bytes<T, KV, false>());
-  if (epilogue == EPI_STORE_STATS)
-    return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_STATS>, gemm_lds_bytes<T, KV, false>());
-  return launch(gemm128_kernel<T, KV, NI, false, EPI_STATS>, gemm_lds_bytes<T, KV, false>());
+  using std::integral_constant;
+  return run(integral_constant<int, 2>{}, integral_constant<int, 2>{});
 }
 
 template int gemm_launch<float>(const GemmParams<float>&, int, hipStream_t);
