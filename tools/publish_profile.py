@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Copy the summaries of one tools/profile_round.sh run into profiles/<round>/ (tracked):
+kernel_stats.csv, bench_under_rocprof.json, pmc_per_dispatch.json, traffic_stage1.json.
+
+    python tools/publish_profile.py gpurun_out/prof_r01e profiles/r01
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+shutil.copy(glob.glob(src + "/trace/*/*_kernel_stats.csv")[0], dst + "/kernel_stats.csv")
+line = [l for l in open(src + "/trace.log") if l.startswith("{")][-1]
+open(dst + "/bench_under_rocprof.json", "w").write(line)
+bench = json.loads(line)
+here = os.path.dirname(os.path.abspath(__file__))
+subprocess.run([sys.executable, here + "/pmc_summary.py", *(src + "/pmc_" + k for k in ("fetch", "write", "l2", "sq")),
+                "--json", dst + "/pmc_per_dispatch.json"], check=True, stdout=subprocess.DEVNULL)
+pmc = json.load(open(dst + "/pmc_per_dispatch.json"))
+stage1 = [k for k in pmc if "gemm128_kernel<float" in k and k.rstrip(">").endswith(", false, 1")][0]
+v = pmc[stage1]
+cfgs = bench["config"]["workload"]
+N, M, L = (int(cfgs.split(f"{t}=")[1].split()[0].rstrip(",")) for t in ("N", "M", "L"))
+Mp = (M + 127) // 128 * 128
+launches = v["dispatches"] / 3                      # bench.py --steps 2 --warmup 1
+esz = 4
+algo = (2 * L * Mp * N * esz + launches * L * Mp * Mp * esz / 2) / launches    # Kzx read + Wt write + the Linv triangle per launch
+out = {"kernel": stage1, "workload": {"config": 3, "N": N, "M": M, "L": L, "chunk": 0, "launches_per_eval": launches},
+       "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"],
+       "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
+       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), averaged over "
+               "the dispatches of `python3 bench.py --steps 2 --warmup 1`; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+               "(gfx950 reports half the bytes of wide coalesced reads); counts L2->fabric requests, Infinity-Cache hits included",
+       "algorithmic_bytes_per_launch": algo}
+json.dump(out, open(dst + "/traffic_stage1.json", "w"), indent=1)
+print("bench under rocprof: %.1f ms/step, stage-1 avg launch %.3f ms, %.1f TF" % (
+    bench["ms_per_step"], bench["roofline"]["avg_launch_ms"], bench["roofline"]["achieved"]))
+for r in csv.DictReader(open(dst + "/kernel_stats.csv")):
+    if "gemm128_kernel<float" in r["Name"]:
+        print("rocprof:", r["Name"][:60], r["Calls"], "calls, avg %.3f ms" % (float(r["AverageNs"]) / 1e6))
+print("traffic %.2f GB / launch, algorithmic %.2f GB" % (out["hbm_bytes_per_launch"] / 1e9, algo / 1e9))
+for k in pmc:
+    if "gemm128_kernel<float" in k and "GRBM_GUI_ACTIVE" in pmc[k]:
+        w = pmc[k]
+        print(k, "MFMA busy %.3f, L2 hit %.3f" % (w["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * w["GRBM_GUI_ACTIVE"] / 8),
+                                                 w["TCC_HIT_sum"] / (w["TCC_HIT_sum"] + w["TCC_MISS_sum"])))
