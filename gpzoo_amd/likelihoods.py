@@ -78,8 +78,10 @@ def poisson_expected_loglik(qF_list, W_list, V_pos, y, E=10, with_lgamma=True, e
     mean = torch.cat([q.mean for q in qF_list], dim=0)
     scale = torch.cat([q.scale for q in qF_list], dim=0)
     W = torch.cat(list(W_list), dim=1)
-    if eps is None:
-        eps = torch.randn((E,) + tuple(mean.shape), dtype=mean.dtype, device=mean.device)
+    if eps is None:   # one draw per factor set, in order, through the function Normal.rsample itself uses
+        import torch.distributions.normal as tdn
+        eps = torch.cat([tdn._standard_normal((E,) + tuple(q.mean.shape), dtype=mean.dtype, device=mean.device)
+                         for q in qF_list], dim=1)
     return _PoissonLogLik.apply(mean, scale, W, V_pos, eps, y, with_lgamma)
 
 
@@ -268,3 +270,16 @@ class Hybrid_NSF(NSF):
         pY, qF2, pF2 = self._hybrid(qF, self.mF[:, idx], self.scale_qF[:, idx],
                                     torch.nn.functional.softplus(self.V)[idx], E)
         return pY, qF, qU, pU, qF2, pF2
+
+    def expected_loglik(self, X, y, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
+        """Fused training-step form over both factor sets (raw loadings W, W2 as in ``_hybrid``)."""
+        Xb = X if idx is None else X[idx]
+        mF, rs = (self.mF, self.scale_qF) if idx is None else (self.mF[:, idx], self.scale_qF[:, idx])
+        V = torch.nn.functional.softplus(self.V)
+        qF, qU, pU = self.gp(X=Xb, **kwargs)
+        scale2 = torch.nn.functional.softplus(rs)
+        qF2 = distributions.Normal(mF, scale2)
+        pF2 = distributions.Normal(torch.zeros_like(mF), torch.ones_like(scale2))
+        ll = poisson_expected_loglik([qF, qF2], [self.W, self.W2], V if idx is None else V[idx], y, E=E,
+                                     with_lgamma=with_lgamma, eps=eps)
+        return ll, qF, qU, pU, qF2, pF2

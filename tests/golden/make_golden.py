@@ -415,8 +415,57 @@ def trajectory_case():
     print("trajectory losses:", [round(v, 4) for v in losses])
 
 
+def poisson_trajectory_cases():
+    """The reference's mini-batch drivers end to end: `train_batched` (utilities.py:600-632) on NSF2 and
+    `train_hybrid_batched` (utilities.py:497-527) on Hybrid_NSF, both over an SVGP + NSF_RBF prior, every
+    parameter trainable, with the index draws (torch.multinomial) and the rsample noise replayed from the
+    fixture: losses per step and final parameters."""
+    import contextlib
+    import io
+    import torch.distributions.normal as tdn
+    import gpzoo.utilities as ru
+    steps, E, L, T, N, Nb, M, D = 8, 3, 3, 2, 150, 60, 16, 12
+    inp = make_inputs(950, N=N, M=M, d=2, L=L)
+    g = torch.Generator().manual_seed(951)
+    y = torch.poisson(3.0 * torch.rand(D, N, generator=g, dtype=torch.float64), generator=g)
+    idxs = torch.stack([torch.randperm(N, generator=g)[:Nb] for _ in range(steps)])
+    eps1 = torch.randn(steps, E, L, Nb, generator=g, dtype=torch.float64)
+    eps2 = torch.randn(steps, E, T, Nb, generator=g, dtype=torch.float64)
+    for name in ("nsf2", "hybrid_nsf"):
+        torch.manual_seed(7)
+        kern = rk.NSF_RBF(sigma=1.0, lengthscale=3.0, L=L)
+        gp = rgp.SVGP(kern, dim=2, M=M, jitter=1e-2)
+        gp.Z = nn.Parameter(inp["Z"].clone()); gp.mu = nn.Parameter(inp["mu"].clone()); gp.Lu = nn.Parameter(inp["Lu_raw"].clone())
+        if name == "nsf2":
+            model = rl.NSF2(gp, y, L=L).double()
+            queue = [e for e in eps1]
+            loop = ru.train_batched
+        else:
+            model = rl.Hybrid_NSF(gp, y, L=L, non_spatial_factors=T).double()
+            queue = [e for pair in zip(eps1, eps2) for e in pair]
+            loop = ru.train_hybrid_batched
+        init = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+        iq = [i for i in idxs]
+        o_norm, o_multi = tdn._standard_normal, torch.multinomial
+        tdn._standard_normal = lambda shape, dtype, device: queue.pop(0).to(dtype)
+        torch.multinomial = lambda *a, **k: iq.pop(0)
+        try:
+            opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+            with contextlib.redirect_stderr(io.StringIO()):
+                losses = loop(model, opt, inp["X"], y, torch.device("cpu"), steps=steps, E=E, batch_size=Nb)
+        finally:
+            tdn._standard_normal, torch.multinomial = o_norm, o_multi
+        rec = {"init." + k: v for k, v in init.items()}
+        rec.update({"final." + k: v.detach().numpy() for k, v in model.state_dict().items()})
+        np.savez_compressed(os.path.join(HERE, f"ref_trajectory_{name}_f64.npz"), X=inp["X"].numpy(), y=y.numpy(),
+                            idx=idxs.numpy(), eps1=eps1.numpy(), eps2=eps2.numpy(), losses=np.array(losses),
+                            lr=np.float64(1e-2), jitter=np.float64(1e-2), **rec)
+        print(f"trajectory {name} losses:", [round(v, 3) for v in losses])
+
+
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "trajectory"):
     trajectory_case()
+    poisson_trajectory_cases()
 
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "state_dict"):
     state_dict_cases()
