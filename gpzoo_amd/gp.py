@@ -308,7 +308,7 @@ class SVGP(_FusedGP):
         self._init_common(kernel, dim, M, jitter)
         self.precompute_distance = False
 
-    def forward_kernels(self, X, Z=None, **args):
+    def forward_kernels(self, X, Z, **args):
         return super().forward_kernels(X, **args)
 
     def forward(self, X, verbose=False):

@@ -368,6 +368,34 @@ def state_dict_cases():
         print(f"state_dict {name}: {list(table[name])}")
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(table, f, indent=1, sort_keys=True)
+    # call signatures (parameter names, order, defaults) of the public API the notebooks use
+    import inspect
+    import gpzoo.utilities as ru
+
+    def sig(f):
+        out = []
+        for n, q in inspect.signature(f).parameters.items():
+            d = None if q.default is inspect.Parameter.empty else repr(q.default)
+            out.append([n, str(q.kind), d])
+        return out
+    sigs = {}
+    for mod, names in ((rk, ["RBF", "NSF_RBF", "batched_RBF", "batched_Matern32", "MGGP_RBF", "MGGP_NSF_RBF", "batched_MGGP_RBF"]),
+                       (rgp, ["VNNGP", "SVGP", "WSVGP", "MGGP_SVGP", "MGGP_WSVGP", "GaussianPrior"]),
+                       (rl, ["GaussianLikelihood", "ExactLikelihood", "PoissonFactorization", "PNMF", "NSF2", "NSF", "MGGP_NSF",
+                             "Hybrid_NSF2", "Hybrid_NSF_Exact", "Hybrid_NSF"])):
+        for n in names:
+            cls = getattr(mod, n)
+            sigs[f"{mod.__name__}.{n}.__init__"] = sig(cls.__init__)
+            for meth in ("forward", "forward_batched", "forward_precomputed", "forward_kernels", "kernel_forward",
+                         "forward_distance", "covariance", "set_group_distances", "get_rate"):
+                if meth in vars(cls) or any(meth in vars(b) for b in cls.__mro__[1:-2]):
+                    sigs[f"{mod.__name__}.{n}.{meth}"] = sig(getattr(cls, meth))
+    for n in ("add_jitter", "whitened_KL", "svgp_forward", "_squared_dist", "_embed_distance_matrix", "reshape_param",
+              "train", "train_batched", "train_hybrid", "train_hybrid_batched", "train_closure_batched"):
+        sigs[f"gpzoo.utilities.{n}"] = sig(getattr(ru, n))
+    with open(os.path.join(HERE, "api_signatures.json"), "w") as f:
+        json.dump(sigs, f, indent=1, sort_keys=True)
+    print(f"{len(sigs)} signatures")
     # a checkpoint written by the reference (plain state_dict of tensors; loads with weights_only=True)
     torch.manual_seed(5)
     L, M, N = 3, 24, 90

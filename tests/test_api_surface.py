@@ -127,3 +127,37 @@ def test_state_dict_names_shapes_match_reference():
         sd = make().state_dict()
         got = {k: [list(v.shape), str(v.dtype)] for k, v in sd.items()}
         assert got == ref[name], f"{name}: {got} != {ref[name]}"
+
+
+def test_call_signatures_match_reference():
+    """Every public constructor / method / helper the notebooks call keeps the reference's parameter names,
+    order and defaults (fixture written from the reference by tests/golden/make_golden.py).  Extra trailing
+    keyword parameters with defaults (e.g. ``fused=True``) and a trailing ``**kwargs`` are allowed."""
+    import importlib
+    import inspect
+    import json
+    import os
+    from helpers import GOLDEN
+    with open(os.path.join(GOLDEN, "api_signatures.json")) as f:
+        ref = json.load(f)
+    bad = []
+    for key, want in ref.items():
+        mod_name, *path = key.split(".", 2)[0:1] + key.split(".")[1:]
+        parts = key.split(".")
+        mod = importlib.import_module(".".join(parts[:2]))
+        obj = mod
+        try:
+            for a in parts[2:]:
+                obj = getattr(obj, a)
+        except AttributeError:
+            bad.append(f"{key}: missing")
+            continue
+        got = [[n, str(q.kind), None if q.default is inspect.Parameter.empty else repr(q.default)]
+               for n, q in inspect.signature(obj).parameters.items()]
+        core = lambda ps: [p for p in ps if p[1] not in ("VAR_KEYWORD", "VAR_POSITIONAL")]  # noqa: E731
+        w, g = core(want), core(got)
+        w = [[n, k, d if n != "device" else None] for n, k, d in w]       # `device` may gain a default of None here
+        g_cmp = [[n, k, d if n != "device" else None] for n, k, d in g[:len(w)]]
+        if g_cmp != w or any(p[2] is None and p[0] != "device" for p in g[len(w):]):
+            bad.append(f"{key}: reference {want} != {got}")
+    assert not bad, "\n".join(bad)
