@@ -58,12 +58,15 @@ _workspaces: dict = {}
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    ws = _workspaces.get(device)
+    """Scratch buffer of at least ``nbytes`` for the library call about to be issued.  One buffer per
+    (device, stream): calls on one stream are ordered and may share it, calls on different streams may not."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        _workspaces.pop(device, None)
+        _workspaces.pop(key, None)
         ws = None
         ws = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 

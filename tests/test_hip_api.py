@@ -203,3 +203,29 @@ def test_reference_checkpoint_loads_and_reproduces_outputs():
     torch.testing.assert_close(qF.mean.cpu(), torch.from_numpy(out["mean"]), rtol=1e-5, atol=1e-8)
     torch.testing.assert_close(qF.scale.cpu(), torch.from_numpy(out["scale"]), rtol=1e-5, atol=1e-8)
     torch.testing.assert_close(pY.scale.cpu().expand(out["pY_scale"].shape), torch.from_numpy(out["pY_scale"]), rtol=1e-12, atol=0)
+
+
+def test_two_streams_do_not_share_scratch():
+    """Evaluations issued on two torch streams overlap on the GPU; each stream carves its own workspace."""
+    from gpzoo_amd import ops
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import make_config
+    probs = []
+    for L in (3, 5):
+        c = make_config(2, N=30000, M=512, L=L)
+        g = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
+        spec, extra = spec_for_config(g)
+        probs.append((c, g, spec, extra))
+    run = lambda p: ops.svgp_forward(p[2], p[1]["X"], p[1]["Z"], p[1]["mu"], p[1]["Lu_raw"], p[0]["jitter"], True,  # noqa: E731
+                                     y=p[1]["y"], noise_sd=p[0]["noise_sd"], check_info=False, **p[3])
+    ref = [run(p) for p in probs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    for rep in range(3):
+        for i, (st, p) in enumerate(zip(streams, probs)):
+            with torch.cuda.stream(st):
+                outs[i] = run(p)
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+        assert torch.equal(o["mean"], r["mean"]) and torch.equal(o["scale"], r["scale"]) and float(o["elbo"]) == float(r["elbo"])
