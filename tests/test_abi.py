@@ -47,3 +47,13 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.KernelDesc) == 56
     assert ctypes.sizeof(_lib.SvgpProblem) == 56 + 16 + 16 + 8 * 6 + 16 + 16 + 8 * 8 + 16 + 16
     assert ctypes.sizeof(_lib.SvgpGrads) == 64
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: without the built .so every entry into the product path raises."""
+    import pytest
+    from gpzoo_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libgpzoo_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU/torch fallback"):
+        _lib.load()
