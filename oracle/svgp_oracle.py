@@ -1,7 +1,7 @@
 """CPU oracle for the SVGP / WSVGP hot path of luisdiaz1997/GPzoo.
 
-TEST INFRASTRUCTURE ONLY.  This file is a CPU restatement (torch CPU tensors,
-no nn.Module, no autograd) of the arithmetic the reference performs on its hot
+TEST INFRASTRUCTURE ONLY.  This file is a CPU restatement (plain torch CPU tensor
+ops, no nn.Module; the gradient tests differentiate through it with torch autograd) of the arithmetic the reference performs on its hot
 path.  It is the *checker* for the HIP kernels: only ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
 import it.  Nothing under ``gpzoo_amd/`` imports it and the product path never
