@@ -142,9 +142,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int b = blockIdx.x;
   if (bk < 0) bk = blockIdx.y;   // all diagonal blocks in one launch (inverse-only mode)
   double* Ab = A + (int64_t)b * stride + (int64_t)bk * 128 * (lda + 1);
-  for (int e = tid; e < 128 * 128; e += 256) {
-    const int i = e >> 7, j = e & 127;
-    S[i * DP + j] = (j <= i) ? Ab[(int64_t)i * lda + j] : 0.0;
+  {
+    // the whole block with 32 independent 16-byte loads per thread in flight (a rolled load -> LDS loop pays
+    // one memory round trip per element: 64 x ~0.7 us); the strict upper triangle is zeroed on the way in
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 v[32];
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int e2 = tid + 256 * it, i = e2 >> 6, j = (e2 & 63) * 2;
+      v[it] = *reinterpret_cast<const d2*>(Ab + (int64_t)i * lda + j);
+    }
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int e2 = tid + 256 * it, i = e2 >> 6, j = (e2 & 63) * 2;
+      S[i * DP + j] = (j <= i) ? v[it][0] : 0.0;
+      S[i * DP + j + 1] = (j + 1 <= i) ? v[it][1] : 0.0;
+    }
   }
   if (tid < 128) S[tid * DP + 128] = 0.0;
   __syncthreads();
@@ -236,7 +249,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const double bv = (k >= j) ? XT(S, oA + j, oA + k) : 0.0;              // A^-1[k][j]
         T[it] = mma(av, bv, T[it]);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -250,7 +262,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const double av = (k <= i) ? XT(S, oB + k, oB + i) : 0.0;            // B^-1[i][k]
           X[it] = mma(-av, T[kt][g], X[it]);
         }
-      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it)
@@ -272,7 +283,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const double bv = (k >= j) ? XT(S, j, k) : 0.0;                        // A^-1[k][j], A = X[0:64][0:64]
         T[kt] = mma(av, bv, T[kt]);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -286,7 +296,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const double av = (k <= i) ? XT(S, 64 + k, 64 + i) : 0.0;            // B^-1[i][k], B = X[64:][64:]
           X[it] = mma(-av, T[kt][g], X[it]);
         }
-      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it)

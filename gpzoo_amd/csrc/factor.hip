@@ -19,6 +19,7 @@
 #include "common.h"
 #include "gemm.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace gpz {

@@ -314,17 +314,26 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
   if (EPI == EPI_STORE_STATS) __syncthreads();   // the strips below reuse the reduction scratch
   if (EPI != EPI_STATS) {
     T* Cg = p.C + b0 * p.sC0 + b1 * p.sC1;
-    if (EPI == EPI_STORE && p.beta != (T)0) {
-      // read-modify-write (trailing updates): straight from the accumulator layout
+    if (EPI == EPI_STORE && BT && p.beta != (T)0) {
+      // read-modify-write (trailing updates): straight from the accumulator layout.  All loads of a batch
+      // are issued before its first store: written element by element, the compiler must assume every store
+      // aliases the next load and the tile pays one memory round trip per element (32 x ~0.8 us in fp64)
+      // instead of one per 16-row sub-tile.
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi) {
+        T cin[NI][4];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            T* dst = Cg + (crow0 + mi * 16 + M::crow(q, g)) * p.ldc + ccol0 + ni * 16 + r;
-            *dst = p.alpha * acc[mi][ni][g] + p.beta * *dst;
-          }
+          for (int g = 0; g < 4; ++g)
+            cin[ni][g] = Cg[(crow0 + mi * 16 + M::crow(q, g)) * p.ldc + ccol0 + ni * 16 + r];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            Cg[(crow0 + mi * 16 + M::crow(q, g)) * p.ldc + ccol0 + ni * 16 + r] =
+                p.alpha * acc[mi][ni][g] + p.beta * cin[ni][g];
+      }
     } else {
       // pure store: transpose each wave's tile through its private LDS strip so every store
       // instruction writes whole row segments (16 B per lane) instead of 64-byte pieces
@@ -389,6 +398,7 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   GPZ_REQUIRE(nblocks < (1ll << 31), "gemm: grid too large");
   const bool bt = (p.flags & GF_B_TRANS) != 0;
   if (epilogue != EPI_STORE) GPZ_REQUIRE(!bt, "gemm: stats / column-scale epilogues are NN only");
+  if (p.beta != (T)0) GPZ_REQUIRE(bt && epilogue == EPI_STORE, "gemm: accumulation (beta != 0) is built for C += A * B^T only");
   if (epilogue == EPI_STORE_COLSCALE) GPZ_REQUIRE(p.colscale && p.beta == (T)0, "gemm: column-scale epilogue needs factors and beta = 0");
   // Tile configuration (KV 64-byte k-chunks per staged tile, NI 16-column sub-tiles per wave): both
   // precisions run 8 waves of 64x32 on two-chunk tiles (32-deep fp32, 16-deep fp64), 4 waves per SIMD.
