@@ -358,18 +358,28 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
         __builtin_amdgcn_wave_barrier();
         constexpr int LPR = WC / VEC;             // lanes per row of the strip
         constexpr int RPI = 64 / LPR;             // rows per wave instruction
+        constexpr int NIT = MPP * 16 / RPI;
+        const int c4 = (lane % LPR) * VEC;
+        vec_t w[NIT], sc, cv;
+        T rv[NIT];
+        if (EPI == EPI_WBAR) {   // every operand of the pass is loaded before its first store (stores may alias)
+          sc = *reinterpret_cast<const vec_t*>(p.colscale + b0 * p.sCs + ccol0 + c4);
+          cv = *reinterpret_cast<const vec_t*>(p.colvec + b0 * p.sCs + ccol0 + c4);
 #pragma unroll
-        for (int it = 0; it < MPP * 16 / RPI; ++it) {
-          const int row = it * RPI + lane / LPR, c4 = (lane % LPR) * VEC;
+          for (int it = 0; it < NIT; ++it) {
+            const int64_t grow = crow0 + pass * MPP * 16 + it * RPI + lane / LPR;
+            w[it] = *reinterpret_cast<const vec_t*>(p.aux + b0 * p.sC0 + b1 * p.sC1 + grow * p.ldc + ccol0 + c4);
+            rv[it] = p.rowvec[b0 * p.sRv + grow];
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int row = it * RPI + lane / LPR;
           vec_t v = *reinterpret_cast<const vec_t*>(strip + row * LDE + c4);
           const int64_t grow = crow0 + pass * MPP * 16 + row;
           if (EPI == EPI_WBAR) {
-            const vec_t w = *reinterpret_cast<const vec_t*>(p.aux + b0 * p.sC0 + b1 * p.sC1 + grow * p.ldc + ccol0 + c4);
-            const vec_t sc = *reinterpret_cast<const vec_t*>(p.colscale + b0 * p.sCs + ccol0 + c4);
-            const vec_t cv = *reinterpret_cast<const vec_t*>(p.colvec + b0 * p.sCs + ccol0 + c4);
-            const T rv = p.rowvec[b0 * p.sRv + grow];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] = v[e] + rv * cv[e] - w[e] * sc[e];
+            for (int e = 0; e < VEC; ++e) v[e] = v[e] + rv[it] * cv[e] - w[it][e] * sc[e];
           }
           *reinterpret_cast<vec_t*>(Cg + grow * p.ldc + ccol0 + c4) = v;
         }
