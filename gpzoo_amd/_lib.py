@@ -43,7 +43,8 @@ class SvgpProblem(C.Structure):
 class SvgpGrads(C.Structure):
     _fields_ = [("g_mean", C.c_void_p), ("g_scale", C.c_void_p), ("scale", C.c_void_p),
                 ("grad_mu", C.c_void_p), ("grad_Lu_raw", C.c_void_p),
-                ("grad_theta", C.c_void_p), ("grad_Z", C.c_void_p), ("g_chol", C.c_void_p)]
+                ("grad_theta", C.c_void_p), ("grad_Z", C.c_void_p), ("g_chol", C.c_void_p),
+                ("g_kl", C.c_void_p)]
 
 
 _SIGNATURES = {

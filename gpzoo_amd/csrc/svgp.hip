@@ -699,7 +699,8 @@ __global__ __launch_bounds__(256) void tril_transpose_kernel(const double* __res
 // Lbar = -tril(GL) (+ tril(upstream dLoss/dchol)) in fp64
 template <typename T>
 __global__ void lbar_kernel(const T* __restrict__ GL, int64_t Mp, int64_t M, const T* __restrict__ g_chol,
-                            const double* __restrict__ E, double* __restrict__ Lbar) {
+                            const double* __restrict__ E, double* __restrict__ Lbar,
+                            const double* __restrict__ g_kl = nullptr, const double* __restrict__ Lc = nullptr) {
   const int l = blockIdx.z;
   const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= Mp) return;
@@ -708,6 +709,7 @@ __global__ void lbar_kernel(const T* __restrict__ GL, int64_t Mp, int64_t M, con
     v = -(double)GL[(int64_t)l * Mp * Mp + i * Mp + j];
     if (E) v -= E[(int64_t)l * Mp * Mp + i * Mp + j];
     if (g_chol && i < M) v += (double)g_chol[(int64_t)l * M * M + i * M + j];
+    if (g_kl && i == j && i < M) v += g_kl[l] / Lc[(int64_t)l * Mp * Mp + i * Mp + i];   // d(sum log diag L)/dL
   }
   Lbar[(int64_t)l * Mp * Mp + i * Mp + j] = v;
 }
@@ -841,15 +843,31 @@ __global__ void tril_kernel(T* __restrict__ G, int64_t Mp) {
 // chain rule of the constraint Lu = tril(raw, -1) + diag(exp(diag raw))
 template <typename T>
 __global__ void lu_grad_kernel(const T* __restrict__ G, int64_t Mp, int64_t M, const T* __restrict__ raw,
-                               T* __restrict__ out) {
+                               T* __restrict__ out, const double* __restrict__ g_kl = nullptr) {
   const int l = blockIdx.z;
   const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= M) return;
   const T g = G[(int64_t)l * Mp * Mp + i * Mp + j];
   T v = 0;
   if (j < i) v = g;
-  else if (j == i) v = g * (T)exp((double)raw[(int64_t)l * M * M + i * M + i]);
+  else if (j == i)   // Lu_ii = exp(raw_ii); the KL's -log Lu_ii contributes -g_kl to the raw diagonal
+    v = (T)((double)g * exp((double)raw[(int64_t)l * M * M + i * M + i]) - (g_kl ? g_kl[l] : 0.0));
   out[(int64_t)l * M * M + i * M + j] = v;
+}
+
+// KL(qU || pU) folded into the un-whitened gradients: dKL/dLuE = LuE (lower), dKL/dmuE = muE
+template <typename T>
+__global__ void kl_add_kernel(T* __restrict__ G, int64_t Mp, const double* __restrict__ LuW,
+                              double* __restrict__ mu_sum, const T* __restrict__ muE, const double* __restrict__ g_kl) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  const double gk = g_kl[l];
+  if (j <= i) {
+    const int64_t o = (int64_t)l * Mp * Mp + i * Mp + j;
+    G[o] = (T)((double)G[o] + gk * LuW[o]);
+  }
+  if (j == 0) mu_sum[(int64_t)l * Mp + i] += gk * (double)muE[(int64_t)l * Mp + i];
 }
 
 template <typename T>
@@ -1010,6 +1028,11 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.mu_part, pl.nchunks,
                      Mp, w.mu_sum);
   GPZ_LAUNCH_OK();
+  const double* g_kl = wh ? nullptr : g->g_kl;     // whitened KL: element-wise, left to the caller
+  if (g_kl) {
+    hipLaunchKernelGGL((kl_add_kernel<T>), gm, dim3(256), 0, s, w.G, Mp, b.LuW, w.mu_sum, b.muE, g_kl);
+    GPZ_LAUNCH_OK();
+  }
   hipLaunchKernelGGL((mu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, w.mu_sum,
                      wh ? (const double*)nullptr : b.Linv, Mp, M, static_cast<T*>(g->grad_mu));
   GPZ_LAUNCH_OK();
@@ -1030,7 +1053,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     Gfin = w.G2;
   }
   hipLaunchKernelGGL((lu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)M, L32), dim3(256), 0, s, Gfin, Mp,
-                     M, static_cast<const T*>(p->Lu_raw), static_cast<T*>(g->grad_Lu_raw));
+                     M, static_cast<const T*>(p->Lu_raw), static_cast<T*>(g->grad_Lu_raw), g_kl);
   GPZ_LAUNCH_OK();
   if (full) {
     // Cholesky backward (Murray 2016): Kbar_zz = Linv^T Phi(L^T Lbar) Linv with Lbar = -tril(GL)
@@ -1055,7 +1078,8 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       if (int rc = dgemm(w.D1, w.D2, w.D3, GF_A_UPPER)) return rc;                                // D3 = E
       E = w.D3;
     }
-    hipLaunchKernelGGL((lbar_kernel<T>), gm, dim3(256), 0, s, w.GL, Mp, M, static_cast<const T*>(g->g_chol), E, w.D2);
+    hipLaunchKernelGGL((lbar_kernel<T>), gm, dim3(256), 0, s, w.GL, Mp, M, static_cast<const T*>(g->g_chol), E, w.D2,
+                       g_kl, b.Kzz);
     GPZ_LAUNCH_OK();                                                                              // D2 = Lbar
     hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Kzz, Mp, w.D1);            // D1 = L^T
     GPZ_LAUNCH_OK();

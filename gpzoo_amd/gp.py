@@ -33,9 +33,9 @@ def _like(grad_l: torch.Tensor, param: torch.Tensor) -> torch.Tensor:
 
 
 class _QFMoments(torch.autograd.Function):
-    """(mean, scale) of q(F) as a differentiable function of mu, the raw Lu and -- on the whitened
-    path -- Z and the kernel hyper-parameters.  forward = gpz_svgp_forward, backward =
-    gpz_svgp_backward (SURVEY.md §8f "next" #1)."""
+    """(mean, scale) of q(F) -- and, un-whitened, chol(Kzz) and the per-latent KL(qU || pU) -- as a
+    differentiable function of mu, the raw Lu, Z and the kernel hyper-parameters.
+    forward = gpz_svgp_forward, backward = gpz_svgp_backward (SURVEY.md §8f "next" #1)."""
 
     @staticmethod
     def forward(ctx, mu, Lu_raw, Z, sigma, lengthscale, group_param, call):
@@ -49,10 +49,10 @@ class _QFMoments(torch.autograd.Function):
         if chol is None:
             chol = out["Lu"].new_empty(0)
             ctx.mark_non_differentiable(chol)
-        return out["mean"], out["scale"], out["Lu"], chol
+        return out["mean"], out["scale"], out["Lu"], chol, out["kl"].to(out["mean"].dtype)
 
     @staticmethod
-    def backward(ctx, g_mean, g_scale, _g_lu, _g_chol):
+    def backward(ctx, g_mean, g_scale, _g_lu, _g_chol, g_kl):
         mu, Lu_raw, scale, Z, sigma, lengthscale, group_param = ctx.saved_tensors
         if g_mean is None:
             g_mean = torch.zeros_like(scale)
@@ -60,7 +60,7 @@ class _QFMoments(torch.autograd.Function):
             g_scale = torch.zeros_like(scale)
         need_kernel = any(ctx.needs_input_grad[2:6])
         res = ctx.call["backward"](mu, Lu_raw, g_mean, g_scale, scale, need_kernel,
-                                   _g_chol if (need_kernel and _g_chol is not None and _g_chol.numel()) else None)
+                                   _g_chol if (need_kernel and _g_chol is not None and _g_chol.numel()) else None, g_kl)
         grads = [res[0].reshape(mu.shape), res[1].reshape(Lu_raw.shape), None, None, None, None, None]
         if need_kernel:
             gth, gZ = res[2], res[3]
@@ -70,6 +70,27 @@ class _QFMoments(torch.autograd.Function):
             if ctx.has_group:
                 grads[5] = _like(gth[:, 2], group_param) * ctx.call["group_chain"]
         return tuple(grads)
+
+
+class _FusedQU(distributions.MultivariateNormal):
+    """q(U) as returned by the un-whitened modules while training: a MultivariateNormal that remembers the
+    per-latent KL(qU || pU) the fused pass already evaluated (differentiable through gpz_svgp_backward)."""
+    _gpz_kl = None
+    _gpz_pair = None
+
+
+class _FusedPU(distributions.MultivariateNormal):
+    _gpz_pair = None
+
+
+@distributions.kl.register_kl(_FusedQU, _FusedPU)
+def _kl_fused(q, p):
+    """kl_divergence(qU, pU) (utilities.py:481) without torch's batched triangular solves: the value comes
+    from the forward pass, its gradient is folded into the fused backward.  Any other pairing falls back
+    to torch's MVN-MVN formula."""
+    if q._gpz_kl is not None and q._gpz_pair is not None and q._gpz_pair is p._gpz_pair:
+        return q._gpz_kl
+    return distributions.kl._kl_multivariatenormal_multivariatenormal(q, p)
 
 
 class _FusedGP(nn.Module):
@@ -160,24 +181,29 @@ class _FusedGP(nn.Module):
             kept["wt"] = out.pop("wt_cache", None)
             return out
 
-        def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel, g_chol):
+        def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel, g_chol, g_kl):
             return ops.svgp_backward(*args, mu, Lu_raw, float(self.jitter), self._whitened, g_mean, g_scale, scale,
-                                     kernel_grads=need_kernel, g_chol=g_chol, wt_cache=kept.pop("wt", None), **common)
+                                     kernel_grads=need_kernel, g_chol=g_chol, wt_cache=kept.pop("wt", None),
+                                     g_kl=None if self._whitened else g_kl, **common)
 
         call = dict(forward=fwd, backward=bwd)
         if gparam is not None:
             call["group_chain"] = self.kernel._group_a_chain()
-        mean, scale, _, chol = _QFMoments.apply(self.mu, self.Lu, self.Z, self.kernel.sigma, self.kernel.lengthscale,
-                                                gparam, call)
-        # q(U)'s scale_tril through torch so that KL terms differentiate w.r.t. the raw parameter
+        mean, scale, _, chol, kl = _QFMoments.apply(self.mu, self.Lu, self.Z, self.kernel.sigma,
+                                                    self.kernel.lengthscale, gparam, call)
+        # q(U)'s scale_tril through torch so that other uses of it differentiate w.r.t. the raw parameter
         Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
         single = self.mu.dim() == 1
         pick = (lambda t: t[0]) if single else (lambda t: t)
         qF = distributions.Normal(pick(mean), pick(scale))
-        qU = distributions.MultivariateNormal(self.mu, scale_tril=Lu)
-        pU = None
-        if not self._whitened:
-            pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(chol))
+        if self._whitened:
+            return qF, distributions.MultivariateNormal(self.mu, scale_tril=Lu), None
+        # un-whitened: kl_divergence(qU, pU) resolves to the KL the fused pass already holds (_kl_fused);
+        # the matrices are valid by construction, so the O(L M^2) argument validation is skipped
+        qU = _FusedQU(self.mu, scale_tril=Lu, validate_args=False)
+        pU = _FusedPU(torch.zeros_like(self.mu), scale_tril=pick(chol), validate_args=False)
+        qU._gpz_kl, qU._gpz_pair = pick(kl), pU
+        pU._gpz_pair = pU
         return qF, qU, pU
 
     def elbo(self, X, y, noise_sd, groupsX=None, chunk=0):

@@ -280,10 +280,12 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
 
 def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
                   gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0, cache: Optional[FactorCache] = None,
-                  cache_key=None, kernel_grads: bool = False, g_chol=None, wt_cache=None):
+                  cache_key=None, kernel_grads: bool = False, g_chol=None, wt_cache=None, g_kl=None):
     """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) (gpz_svgp_backward); with ``kernel_grads`` also
     dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64.
-    ``wt_cache``: the buffer a forward pass on the same inputs and ``chunk`` returned under "wt_cache"."""
+    ``wt_cache``: the buffer a forward pass on the same inputs and ``chunk`` returned under "wt_cache".
+    ``g_kl`` (L,): upstream gradient of the forward's per-latent ``kl`` (un-whitened path); its own
+    gradient is folded into the results."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
     lib = _lib.load()
     keep: list = []
@@ -306,6 +308,10 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
         gth = torch.zeros((L, 4), dtype=torch.float64, device=dev)
         gz = torch.zeros((M, 4), dtype=torch.float64, device=dev)
         g.grad_theta, g.grad_Z = gth.data_ptr(), gz.data_ptr()
+    if g_kl is not None and not whitened:
+        gk = g_kl.detach().to(device=dev, dtype=torch.float64).reshape(-1).expand(L).contiguous()
+        keep.append(gk)
+        g.g_kl = gk.data_ptr()
     if cache is not None:
         cache.attach(lib, p, cache_key, dev)
     if wt_cache is not None:

@@ -165,6 +165,12 @@ typedef struct gpz_svgp_grads {
   double* grad_theta;    /* (L,4) fp64: d/dsigma, d/dlengthscale, d/dgroup_a (effective), 0 */
   double* grad_Z;        /* (M,4) fp64: first d columns used */
   const void* g_chol;    /* (L,M,M) dtype or NULL: upstream dLoss/dchol (un-whitened: KL(qU||pU) uses it) */
+  /* (L,) fp64 or NULL: upstream dLoss/dkl_l of the per-latent KL the forward pass reports (`kl`).  The
+   * KL's own gradient -- kl_divergence(qU, pU) through torch's MVN KL and its autograd in the reference
+   * (utilities.py:481) -- is then folded into grad_mu, grad_Lu_raw and, with grad_theta / grad_Z, into
+   * the factor's gradient, at no extra matrix product: dKL/dLuE = LuE, dKL/dmuE = muE, plus the two
+   * log-determinant diagonals. */
+  const double* g_kl;
 } gpz_svgp_grads;
 
 size_t gpz_svgp_backward_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);

@@ -46,7 +46,7 @@ def test_struct_layout_matches_header():
     from gpzoo_amd import _lib
     assert ctypes.sizeof(_lib.KernelDesc) == 56
     assert ctypes.sizeof(_lib.SvgpProblem) == 56 + 16 + 16 + 8 * 6 + 16 + 16 + 8 * 8 + 16 + 16
-    assert ctypes.sizeof(_lib.SvgpGrads) == 64
+    assert ctypes.sizeof(_lib.SvgpGrads) == 72
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
