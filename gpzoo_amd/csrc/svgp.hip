@@ -817,13 +817,15 @@ __global__ void chunk_sum_kernel(const double* __restrict__ part, int64_t nchunk
 // out[l][a] = sum_{i >= a} Linv[l][i][a] * v[l][i]   (Linv^T v, Linv lower triangular) or v itself
 template <typename T>
 __global__ void mu_grad_kernel(const double* __restrict__ v, const double* __restrict__ Linv, int64_t Mp, int64_t M,
-                               T* __restrict__ out) {
+                               T* __restrict__ out, const double* __restrict__ g_kl_w = nullptr,
+                               const T* __restrict__ mu = nullptr) {
   const int l = blockIdx.y;
   const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (a >= M) return;
   double t;
   if (!Linv) {
     t = v[(int64_t)l * Mp + a];
+    if (g_kl_w) t += g_kl_w[l] * (double)mu[(int64_t)l * M + a];     // whitened KL: d/dmu of |mu|^2 / 2
   } else {
     t = 0.0;
     const double* Lb = Linv + (int64_t)l * Mp * Mp;
@@ -843,15 +845,22 @@ __global__ void tril_kernel(T* __restrict__ G, int64_t Mp) {
 // chain rule of the constraint Lu = tril(raw, -1) + diag(exp(diag raw))
 template <typename T>
 __global__ void lu_grad_kernel(const T* __restrict__ G, int64_t Mp, int64_t M, const T* __restrict__ raw,
-                               T* __restrict__ out, const double* __restrict__ g_kl = nullptr) {
+                               T* __restrict__ out, const double* __restrict__ g_kl = nullptr, int whitened_kl = 0) {
   const int l = blockIdx.z;
   const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= M) return;
-  const T g = G[(int64_t)l * Mp * Mp + i * Mp + j];
+  double g = (double)G[(int64_t)l * Mp * Mp + i * Mp + j];
+  const double gk = g_kl ? g_kl[l] : 0.0;
+  const double x = (double)raw[(int64_t)l * M * M + i * M + j];
   T v = 0;
-  if (j < i) v = g;
-  else if (j == i)   // Lu_ii = exp(raw_ii); the KL's -log Lu_ii contributes -g_kl to the raw diagonal
-    v = (T)((double)g * exp((double)raw[(int64_t)l * M * M + i * M + i]) - (g_kl ? g_kl[l] : 0.0));
+  if (j < i) {
+    if (whitened_kl) g += gk * x;                 // whitened KL: d/dLu of |Lu|_F^2 / 2 (un-whitened: already in G)
+    v = (T)g;
+  } else if (j == i) {   // Lu_ii = exp(raw_ii); the KL's -log Lu_ii contributes -g_kl to the raw diagonal
+    const double e = exp(x);
+    if (whitened_kl) g += gk * e;
+    v = (T)(g * e - gk);
+  }
   out[(int64_t)l * M * M + i * M + j] = v;
 }
 
@@ -1028,13 +1037,14 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.mu_part, pl.nchunks,
                      Mp, w.mu_sum);
   GPZ_LAUNCH_OK();
-  const double* g_kl = wh ? nullptr : g->g_kl;     // whitened KL: element-wise, left to the caller
-  if (g_kl) {
+  const double* g_kl = g->g_kl;
+  if (g_kl && !wh) {
     hipLaunchKernelGGL((kl_add_kernel<T>), gm, dim3(256), 0, s, w.G, Mp, b.LuW, w.mu_sum, b.muE, g_kl);
     GPZ_LAUNCH_OK();
   }
   hipLaunchKernelGGL((mu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, w.mu_sum,
-                     wh ? (const double*)nullptr : b.Linv, Mp, M, static_cast<T*>(g->grad_mu));
+                     wh ? (const double*)nullptr : b.Linv, Mp, M, static_cast<T*>(g->grad_mu), wh ? g_kl : nullptr,
+                     static_cast<const T*>(p->mu));
   GPZ_LAUNCH_OK();
   T* Gfin = w.G;
   if (!wh) {
@@ -1053,7 +1063,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     Gfin = w.G2;
   }
   hipLaunchKernelGGL((lu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)M, L32), dim3(256), 0, s, Gfin, Mp,
-                     M, static_cast<const T*>(p->Lu_raw), static_cast<T*>(g->grad_Lu_raw), g_kl);
+                     M, static_cast<const T*>(p->Lu_raw), static_cast<T*>(g->grad_Lu_raw), g_kl, (int)wh);
   GPZ_LAUNCH_OK();
   if (full) {
     // Cholesky backward (Murray 2016): Kbar_zz = Linv^T Phi(L^T Lbar) Linv with Lbar = -tril(GL)
@@ -1079,7 +1089,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       E = w.D3;
     }
     hipLaunchKernelGGL((lbar_kernel<T>), gm, dim3(256), 0, s, w.GL, Mp, M, static_cast<const T*>(g->g_chol), E, w.D2,
-                       g_kl, b.Kzz);
+                       wh ? nullptr : g_kl, b.Kzz);
     GPZ_LAUNCH_OK();                                                                              // D2 = Lbar
     hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Kzz, Mp, w.D1);            // D1 = L^T
     GPZ_LAUNCH_OK();

@@ -150,10 +150,13 @@ class _FusedGP(nn.Module):
         single = self.mu.dim() == 1
         pick = (lambda t: t[0]) if single else (lambda t: t)
         qF = distributions.Normal(pick(out["mean"]), pick(out["scale"]))
-        qU = distributions.MultivariateNormal(self.mu, scale_tril=pick(out["Lu"]))
+        qU = _FusedQU(self.mu, scale_tril=pick(out["Lu"]), validate_args=False)
+        if "kl" in out:
+            qU._gpz_kl = pick(out["kl"].to(out["Lu"].dtype))
         pU = None
         if not self._whitened:
-            pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(out["chol"]))
+            pU = _FusedPU(torch.zeros_like(self.mu), scale_tril=pick(out["chol"]), validate_args=False)
+            qU._gpz_pair = pU._gpz_pair = pU
         return qF, qU, pU
 
     def _forward(self, X, groupsX=None, verbose=False):
@@ -184,7 +187,7 @@ class _FusedGP(nn.Module):
         def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel, g_chol, g_kl):
             return ops.svgp_backward(*args, mu, Lu_raw, float(self.jitter), self._whitened, g_mean, g_scale, scale,
                                      kernel_grads=need_kernel, g_chol=g_chol, wt_cache=kept.pop("wt", None),
-                                     g_kl=None if self._whitened else g_kl, **common)
+                                     g_kl=g_kl, **common)
 
         call = dict(forward=fwd, backward=bwd)
         if gparam is not None:
@@ -196,14 +199,14 @@ class _FusedGP(nn.Module):
         single = self.mu.dim() == 1
         pick = (lambda t: t[0]) if single else (lambda t: t)
         qF = distributions.Normal(pick(mean), pick(scale))
-        if self._whitened:
-            return qF, distributions.MultivariateNormal(self.mu, scale_tril=Lu), None
-        # un-whitened: kl_divergence(qU, pU) resolves to the KL the fused pass already holds (_kl_fused);
-        # the matrices are valid by construction, so the O(L M^2) argument validation is skipped
+        # the matrices are valid by construction, so the O(L M^2) argument validation of scale_tril is skipped
         qU = _FusedQU(self.mu, scale_tril=Lu, validate_args=False)
+        qU._gpz_kl = pick(kl)          # whitened: read by the training loops' KL term (utilities._kl_u)
+        if self._whitened:
+            return qF, qU, None
+        # un-whitened: kl_divergence(qU, pU) resolves to the KL the fused pass already holds (_kl_fused)
         pU = _FusedPU(torch.zeros_like(self.mu), scale_tril=pick(chol), validate_args=False)
-        qU._gpz_kl, qU._gpz_pair = pick(kl), pU
-        pU._gpz_pair = pU
+        qU._gpz_pair = pU._gpz_pair = pU
         return qF, qU, pU
 
     def elbo(self, X, y, noise_sd, groupsX=None, chunk=0):

@@ -284,7 +284,7 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) (gpz_svgp_backward); with ``kernel_grads`` also
     dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64.
     ``wt_cache``: the buffer a forward pass on the same inputs and ``chunk`` returned under "wt_cache".
-    ``g_kl`` (L,): upstream gradient of the forward's per-latent ``kl`` (un-whitened path); its own
+    ``g_kl`` (L,): upstream gradient of the forward's per-latent ``kl``; its own
     gradient is folded into the results."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
     lib = _lib.load()
@@ -308,7 +308,7 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
         gth = torch.zeros((L, 4), dtype=torch.float64, device=dev)
         gz = torch.zeros((M, 4), dtype=torch.float64, device=dev)
         g.grad_theta, g.grad_Z = gth.data_ptr(), gz.data_ptr()
-    if g_kl is not None and not whitened:
+    if g_kl is not None:
         gk = g_kl.detach().to(device=dev, dtype=torch.float64).reshape(-1).expand(L).contiguous()
         keep.append(gk)
         g.g_kl = gk.data_ptr()

@@ -74,7 +74,8 @@ def _kl_u(qU, pU):
     call kl_divergence(qU, pU) and therefore only run un-whitened priors)."""
     from torch import distributions
     if pU is None:
-        return whitened_KL_batched(qU.mean, qU.scale_tril).sum()
+        kl = getattr(qU, "_gpz_kl", None)       # the fused pass's own per-latent KL (differentiable), when present
+        return kl.sum() if kl is not None else whitened_KL_batched(qU.mean, qU.scale_tril).sum()
     return torch.sum(distributions.kl_divergence(qU, pU))
 
 

@@ -168,8 +168,8 @@ typedef struct gpz_svgp_grads {
   /* (L,) fp64 or NULL: upstream dLoss/dkl_l of the per-latent KL the forward pass reports (`kl`).  The
    * KL's own gradient -- kl_divergence(qU, pU) through torch's MVN KL and its autograd in the reference
    * (utilities.py:481) -- is then folded into grad_mu, grad_Lu_raw and, with grad_theta / grad_Z, into
-   * the factor's gradient, at no extra matrix product: dKL/dLuE = LuE, dKL/dmuE = muE, plus the two
-   * log-determinant diagonals. */
+   * the factor's gradient, at no extra matrix product: dKL/dLuE = LuE, dKL/dmuE = muE, plus the
+   * log-determinant diagonals (whitened: LuE = Lu, muE = mu, the whitened_KL of utilities.py:27-36). */
   const double* g_kl;
 } gpz_svgp_grads;
 

@@ -236,3 +236,41 @@ def test_retained_wt_gives_identical_gradients(whitened, kernel_grads):
         assert torch.equal(x, y)
     with pytest.raises(ValueError):
         ops.svgp_backward(*args, gm, gs, out["scale"], chunk=1024, wt_cache=out["wt_cache"], **extra)
+
+
+@pytest.mark.parametrize("name", ["wsvgp_nsf_rbf_f64", "svgp_nsf_rbf_f64", "mggp_svgp_mggp_nsf_rbf_f64", "svgp_rbf_f64"])
+def test_fused_kl_equals_torch_kl_in_value_and_gradients(name):
+    """The KL carried by the returned q(U) (whitened: read by the training loops; un-whitened: what
+    kl_divergence(qU, pU) resolves to) against torch's own formulas on the same distributions, value and
+    gradients w.r.t. every parameter; and a q(U) paired with a p(U) of another call falls back to torch."""
+    from torch import distributions
+    from gpzoo.utilities import whitened_KL_batched
+    c = load_case(name)
+    X = c["X"].cuda()
+    kw = {"groupsX": c["gX"].cuda()} if "gX" in c else {}
+    grads, vals = [], []
+    for fused in (True, False):
+        model = build(name, c)
+        gp = model.gp
+        pY, qF, qU, pU = model(X=X, E=1, **kw)
+        if c["whitened"]:
+            kl = qU._gpz_kl if fused else whitened_KL_batched(qU.mean, qU.scale_tril)
+        else:
+            kl = distributions.kl_divergence(qU, pU) if fused else \
+                distributions.kl._kl_multivariatenormal_multivariatenormal(qU, pU)
+        w = torch.linspace(0.5, 1.5, kl.numel(), dtype=kl.dtype, device=kl.device).reshape(kl.shape)
+        ((w * kl).sum() + 0.3 * qF.mean.sum() + 0.1 * qF.scale.sum()).backward()
+        vals.append(kl.detach().cpu())
+        grads.append({n: p.grad.detach().cpu().clone() for n, p in gp.named_parameters() if p.grad is not None})
+    torch.testing.assert_close(vals[0], vals[1], rtol=1e-9, atol=1e-12)
+    assert set(grads[0]) == set(grads[1]) and len(grads[0]) >= 5
+    for n in grads[0]:
+        ref = grads[1][n]
+        torch.testing.assert_close(grads[0][n], ref, rtol=1e-7, atol=1e-9 * float(ref.abs().max() + 1e-30), msg=lambda m: f"{n}: {m}")
+    if not c["whitened"]:
+        m1, m2 = build(name, c), build(name, c)
+        _, _, qU1, _ = m1(X=X, E=1, **kw)
+        _, _, _, pU2 = m2(X=X, E=1, **kw)
+        mixed = distributions.kl_divergence(qU1, pU2)
+        torch.testing.assert_close(mixed.detach().cpu(), vals[1], rtol=1e-9, atol=1e-12)
+        assert mixed.grad_fn is not qU1._gpz_kl.grad_fn

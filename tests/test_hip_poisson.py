@@ -114,7 +114,7 @@ def test_fused_matches_torch_formula_at_scale():
     rate = lv[3] * torch.matmul(lv[2], torch.exp(F))
     ref = torch.distributions.Poisson(rate).log_prob(y.double()).mean(0).sum()
     ref.backward()
-    assert float(ll) == pytest.approx(float(ref), rel=2e-5)
+    assert float(ll.detach()) == pytest.approx(float(ref), rel=2e-5)
     for got, want in zip((dmean, dscale, dW, dV), lv):
         close(got.double(), want.grad, rt=5e-4)
 
