@@ -283,8 +283,9 @@ class VNNGP(nn.Module):
             Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
             Lu = Lu.reshape(-1, Lu.shape[-2], Lu.shape[-1])
         qF = distributions.Normal(pick(mean), pick(scale))
-        qU = distributions.MultivariateNormal(self.mu, scale_tril=pick(Lu))
-        pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(chol))
+        # valid by construction: skip the O(L M^2) scale_tril validation
+        qU = distributions.MultivariateNormal(self.mu, scale_tril=pick(Lu), validate_args=False)
+        pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(chol), validate_args=False)
         return qF, qU, pU
 
 
