@@ -1,0 +1,32 @@
+#!/bin/bash
+# Every secondary number quoted in DESIGN.md / README.md, in one run on the GPU box:
+#   bash tools/bench_suite.sh > gpurun_out/bench_suite.txt 2>&1   (then copied to profiles/<round>/)
+set -e
+one() { python3 - "$1" <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+k = r["kernels"]
+print("  value %.4f %s | %.2f ms/step | stage1 %.1f TF (frac %.3f) | stage2 %.1f TF | kfill %.0f GB/s | potrf %.2f ms (trailing %.1f TF) | trtri %.2f ms%s" % (
+    r["value"], r["unit"], r["ms_per_step"], r["roofline"]["achieved"], r["roofline"]["frac"], k["stage2_LuT_Wt"]["achieved_TFLOPs"],
+    k["kuf_fill"]["achieved_GBps"], k["potrf_ms_per_eval"], k["potrf_trailing"]["achieved_TFLOPs"], k["trtri_ms_per_eval"],
+    (" | fwd+bwd %s ms" % {a: round(b, 1) for a, b in r["forward_backward_ms"].items()}) if "forward_backward_ms" in r else ""))
+PY
+}
+echo "== config 3 (default): N=200k M=2048 L=32 Matern-3/2 fp32, with forward+backward"
+python3 bench.py --no-cpu-baseline --with-backward > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== config 2: N=50k M=512 L=8 RBF fp32"
+python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== config 5: MGGP 4 groups, N=200k M=2048 fp64, L=32 on one GPU"
+python3 bench.py --config 5 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== config 5 as sharded over 8 GPUs: 4 latents per GPU"
+python3 bench.py --config 5 --L 4 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== config 4 on one GPU: L=256"
+python3 bench.py --L 256 --steps 1 --warmup 1 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== minibatch training step (N_b=7000, M=3000, L=20, fp32): tools/minibatch_step.py"
+python3 tools/minibatch_step.py 2>/dev/null | grep step
+echo "== Poisson NSF minibatch step: tools/poisson_step.py"
+python3 tools/poisson_step.py 2>/dev/null | tail -4
+echo "== VNNGP: tools/vnngp_step.py"
+python3 tools/vnngp_step.py 2>/dev/null | grep VNNGP
+echo "== batched Cholesky alone, L=32 M=2048 fp64: tools/potrf_only.py"
+python3 tools/potrf_only.py 32 2048 2>/dev/null | tail -2
