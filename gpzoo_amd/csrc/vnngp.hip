@@ -281,12 +281,12 @@ __global__ void vnn_chol_out_kernel(const double* __restrict__ Lc, int64_t Mp, i
 struct VnnPlan {
   int64_t L, N, M, Mp; int K; size_t bytes;
   double *Kzz, *Kfac, *Dinv, *LuD, *S, *scratch; int64_t* idx;
-  // backward only
-  double *gmu, *gS, *gK, *kacc, *G, *Linv, *Tmp, *D1, *D2; void* PS;
+  double *Linv, *Tmp, *LuE, *muE;                       // KL(qU || pU): L^{-1}, L^{-1} Lu, L^{-1} mu
+  double *gmu, *gS, *gK, *kacc, *G, *D1, *D2; void* PS;  // backward only
 };
 
-static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws, int bwd = 0, bool kernel_grads = false,
-                        bool with_chol = false) {
+// M is a few thousand at most on this path: every mode carves the same (generous) set of M x M buffers
+static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws, int bwd = 0) {
   VnnPlan pl;
   pl.L = p->k.n_latent; pl.N = p->N; pl.M = p->M; pl.Mp = pad_up(p->M); pl.K = K;
   const int64_t mm = pl.L * pl.Mp * pl.Mp;
@@ -298,23 +298,21 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
   pl.S = c.take<double>(mm);
   pl.scratch = c.take<double>((int64_t)(K * K + (bwd ? 4 : 2) * K) * pl.L * pl.N);
   pl.idx = own_idx ? c.take<int64_t>(pl.N * K) : nullptr;
-  pl.gmu = pl.gS = pl.gK = pl.kacc = pl.G = pl.Linv = pl.Tmp = pl.D1 = pl.D2 = nullptr;
+  pl.Linv = c.take<double>(mm);
+  pl.Tmp = c.take<double>(mm / 2 + 64);
+  pl.LuE = c.take<double>(mm);
+  pl.muE = c.take<double>(pl.L * pl.Mp);
+  pl.gmu = pl.gS = pl.gK = pl.kacc = pl.G = pl.D1 = pl.D2 = nullptr;
   pl.PS = nullptr;
   if (bwd) {
     pl.gmu = c.take<double>(pl.L * pl.Mp);
     pl.gS = c.take<double>(mm);
     pl.G = c.take<double>(mm);
-    if (kernel_grads) {
-      pl.gK = c.take<double>(mm);
-      pl.kacc = c.take<double>(pl.L * pl.Mp * 8);
-      pl.PS = c.take<double>(mm);       // holds T; sized for fp64
-      if (with_chol) {
-        pl.Linv = c.take<double>(mm);
-        pl.Tmp = c.take<double>(mm / 2);
-        pl.D1 = c.take<double>(mm);
-        pl.D2 = c.take<double>(mm);
-      }
-    }
+    pl.gK = c.take<double>(mm);
+    pl.kacc = c.take<double>(pl.L * pl.Mp * 8);
+    pl.PS = c.take<double>(mm);       // holds T; sized for fp64
+    pl.D1 = c.take<double>(mm);
+    pl.D2 = c.take<double>(mm);
   }
   pl.bytes = c.used();
   return pl;
@@ -368,6 +366,56 @@ static int vnn_prepare(const gpz_svgp_problem* p, VnnPlan& pl, const int64_t* id
   return 0;
 }
 
+// muE = Linv mu (fp64) and, per latent, the un-whitened KL(qU || pU) of utilities.py:481 /
+// torch kl.py:442:  sum log diag L - sum log diag Lu + (|Linv Lu|_F^2 + |Linv mu|^2 - M) / 2.  One block per latent.
+template <typename T>
+__global__ __launch_bounds__(256) void vnn_kl_kernel(const double* __restrict__ Lc, const double* __restrict__ Linv,
+                                                    const double* __restrict__ LuE, const T* __restrict__ raw,
+                                                    const T* __restrict__ mu, int64_t M, int64_t Mp,
+                                                    double* __restrict__ muE, double* __restrict__ kl) {
+  __shared__ double sh[256];
+  const int l = blockIdx.x, tid = threadIdx.x;
+  const double* Lb = Lc + (int64_t)l * Mp * Mp;
+  const double* Li = Linv + (int64_t)l * Mp * Mp;
+  const double* Le = LuE + (int64_t)l * Mp * Mp;
+  double acc = 0.0;
+  for (int64_t i = tid; i < Mp; i += 256) {
+    double me = 0.0;
+    if (i < M) {
+      for (int64_t k = 0; k <= i; ++k) me += Li[i * Mp + k] * (double)mu[(int64_t)l * M + k];
+      acc += 0.5 * me * me + log(Lb[i * Mp + i]) - (double)raw[(int64_t)l * M * M + i * M + i];
+    }
+    muE[(int64_t)l * Mp + i] = me;
+  }
+  for (int64_t e = tid; e < M * M; e += 256) {
+    const int64_t i = e / M, j = e - i * M;
+    if (j <= i) { const double v = Le[i * Mp + j]; acc += 0.5 * v * v; }
+  }
+  sh[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) sh[tid] += sh[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0 && kl) kl[l] = sh[0] - 0.5 * (double)M;
+}
+
+// Linv, LuE = Linv Lu (lower), muE and the per-latent KL (kl may be null: backward only needs the operands)
+template <typename T>
+static int vnn_kl_prepare(const gpz_svgp_problem* p, VnnPlan& pl, double* kl, hipStream_t s) {
+  const int64_t L = pl.L, Mp = pl.Mp, mm = Mp * Mp;
+  if (int rc = trtri_padded(pl.Kfac, Mp, mm, pl.Dinv, pl.Linv, Mp, L, pl.Tmp, s)) return rc;
+  GPZ_HIP_OK(hipMemsetAsync(pl.LuE, 0, sizeof(double) * L * mm, s));
+  GemmParams<double> g;
+  g.A = pl.Linv; g.lda = Mp; g.sA0 = mm; g.B = pl.LuD; g.ldb = Mp; g.sB0 = mm; g.C = pl.LuE; g.ldc = Mp; g.sC0 = mm;
+  g.nb0 = (int)L; g.mt = g.nt = (int)(Mp / 128); g.K = (int)Mp; g.flags = GF_A_LOWER | GF_B_LOWER | GF_TILES_LOWER;
+  if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
+  hipLaunchKernelGGL((vnn_kl_kernel<T>), dim3((unsigned)L), dim3(256), 0, s, pl.Kfac, pl.Linv, pl.LuE,
+                     static_cast<const T*>(p->Lu_raw), static_cast<const T*>(p->mu), pl.M, Mp, pl.muE, kl);
+  GPZ_LAUNCH_OK();
+  return 0;
+}
+
 template <typename T>
 static int vnngp_t(const gpz_svgp_problem* p, int K, const int64_t* idx_in, void* ws, size_t ws_bytes, hipStream_t s) {
   VnnPlan pl = vnn_plan(p, K, idx_in == nullptr, ws);
@@ -376,6 +424,8 @@ static int vnngp_t(const gpz_svgp_problem* p, int K, const int64_t* idx_in, void
   if (int rc = vnn_prepare<T>(p, pl, idx_in, a, s)) return rc;
   hipLaunchKernelGGL((vnngp_point_kernel<T>), dim3((unsigned)((pl.L * pl.N + 255) / 256)), dim3(256), 0, s, a);
   GPZ_LAUNCH_OK();
+  if (p->kl)
+    if (int rc = vnn_kl_prepare<T>(p, pl, p->kl, s)) return rc;
   return 0;
 }
 
@@ -390,14 +440,15 @@ __global__ void vnn_mu_out_kernel(const double* __restrict__ gmu, int64_t Mp, in
 // chain rule of Lu = tril(raw, -1) + diag(exp(diag raw)) applied to G = dLoss/dLu (fp64, padded)
 template <typename T>
 __global__ void vnn_lu_grad_kernel(const double* __restrict__ G, int64_t Mp, int64_t M, const T* __restrict__ raw,
-                                   T* __restrict__ out) {
+                                   T* __restrict__ out, const double* __restrict__ g_kl = nullptr) {
   const int l = blockIdx.z;
   const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= M) return;
   const double g = G[(int64_t)l * Mp * Mp + i * Mp + j];
   double v = 0.0;
   if (j < i) v = g;
-  else if (j == i) v = g * exp((double)raw[(int64_t)l * M * M + i * M + i]);
+  else if (j == i)   // Lu_ii = exp(raw_ii); the KL's -log Lu_ii contributes -g_kl to the raw diagonal
+    v = g * exp((double)raw[(int64_t)l * M * M + i * M + i]) - (g_kl ? g_kl[l] : 0.0);
   out[(int64_t)l * M * M + i * M + j] = (T)v;
 }
 
@@ -487,19 +538,65 @@ __global__ __launch_bounds__(256) void vnn_kgrad_finish_kernel(const double* __r
   }
 }
 
+// ---- KL(qU || pU) folded into the backward pass (g_kl = upstream dLoss/dkl_l) --------------------------------
+// G[l] += gk[l] * tril(T[l])                      (dKL/dLu = tril(Linv^T LuE); T = Linv^T LuE on the lower tiles)
+__global__ void vnn_kl_addG_kernel(double* __restrict__ G, const double* __restrict__ T, int64_t Mp,
+                                   const double* __restrict__ g_kl) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j > i || j >= Mp) return;
+  const int64_t o = (int64_t)l * Mp * Mp + i * Mp + j;
+  G[o] += g_kl[l] * T[o];
+}
+
+// gmu[l][a] += gk[l] * sum_{i >= a} Linv[l][i][a] * muE[l][i]        (dKL/dmu = Linv^T Linv mu)
+__global__ void vnn_kl_mu_kernel(double* __restrict__ gmu, const double* __restrict__ Linv,
+                                 const double* __restrict__ muE, int64_t Mp, int64_t M, const double* __restrict__ g_kl) {
+  const int l = blockIdx.y;
+  const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a >= M) return;
+  const double* Li = Linv + (int64_t)l * Mp * Mp;
+  double t = 0.0;
+  for (int64_t i = a; i < M; ++i) t += Li[i * Mp + a] * muE[(int64_t)l * Mp + i];
+  gmu[(int64_t)l * Mp + a] += g_kl[l] * t;
+}
+
+// Q[l][i][j] += muE[l][i] * muE[l][j]
+__global__ void vnn_rank1_kernel(double* __restrict__ Q, const double* __restrict__ muE, int64_t Mp) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  Q[(int64_t)l * Mp * Mp + i * Mp + j] += muE[(int64_t)l * Mp + i] * muE[(int64_t)l * Mp + j];
+}
+
+// Lbar[l] += gk[l] * (diag(1 / L_ii) - tril(E[l]))   (the factor's share: log-determinant and LuE / muE dependence)
+__global__ void vnn_kl_lbar_kernel(double* __restrict__ Lbar, const double* __restrict__ E, const double* __restrict__ Lc,
+                                   int64_t Mp, int64_t M, const double* __restrict__ g_kl) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j > i || i >= M) return;
+  const int64_t o = (int64_t)l * Mp * Mp + i * Mp + j;
+  double v = -E[o];
+  if (i == j) v += 1.0 / Lc[o];
+  Lbar[o] += g_kl[l] * v;
+}
+
 template <typename T>
 static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int K, const int64_t* idx_in, void* ws,
                             size_t ws_bytes, hipStream_t s) {
   const bool kgrads = g->grad_theta != nullptr || g->grad_Z != nullptr;
-  const bool with_chol = kgrads && g->g_chol != nullptr;
-  VnnPlan pl = vnn_plan(p, K, idx_in == nullptr, ws, 1, kgrads, with_chol);
+  const double* g_kl = g->g_kl;
+  const bool with_chol = kgrads && (g->g_chol != nullptr || g_kl != nullptr);
+  VnnPlan pl = vnn_plan(p, K, idx_in == nullptr, ws, 1);
   GPZ_REQUIRE(ws_bytes >= pl.bytes, "gpz_vnngp_backward: workspace too small");
   const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, mm = Mp * Mp;
   const int L32 = (int)L;
   gpz_svgp_problem q = *p;           // forward-only outputs are not produced again
-  q.chol = nullptr; q.Lu = nullptr;
+  q.chol = nullptr; q.Lu = nullptr; q.kl = nullptr;
   VnnBwdArgs<T> b;
   if (int rc = vnn_prepare<T>(&q, pl, idx_in, b.f, s)) return rc;
+  if (g_kl || with_chol)             // Linv (and, for the KL, LuE = Linv Lu and muE = Linv mu)
+    if (int rc = vnn_kl_prepare<T>(p, pl, nullptr, s)) return rc;
   GPZ_HIP_OK(hipMemsetAsync(pl.gmu, 0, sizeof(double) * L * Mp, s));
   GPZ_HIP_OK(hipMemsetAsync(pl.gS, 0, sizeof(double) * L * mm, s));
   if (kgrads) {
@@ -507,7 +604,7 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
     GPZ_HIP_OK(hipMemsetAsync(pl.kacc, 0, sizeof(double) * L * Mp * 8, s));
   }
   b.g_mean = static_cast<const T*>(g->g_mean); b.g_scale = static_cast<const T*>(g->g_scale);
-  b.gmu = pl.gmu; b.gS = pl.gS; b.gK = pl.gK; b.kacc = pl.kacc;
+  b.gmu = pl.gmu; b.gS = pl.gS; b.gK = kgrads ? pl.gK : nullptr; b.kacc = kgrads ? pl.kacc : nullptr;
   hipLaunchKernelGGL((vnngp_point_bwd_kernel<T>), dim3((unsigned)((L * pl.N + 255) / 256)), dim3(256), 0, s, b);
   GPZ_LAUNCH_OK();
   const dim3 g32((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32);
@@ -518,22 +615,48 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
     d.nb0 = L32; d.mt = d.nt = (int)(Mp / 128); d.K = (int)Mp; d.flags = flags; d.alpha = alpha;
     return gemm_launch(d, EPI_STORE, s);
   };
-  hipLaunchKernelGGL((vnn_mu_out_kernel<T>), dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, pl.gmu, Mp, M,
-                     static_cast<T*>(g->grad_mu));
-  GPZ_LAUNCH_OK();
   // S = Lu Lu^T, dS symmetric: dLoss/dLu = tril(2 dS Lu)
   GPZ_HIP_OK(hipMemsetAsync(pl.G, 0, sizeof(double) * L * mm, s));
   if (int rc = dgemm(pl.gS, pl.LuD, pl.G, GF_B_LOWER | GF_TILES_LOWER, 2.0)) return rc;
+  double* const LinvT = pl.S;        // the point kernels are done with S and Kzz: scratch from here on
+  double* const Tm = pl.Kzz;
+  if (g_kl) {
+    hipLaunchKernelGGL(vnn_tril_transpose_kernel, g32, dim3(256), 0, s, pl.Linv, Mp, LinvT);
+    GPZ_LAUNCH_OK();
+    GPZ_HIP_OK(hipMemsetAsync(Tm, 0, sizeof(double) * L * mm, s));
+    if (int rc = dgemm(LinvT, pl.LuE, Tm, GF_A_UPPER | GF_B_LOWER | GF_TILES_LOWER, 1.0)) return rc;   // Linv^T LuE
+    hipLaunchKernelGGL(vnn_kl_addG_kernel, gm, dim3(256), 0, s, pl.G, Tm, Mp, g_kl);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL(vnn_kl_mu_kernel, dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, pl.gmu, pl.Linv, pl.muE,
+                       Mp, M, g_kl);
+    GPZ_LAUNCH_OK();
+  }
+  hipLaunchKernelGGL((vnn_mu_out_kernel<T>), dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, pl.gmu, Mp, M,
+                     static_cast<T*>(g->grad_mu));
+  GPZ_LAUNCH_OK();
   hipLaunchKernelGGL((vnn_lu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)M, L32), dim3(256), 0, s, pl.G,
-                     Mp, M, static_cast<const T*>(p->Lu_raw), static_cast<T*>(g->grad_Lu_raw));
+                     Mp, M, static_cast<const T*>(p->Lu_raw), static_cast<T*>(g->grad_Lu_raw), g_kl);
   GPZ_LAUNCH_OK();
   if (!kgrads) return 0;
   const double* P = nullptr;
   if (with_chol) {
-    // Cholesky backward (Murray 2016) of the upstream dLoss/dchol: P = Linv^T Phi(L^T Lbar) Linv
-    if (int rc = trtri_padded(pl.Kfac, Mp, mm, pl.Dinv, pl.Linv, Mp, L, pl.Tmp, s)) return rc;
-    hipLaunchKernelGGL((vnn_tril_in_kernel<T>), gm, dim3(256), 0, s, static_cast<const T*>(g->g_chol), M, Mp, pl.D1);
-    GPZ_LAUNCH_OK();                                                                          // D1 = Lbar
+    // upstream dLoss/dchol (+ the KL's own dependence on the factor) -> Lbar
+    if (g->g_chol) {
+      hipLaunchKernelGGL((vnn_tril_in_kernel<T>), gm, dim3(256), 0, s, static_cast<const T*>(g->g_chol), M, Mp, pl.D1);
+      GPZ_LAUNCH_OK();
+    } else {
+      GPZ_HIP_OK(hipMemsetAsync(pl.D1, 0, sizeof(double) * L * mm, s));
+    }
+    if (g_kl) {
+      double* const Q = pl.gS;       // free since G was formed
+      if (int rc = dgemm(pl.LuE, pl.LuE, Q, GF_A_LOWER | GF_B_UPPER | GF_B_TRANS, 1.0)) return rc;      // LuE LuE^T
+      hipLaunchKernelGGL(vnn_rank1_kernel, gm, dim3(256), 0, s, Q, pl.muE, Mp);
+      GPZ_LAUNCH_OK();
+      if (int rc = dgemm(LinvT, Q, Tm, GF_A_UPPER, 1.0)) return rc;                                    // E = Linv^T Q
+      hipLaunchKernelGGL(vnn_kl_lbar_kernel, gm, dim3(256), 0, s, pl.D1, Tm, pl.Kfac, Mp, M, g_kl);
+      GPZ_LAUNCH_OK();
+    }
+    // Cholesky backward (Murray 2016): P = Linv^T Phi(L^T Lbar) Linv
     hipLaunchKernelGGL(vnn_tril_transpose_kernel, g32, dim3(256), 0, s, pl.Kfac, Mp, pl.G);   // G  = L^T
     GPZ_LAUNCH_OK();
     if (int rc = dgemm(pl.G, pl.D1, pl.D2, GF_A_UPPER | GF_B_LOWER, 1.0)) return rc;          // D2 = L^T Lbar
@@ -597,7 +720,7 @@ extern "C" int gpz_vnngp_forward(const gpz_svgp_problem* p, int32_t K, const int
 
 extern "C" size_t gpz_vnngp_backward_workspace_bytes(const gpz_svgp_problem* p, int32_t K) {
   if (vnn_check(p, K)) return 0;
-  return vnn_plan(p, K, true, nullptr, 1, true, true).bytes;
+  return vnn_plan(p, K, true, nullptr, 1).bytes;
 }
 
 extern "C" int gpz_vnngp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int32_t K, const int64_t* idx,

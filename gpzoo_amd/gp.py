@@ -218,7 +218,7 @@ class _FusedGP(nn.Module):
 
 
 class _VNNMoments(torch.autograd.Function):
-    """(mean, scale, chol) of VNNGP as a differentiable function of mu, the raw Lu, Z, sigma and
+    """(mean, scale, chol, kl) of VNNGP as a differentiable function of mu, the raw Lu, Z, sigma and
     lengthscale: forward = gpz_vnngp_forward, backward = gpz_vnngp_backward.  The neighbour table is a
     constant of the graph, exactly as argsort is in the reference's."""
 
@@ -227,13 +227,13 @@ class _VNNMoments(torch.autograd.Function):
         out = call["forward"](mu, Lu_raw)
         ctx.call, ctx.idx = call, out["idx"]
         ctx.save_for_backward(mu, Lu_raw, Z, sigma, lengthscale)
-        return out["mean"], out["scale"], out["chol"]
+        return out["mean"], out["scale"], out["chol"], out["kl"].to(out["mean"].dtype)
 
     @staticmethod
-    def backward(ctx, g_mean, g_scale, g_chol):
+    def backward(ctx, g_mean, g_scale, g_chol, g_kl):
         mu, Lu_raw, Z, sigma, lengthscale = ctx.saved_tensors
         need_kernel = any(ctx.needs_input_grad[2:5])
-        res = ctx.call["backward"](mu, Lu_raw, ctx.idx, g_mean, g_scale, need_kernel, g_chol if need_kernel else None)
+        res = ctx.call["backward"](mu, Lu_raw, ctx.idx, g_mean, g_scale, need_kernel, g_chol if need_kernel else None, g_kl)
         grads = [res[0].reshape(mu.shape), res[1].reshape(Lu_raw.shape), None, None, None, None]
         if need_kernel:
             grads[2] = res[3].to(Z.dtype)
@@ -246,7 +246,8 @@ class VNNGP(nn.Module):
     """Nearest-neighbour variational GP; reference gp.py:7-122 (RBF-family kernels: the ones with
     ``return_distance``).  The reference's scalar-``RBF`` path raises (gp.py:83 repeats the neighbour
     table N times instead of L); here a scalar kernel returns ``(N,)`` moments.  Differentiable w.r.t.
-    ``mu``, ``Lu``, ``Z``, ``sigma`` and ``lengthscale``."""
+    ``mu``, ``Lu``, ``Z``, ``sigma`` and ``lengthscale``; ``kl_divergence(qU, pU)`` on the returned pair
+    resolves to the KL the fused pass evaluated (see ``_kl_fused``)."""
     _clamp_min = 5e-2
 
     def __init__(self, kernel, dim=1, M=50, K=3, jitter=1e-4):
@@ -267,25 +268,25 @@ class VNNGP(nn.Module):
         params = (self.mu, self.Lu, self.Z, self.kernel.sigma, self.kernel.lengthscale)
         if not (torch.is_grad_enabled() and any(t.requires_grad for t in params)):
             out = ops.vnngp_forward(spec, X, self.Z, self.mu, self.Lu, jitter, K, self._clamp_min)
-            mean, scale, Lu, chol = out["mean"], out["scale"], out["Lu"], out["chol"]
+            mean, scale, Lu, chol, kl = out["mean"], out["scale"], out["Lu"], out["chol"], out["kl"].to(out["mean"].dtype)
         else:
             def fwd(mu, Lu_raw):
                 return ops.vnngp_forward(spec, X, self.Z, mu, Lu_raw, jitter, K, self._clamp_min)
 
-            def bwd(mu, Lu_raw, idx, g_mean, g_scale, need_kernel, g_chol):
-                z = torch.zeros((nlat, X.shape[0]), dtype=X.dtype, device=X.device)
-                return ops.vnngp_backward(spec, X, self.Z, mu, Lu_raw, jitter, K, idx, z if g_mean is None else g_mean,
-                                          z if g_scale is None else g_scale, clamp_min=self._clamp_min,
-                                          kernel_grads=need_kernel, g_chol=g_chol)
+            def bwd(mu, Lu_raw, idx, g_mean, g_scale, need_kernel, g_chol, g_kl):
+                return ops.vnngp_backward(spec, X, self.Z, mu, Lu_raw, jitter, K, idx, g_mean, g_scale,
+                                          clamp_min=self._clamp_min, kernel_grads=need_kernel, g_chol=g_chol, g_kl=g_kl)
 
-            mean, scale, chol = _VNNMoments.apply(*params, dict(forward=fwd, backward=bwd))
-            # q(U)'s scale_tril through torch so that KL terms differentiate w.r.t. the raw parameter
+            mean, scale, chol, kl = _VNNMoments.apply(*params, dict(forward=fwd, backward=bwd))
+            # q(U)'s scale_tril through torch so that other uses of it differentiate w.r.t. the raw parameter
             Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
             Lu = Lu.reshape(-1, Lu.shape[-2], Lu.shape[-1])
         qF = distributions.Normal(pick(mean), pick(scale))
         # valid by construction: skip the O(L M^2) scale_tril validation
-        qU = distributions.MultivariateNormal(self.mu, scale_tril=pick(Lu), validate_args=False)
-        pU = distributions.MultivariateNormal(torch.zeros_like(self.mu), scale_tril=pick(chol), validate_args=False)
+        qU = _FusedQU(self.mu, scale_tril=pick(Lu), validate_args=False)
+        pU = _FusedPU(torch.zeros_like(self.mu), scale_tril=pick(chol), validate_args=False)
+        qU._gpz_kl = pick(kl)
+        qU._gpz_pair = pU._gpz_pair = pU
         return qF, qU, pU
 
 

@@ -376,6 +376,8 @@ def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, cla
     info = torch.empty(L, dtype=torch.int32, device=dev)
     p.mean, p.scale, p.Lu, p.chol = (out[k].data_ptr() for k in ("mean", "scale", "Lu", "chol"))
     p.info = info.data_ptr()
+    out["kl"] = torch.empty(L, dtype=torch.float64, device=dev)      # KL(qU || pU) per latent
+    p.kl = out["kl"].data_ptr()
     out["idx"] = knn(X, Z, K) if idx is None else idx
     nbytes = lib.gpz_vnngp_workspace_bytes(C.byref(p), K)
     if nbytes == 0:
@@ -389,7 +391,7 @@ def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, cla
 
 
 def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, idx, g_mean, g_scale, *,
-                   clamp_min: float = 5e-2, kernel_grads: bool = False, g_chol=None):
+                   clamp_min: float = 5e-2, kernel_grads: bool = False, g_chol=None, g_kl=None):
     """dLoss/dmu (L,M), dLoss/dLu_raw (L,M,M) of VNNGP (gpz_vnngp_backward); with ``kernel_grads`` also
     dLoss/d(sigma, lengthscale) (L,2) and dLoss/dZ (M,d), both fp64."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale, idx)
@@ -413,6 +415,10 @@ def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, id
         gth = torch.zeros((L, 4), dtype=torch.float64, device=dev)
         gz = torch.zeros((M, 4), dtype=torch.float64, device=dev)
         g.grad_theta, g.grad_Z = gth.data_ptr(), gz.data_ptr()
+    if g_kl is not None:
+        gk = g_kl.detach().to(device=dev, dtype=torch.float64).reshape(-1).expand(L).contiguous()
+        keep.append(gk)
+        g.g_kl = gk.data_ptr()
     idx = idx.contiguous()
     nbytes = lib.gpz_vnngp_backward_workspace_bytes(C.byref(p), K)
     if nbytes == 0:

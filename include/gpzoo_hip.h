@@ -209,7 +209,8 @@ int gpz_vnngp_forward(const gpz_svgp_problem* p, int32_t K, const int64_t* idx, 
  * hyper-parameters, dLoss/dchol from KL(qU || pU)) writes grad_mu, grad_Lu_raw and, when
  * grad_theta / grad_Z are non-NULL, the gradients w.r.t. (sigma, lengthscale) per latent and Z.
  * The neighbour table is a constant of the graph (argsort has no gradient).  `scale` of
- * gpz_svgp_grads is unused (the variance is recomputed).  The K-sparse terms are accumulated with
+ * gpz_svgp_grads is unused (the variance is recomputed); `g_kl` folds the gradient of the forward's
+ * per-latent KL(qU || pU) (problem field `kl`) in, as in gpz_svgp_backward.  The K-sparse terms are accumulated with
  * fp64 atomics: results are reproducible to rounding, not bitwise. */
 size_t gpz_vnngp_backward_workspace_bytes(const gpz_svgp_problem* p, int32_t K);
 int gpz_vnngp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int32_t K,

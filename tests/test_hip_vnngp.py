@@ -155,5 +155,30 @@ def test_vnngp_trains():
                  - distributions.kl_divergence(qU, pU).sum())
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("name", ["vnngp_nsf_rbf_L3_f64", "vnngp_nsf_rbf_L2_f64"])
+def test_fused_kl_equals_torch_kl_in_value_and_gradients(name):
+    """kl_divergence(qU, pU) on the module's distributions (the fused pass's KL, its gradient folded into
+    gpz_vnngp_backward) against torch's MVN-MVN formula on the same distributions: value and the gradients
+    w.r.t. mu, Lu, Z, sigma, lengthscale with a per-latent weighting."""
+    from torch import distributions
+    c = load(name)
+    X = c["X"].cuda()
+    vals, grads = [], []
+    for fused in (True, False):
+        gp, k = _module(c)
+        qF, qU, pU = gp(X)
+        kl = distributions.kl_divergence(qU, pU) if fused else \
+            distributions.kl._kl_multivariatenormal_multivariatenormal(qU, pU)
+        w = torch.linspace(0.5, 1.5, kl.numel(), dtype=kl.dtype, device=kl.device).reshape(kl.shape)
+        ((w * kl).sum() + 0.3 * qF.mean.sum() + 0.1 * qF.scale.sum()).backward()
+        vals.append(kl.detach().cpu())
+        grads.append({n: p.grad.detach().cpu().clone() for n, p in gp.named_parameters() if p.grad is not None})
+    torch.testing.assert_close(vals[0], vals[1], rtol=1e-9, atol=1e-12)
+    assert set(grads[0]) == set(grads[1]) == {"Z", "Lu", "mu", "kernel.sigma", "kernel.lengthscale"}
+    for n in grads[0]:
+        ref = grads[1][n]
+        torch.testing.assert_close(grads[0][n], ref, rtol=1e-7, atol=1e-9 * float(ref.abs().max() + 1e-30), msg=lambda m: f"{n}: {m}")
