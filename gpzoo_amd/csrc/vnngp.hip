@@ -180,8 +180,8 @@ struct VnnBwdArgs {
   VnnArgs<T> f;                 // scratch holds (K*K + 4K) columns here
   const T* g_mean; const T* g_scale;
   double* gmu;                  // (L,Mp)
-  double* gS;                   // (L,Mp,Mp)  dLoss/dS, symmetric
-  double* gK;                   // (L,Mp,Mp)  dLoss/d(Kzz + jitter I) from the K x K blocks, or null
+  double* gS;                   // (L,Mp,Mp)  T with dLoss/dS = T + T^T
+  double* gK;                   // (L,Mp,Mp)  T with T + T^T = 2 sym(dLoss/d(Kzz + jitter I)) from the K x K blocks, or null
   double* kacc;                 // (L,Mp,8)   dz0..3, dsigma, dlengthscale (kgrad.hip layout), or null
 };
 
@@ -227,10 +227,12 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_kernel(VnnBwdArgs<T> b) {
     const int64_t ip = id[p];
     const double wp = w[p * total], vp = v[p * total];
     if (gm != 0.0) unsafeAtomicAdd(gmu + ip, gm * wp);
-    for (int q = 0; q < K; ++q) {
+    // both accumulators are only ever used symmetrised (T + T^T): one atomic per unordered pair, the
+    // diagonal at half weight for dS
+    for (int q = 0; q <= p; ++q) {
       const double wq = w[q * total];
-      if (gcov != 0.0) unsafeAtomicAdd(gS + ip * a.Mp + id[q], gcov * wp * wq);
-      if (gK) unsafeAtomicAdd(gK + ip * a.Mp + id[q], -vp * wq);
+      if (gcov != 0.0) unsafeAtomicAdd(gS + ip * a.Mp + id[q], (p == q ? 0.5 : 1.0) * gcov * wp * wq);
+      if (gK) unsafeAtomicAdd(gK + ip * a.Mp + id[q], p == q ? -vp * wq : -(vp * wq + v[q * total] * wp));
     }
     if (b.kacc) {
       const double kv = kx[p * total], gk = (vp - gcov * wp) * kv;   // dLoss/dk_p * k_p
@@ -615,9 +617,11 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
     d.nb0 = L32; d.mt = d.nt = (int)(Mp / 128); d.K = (int)Mp; d.flags = flags; d.alpha = alpha;
     return gemm_launch(d, EPI_STORE, s);
   };
-  // S = Lu Lu^T, dS symmetric: dLoss/dLu = tril(2 dS Lu)
+  // S = Lu Lu^T, dS = T + T^T symmetric: dLoss/dLu = tril(2 dS Lu)
+  hipLaunchKernelGGL((vnn_sym_cast_kernel<double>), g32, dim3(256), 0, s, pl.gS, (const double*)nullptr, Mp, pl.D1);
+  GPZ_LAUNCH_OK();
   GPZ_HIP_OK(hipMemsetAsync(pl.G, 0, sizeof(double) * L * mm, s));
-  if (int rc = dgemm(pl.gS, pl.LuD, pl.G, GF_B_LOWER | GF_TILES_LOWER, 2.0)) return rc;
+  if (int rc = dgemm(pl.D1, pl.LuD, pl.G, GF_B_LOWER | GF_TILES_LOWER, 2.0)) return rc;
   double* const LinvT = pl.S;        // the point kernels are done with S and Kzz: scratch from here on
   double* const Tm = pl.Kzz;
   if (g_kl) {
