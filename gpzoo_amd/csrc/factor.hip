@@ -34,7 +34,7 @@ __global__ void diag128_kernel(double* __restrict__ A, int64_t lda, int64_t stri
 
 // Copies the inverted diagonal blocks into the diagonal of Linv (rest zeroed by memset).
 __global__ void scatter_diag_kernel(const double* __restrict__ Dinv, int64_t dinv_stride, double* __restrict__ Linv,
-                                    int64_t ld, int64_t stride, int nblk) {
+                                    int64_t ld, int64_t stride) {
   const int b = blockIdx.y, k = blockIdx.x;
   const double* src = Dinv + (int64_t)b * dinv_stride + (int64_t)k * NB * NB;
   double* dst = Linv + (int64_t)b * stride + (int64_t)k * NB * (ld + 1);
@@ -119,8 +119,7 @@ int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* 
   const int64_t stride = Mp * Mp;
   prof_begin(PROF_TRTRI, s);
   GPZ_HIP_OK(hipMemsetAsync(Linv, 0, sizeof(double) * stride * batch, s));
-  hipLaunchKernelGGL(scatter_diag_kernel, dim3(nblk, (unsigned)batch), dim3(256), 0, s, Dinv, dstride, Linv, Mp, stride,
-                     nblk);
+  hipLaunchKernelGGL(scatter_diag_kernel, dim3(nblk, (unsigned)batch), dim3(256), 0, s, Dinv, dstride, Linv, Mp, stride);
   GPZ_LAUNCH_OK();
   // segments: boundaries of the already-inverted diagonal blocks, in units of NB
   std::vector<int> seg(nblk + 1);

@@ -106,7 +106,7 @@ struct VnnArgs {
 // Per-point forward state left in the thread's scratch columns: A = Cholesky factor of the jittered
 // K x K block (lower), kx = k(x, z_idx), w = A^{-1} kx, sw = S_block w.  Returns mean and the unclamped cov.
 template <typename T>
-__device__ __forceinline__ void vnn_point_solve(const VnnArgs<T>& a, int64_t t, int64_t total, int l, int64_t n,
+__device__ __forceinline__ void vnn_point_solve(const VnnArgs<T>& a, int64_t total, int l, int64_t n,
                                                 const int64_t* id, double* A, double* kx, double* w, double* sw,
                                                 double& mean, double& cov) {
   const int K = a.K;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void vnngp_point_kernel(VnnArgs<T> a) {
   double* kx = a.scratch + (int64_t)K * K * total + t;     // kx[p] at kx[p * total]
   double* w = kx + (int64_t)K * total;
   double mean, cov;
-  vnn_point_solve<T>(a, t, total, l, n, a.idx + n * K, A, kx, w, nullptr, mean, cov);
+  vnn_point_solve<T>(a, total, l, n, a.idx + n * K, A, kx, w, nullptr, mean, cov);
   if (!(cov > a.clamp_min)) cov = a.clamp_min;
   a.mean[t] = (T)mean;
   a.scale[t] = (T)sqrt(cov);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_kernel(VnnBwdArgs<T> b) {
   double* sw = w + (int64_t)K * total;
   double* v = sw + (int64_t)K * total;
   double mean, cov;
-  vnn_point_solve<T>(a, t, total, l, n, id, A, kx, w, sw, mean, cov);
+  vnn_point_solve<T>(a, total, l, n, id, A, kx, w, sw, mean, cov);
   const double gm = (double)b.g_mean[t];
   // scale = sqrt(clamp(cov, min)): no gradient through a clamped variance (gp.py:117)
   const double gcov = (cov > a.clamp_min) ? 0.5 * (double)b.g_scale[t] / sqrt(cov) : 0.0;
