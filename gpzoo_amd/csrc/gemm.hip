@@ -154,30 +154,37 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
                : Bg + (int64_t)(k_begin + rb_row + BROWS * h) * p.ldb + rb_vc;
   }
   const int64_t b_step = BT ? (int64_t)BK : (int64_t)BK * p.ldb;
-  vec_t ga[RP], gb[RP];
-  auto gload = [&]() {
+  // Global -> register -> LDS staging, PFD tiles ahead (tile i lives in register set i % PFD).  Two tiles ahead
+  // (fp32 has the registers for it) measured the same as one: the prefetch distance is not what the MFMA pipes
+  // wait for.  Kept at one.
+  constexpr int PFD = 1;
+  vec_t ga[PFD][RP], gb[PFD][RP];
+  auto gload_set = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int h = 0; h < RP; ++h) {
-      ga[h] = *reinterpret_cast<const vec_t*>(pa[h]);
-      gb[h] = *reinterpret_cast<const vec_t*>(pb[h]);
+      ga[S][h] = *reinterpret_cast<const vec_t*>(pa[h]);
+      gb[S][h] = *reinterpret_cast<const vec_t*>(pb[h]);
       pa[h] += BK;
       pb[h] += b_step;
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore_set = [&](int buf, auto set_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int h = 0; h < RP; ++h)
-      *reinterpret_cast<vec_t*>(sA(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = ga[h];
+      *reinterpret_cast<vec_t*>(sA(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = ga[S][h];
     if (BT) {
 #pragma unroll
       for (int h = 0; h < RP; ++h)
-        *reinterpret_cast<vec_t*>(sB(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = gb[h];
+        *reinterpret_cast<vec_t*>(sB(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = gb[S][h];
     } else {
 #pragma unroll
       for (int h = 0; h < RP; ++h)
-        *reinterpret_cast<vec_t*>(sB(buf) + (rb_row + BROWS * h) * LDN + rb_vc) = gb[h];
+        *reinterpret_cast<vec_t*>(sB(buf) + (rb_row + BROWS * h) * LDN + rb_vc) = gb[S][h];
     }
   };
+  using std::integral_constant;
 
   acc_t acc[4][NI];
 #pragma unroll
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
 
   // One staged tile of MFMAs over the 16-row sub-tiles MI_LO..MI_HI of this wave (compile-time range).
   // In each 64-byte k-chunk lane (r, q) owns k = VEC*q + j, j < VEC.
-  auto compute = [&](int buf, auto lo_c, auto hi_c) {
+  auto compute = [&](int buf, auto lo_c, auto hi_c) __attribute__((always_inline)) {
     constexpr int MI_LO = decltype(lo_c)::value, MI_HI = decltype(hi_c)::value;
 #pragma unroll
     for (int kc = 0; kc < KV; ++kc) {
@@ -237,47 +244,54 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
   if ((p.flags & GF_A_LOWER) && k_end == (ti + 1) * 128 && k_begin <= ti * 128) { part_lo = true; n_post = wm_s == 0 ? PT : 0; }
   if ((p.flags & GF_A_UPPER) && k_begin == ti * 128 && k_end >= (ti + 1) * 128) { part_hi = true; n_pre = wm_s == 1 ? PT : 0; }
   if (nk > 0) {
-    gload();
-    sstore(0);
+    gload_set(integral_constant<int, 0>{});
+    sstore_set(0, integral_constant<int, 0>{});
+    if (PFD == 2 && nk > 1) gload_set(integral_constant<int, PFD - 1>{});
   }
   __syncthreads();
   int t = 0;
-  auto idle = [&]() {
-    if (t + 1 < nk) { gload(); sstore((t & 1) ^ 1); }
+  // Iteration t: fetch tile t + PFD, run tile t (when `run`), stage tile t + 1 into the other LDS buffer.
+  // Every region below starts at an even t and has an even length (k-ranges are multiples of 128 = 4 BK at
+  // most... PT tiles per 64 k), so the parity of t -- the LDS buffer and, with two register sets, which set
+  // is fetched and which is staged -- is a compile-time constant of each iteration: straight-line code, and
+  // the compiler can count exactly how many loads may still be in flight at each LDS store.
+  static_assert(PT % 2 == 0, "staged tiles come in pairs");
+  auto iteration = [&](auto par_c, auto run_c, auto lo_c, auto hi_c) __attribute__((always_inline)) {
+    constexpr int P = decltype(par_c)::value;                  // t & 1
+    constexpr int FS = PFD == 1 ? 0 : P, SS = PFD == 1 ? 0 : 1 - P;
+    if (t + PFD < nk) gload_set(integral_constant<int, FS>{});
+    if constexpr (decltype(run_c)::value) compute(P, lo_c, hi_c);
+    if (t + 1 < nk) sstore_set(P ^ 1, integral_constant<int, SS>{});
     __syncthreads();
     ++t;
   };
-  auto work = [&](auto lo_c, auto hi_c) {
-    const int buf = t & 1;
-    if (t + 1 < nk) gload();
-    compute(buf, lo_c, hi_c);
-    if (t + 1 < nk) sstore(buf ^ 1);
-    __syncthreads();
-    ++t;
-  };
+  using no_run = integral_constant<bool, false>;
+  using run = integral_constant<bool, true>;
+  using i0 = integral_constant<int, 0>;
+  using i1 = integral_constant<int, 1>;
+  using i3 = integral_constant<int, 3>;
   // tile u of the diagonal sub-block covers k in [u*BK, (u+1)*BK): it needs the 16-row sub-tiles
   // mi >= u*BK/16 when A is lower triangular, mi <= ((u+1)*BK-1)/16 when it is upper triangular
-  using std::integral_constant;
-  while (t < n_pre) idle();
+  for (int u = 0; u < n_pre; u += 2) { iteration(i0{}, no_run{}, i0{}, i3{}); iteration(i1{}, no_run{}, i0{}, i3{}); }
   if (part_hi) {
-    auto phases = [&](auto self, auto u_c) -> void {
+    auto phases = [&](auto self, auto u_c) __attribute__((always_inline)) -> void {
       constexpr int U = decltype(u_c)::value;
-      work(integral_constant<int, 0>{}, integral_constant<int, ((U + 1) * BK - 1) / 16>{});
+      iteration(integral_constant<int, U & 1>{}, run{}, i0{}, integral_constant<int, ((U + 1) * BK - 1) / 16>{});
       if constexpr (U + 1 < PT) self(self, integral_constant<int, U + 1>{});
     };
-    phases(phases, integral_constant<int, 0>{});
+    phases(phases, i0{});
   }
   const int t_main_end = nk - n_post - (part_lo ? PT : 0);
-  while (t < t_main_end) work(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+  while (t < t_main_end) { iteration(i0{}, run{}, i0{}, i3{}); iteration(i1{}, run{}, i0{}, i3{}); }
   if (part_lo) {
-    auto phases = [&](auto self, auto u_c) -> void {
+    auto phases = [&](auto self, auto u_c) __attribute__((always_inline)) -> void {
       constexpr int U = decltype(u_c)::value;
-      work(integral_constant<int, (U * BK) / 16>{}, integral_constant<int, 3>{});
+      iteration(integral_constant<int, U & 1>{}, run{}, integral_constant<int, (U * BK) / 16>{}, i3{});
       if constexpr (U + 1 < PT) self(self, integral_constant<int, U + 1>{});
     };
-    phases(phases, integral_constant<int, 0>{});
+    phases(phases, i0{});
   }
-  while (t < nk) idle();
+  while (t < nk) { iteration(i0{}, no_run{}, i0{}, i3{}); iteration(i1{}, no_run{}, i0{}, i3{}); }
 
   // ---------------- epilogue ----------------
   const int64_t crow0 = (int64_t)ti * 128 + wm * 64;
