@@ -156,7 +156,7 @@ class _FusedGP(nn.Module):
         pU = None
         if not self._whitened:
             pU = _FusedPU(torch.zeros_like(self.mu), scale_tril=pick(out["chol"]), validate_args=False)
-            qU._gpz_pair = pU._gpz_pair = pU
+            qU._gpz_pair = pU._gpz_pair = object()    # a token, not the distribution: no reference cycle
         return qF, qU, pU
 
     def _forward(self, X, groupsX=None, verbose=False):
@@ -206,7 +206,7 @@ class _FusedGP(nn.Module):
             return qF, qU, None
         # un-whitened: kl_divergence(qU, pU) resolves to the KL the fused pass already holds (_kl_fused)
         pU = _FusedPU(torch.zeros_like(self.mu), scale_tril=pick(chol), validate_args=False)
-        qU._gpz_pair = pU._gpz_pair = pU
+        qU._gpz_pair = pU._gpz_pair = object()    # a token, not the distribution: no reference cycle
         return qF, qU, pU
 
     def elbo(self, X, y, noise_sd, groupsX=None, chunk=0):
@@ -286,7 +286,7 @@ class VNNGP(nn.Module):
         qU = _FusedQU(self.mu, scale_tril=pick(Lu), validate_args=False)
         pU = _FusedPU(torch.zeros_like(self.mu), scale_tril=pick(chol), validate_args=False)
         qU._gpz_kl = pick(kl)
-        qU._gpz_pair = pU._gpz_pair = pU
+        qU._gpz_pair = pU._gpz_pair = object()    # a token, not the distribution: no reference cycle
         return qF, qU, pU
 
 

@@ -2,6 +2,7 @@
 w.r.t. mu and Lu (golden vectors), for every (GP class x kernel class) cell, fp64 and fp32."""
 import pytest
 import torch
+import torch.nn as nn
 
 from conftest import golden_cases
 from helpers import load_case, rtol_for
@@ -274,3 +275,31 @@ def test_fused_kl_equals_torch_kl_in_value_and_gradients(name):
         mixed = distributions.kl_divergence(qU1, pU2)
         torch.testing.assert_close(mixed.detach().cpu(), vals[1], rtol=1e-9, atol=1e-12)
         assert mixed.grad_fn is not qU1._gpz_kl.grad_fn
+
+
+@pytest.mark.parametrize("whitened", [True, False])
+def test_training_steps_do_not_accumulate_device_memory(whitened):
+    """Nothing a step allocates (workspaces, the retained Wt, distributions carrying the fused KL) may outlive
+    it: allocated device memory is flat over repeated optimisation steps without waiting for the cyclic GC."""
+    import gc
+    from gpzoo.gp import SVGP, WSVGP
+    from gpzoo.kernels import NSF_RBF
+    from gpzoo.likelihoods import GaussianLikelihood
+    from gpzoo.utilities import train_batched
+    torch.manual_seed(0)
+    N, M, L = 4000, 200, 3
+    X = (torch.rand(N, 2) * 50).cuda(); y = torch.randn(L, N).cuda()
+    gp = (WSVGP if whitened else SVGP)(NSF_RBF(sigma=1.0, lengthscale=4.0, L=L), dim=2, M=M, jitter=1e-2)
+    gp.Z = nn.Parameter(X[:M].clone().cpu()); gp.mu = nn.Parameter(torch.zeros(L, M)); gp.Lu = nn.Parameter(0.01 * torch.randn(L, M, M))
+    model = GaussianLikelihood(gp, noise=0.5).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    gc.collect(); gc.disable()
+    try:
+        mem = []
+        for _ in range(4):
+            train_batched(model, opt, X, y, torch.device("cuda"), steps=8, E=2, batch_size=1000)
+            torch.cuda.synchronize()
+            mem.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    assert mem[-1] == mem[1], mem
