@@ -2,6 +2,8 @@
 moments, ELBO and the mu / Lu (and, whitened, kernel hyper-parameter) gradients against the CPU oracle
 and torch autograd through it.  Ragged extents (N, M not multiples of 128, single points, single
 latents, 1-D to 3-D inputs) are drawn on purpose."""
+import os
+
 import pytest
 import torch
 
@@ -54,7 +56,7 @@ def oracle_parts(c, leaf):
     return mean, scale, kl, O.gaussian_elbo(c["y"], mean, scale, c["noise_sd"], kl)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPZ_FUZZ_SEEDS", "40"))))
 def test_random_case(seed):
     from gpzoo_amd import _lib, ops
     from gpzoo_amd.ops import KernelSpec

