@@ -24,7 +24,7 @@
 
 namespace gpz {
 
-constexpr int PMAXL = 32;   // factors (spatial + non-spatial)
+constexpr int PMAXL = 64;   // factors (spatial + non-spatial): the notebooks' hybrids run L = 20 spatial + T = 19..20
 constexpr int PMAXE = 4;    // Monte-Carlo samples handled per launch group
 
 struct PoissonArgs {
@@ -138,9 +138,9 @@ __global__ __launch_bounds__(256) void spot_kernel(PoissonArgs a) {
   }
 }
 
-// grid (ceil(D/(4*GPW))): each wave owns GPW genes; lanes sweep the spots in tiles of 64 staged in LDS
-constexpr int GPW = 4;
-template <int LT, int E>
+// grid (ceil(D/(4*GPW))): each wave owns GPW genes (4, or 2 above 32 factors: w and acc are 2 x GPW x LT
+// registers); lanes sweep the spots in tiles of 64 staged in LDS
+template <int LT, int E, int GPW>
 __global__ __launch_bounds__(256) void gene_kernel(PoissonArgs a) {
   __shared__ float sF[E][LT][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -277,18 +277,20 @@ extern "C" int gpz_poisson_nsf(const float* mean, const float* scale, const floa
   const int64_t tot = (int64_t)E * Lt * N;
   hipLaunchKernelGGL(expf_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a);
   GPZ_LAUNCH_OK();
-  const dim3 gs((unsigned)pl.nblk, (unsigned)pl.S), gg((unsigned)((D + 4 * GPW - 1) / (4 * GPW)));
-#define GPZ_PO(LT, EE)                                                         \
-  do {                                                                         \
-    hipLaunchKernelGGL((spot_kernel<LT, EE>), gs, dim3(256), 0, s, a);         \
-    hipLaunchKernelGGL((gene_kernel<LT, EE>), gg, dim3(256), 0, s, a);         \
+  const int gpw = Lt <= 32 ? 4 : 2;
+  const dim3 gs((unsigned)pl.nblk, (unsigned)pl.S), gg((unsigned)((D + 4 * gpw - 1) / (4 * gpw)));
+#define GPZ_PO(LT, EE)                                                                       \
+  do {                                                                                       \
+    hipLaunchKernelGGL((spot_kernel<LT, EE>), gs, dim3(256), 0, s, a);                       \
+    hipLaunchKernelGGL((gene_kernel<LT, EE, (LT <= 32 ? 4 : 2)>), gg, dim3(256), 0, s, a);   \
   } while (0)
 #define GPZ_POE(LT)                                                            \
   do {                                                                         \
     if (E == 1) GPZ_PO(LT, 1); else if (E == 2) GPZ_PO(LT, 2); else if (E == 3) GPZ_PO(LT, 3); else GPZ_PO(LT, 4); \
   } while (0)
 #define GPZ_POE2(LT) do { if (E == 1) GPZ_PO(LT, 1); else GPZ_PO(LT, 2); } while (0)
-  if (Lt <= 8) GPZ_POE(8); else if (Lt <= 16) GPZ_POE(16); else if (Lt <= 24) GPZ_POE2(24); else GPZ_POE2(32);
+  if (Lt <= 8) GPZ_POE(8); else if (Lt <= 16) GPZ_POE(16); else if (Lt <= 24) GPZ_POE2(24); else if (Lt <= 32) GPZ_POE2(32);
+  else if (Lt <= 48) GPZ_PO(48, 1); else GPZ_PO(64, 1);
 #undef GPZ_POE2
 #undef GPZ_POE
 #undef GPZ_PO

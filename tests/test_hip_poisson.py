@@ -164,3 +164,40 @@ def test_minibatch_drivers_reproduce_reference_trajectories(name, fused):
     torch.testing.assert_close(torch.tensor(losses, dtype=torch.float64), t("losses"), rtol=1e-7, atol=0)
     for k, v in model.state_dict().items():
         torch.testing.assert_close(v.cpu(), t("final." + k), rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_poisson_shapes(seed):
+    """Seeded sweep over ragged (genes, spots, factors, samples): value and the four gradients of the fused
+    expected log-likelihood against the plain torch evaluation, with and without the log y! term."""
+    from gpzoo_amd import ops
+    g = torch.Generator().manual_seed(900 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))   # noqa: E731
+    D, N = [1, 7, 130, 257, 1000][ri(0, 4)], [1, 63, 64, 500, 3001][ri(0, 4)]
+    Lt, E = [1, 3, 8, 9, 20, 33, 40, 64][ri(0, 7)], [1, 2, 3, 8][ri(0, 3)]      # 40 = the notebooks' L=20 + T=20 hybrids
+    with_lgamma = bool(seed % 2)
+    mean = 0.3 * torch.randn(Lt, N, generator=g)
+    scale = 0.2 + 0.3 * torch.rand(Lt, N, generator=g)
+    eps = torch.randn(E, Lt, N, generator=g)
+    W = torch.rand(D, Lt, generator=g) + 0.05
+    V = 0.5 + torch.rand(N, generator=g)
+    y = torch.poisson(2.0 * torch.rand(D, N, generator=g), generator=g)
+    ll, dmean, dscale, dW, dV = ops.poisson_nsf(mean.cuda(), scale.cuda(), eps.cuda(), W.cuda(), V.cuda(), y.cuda(), with_lgamma)
+    lv = [t.double().requires_grad_(True) for t in (mean, scale, W, V)]
+    rate = lv[3] * torch.matmul(lv[2], torch.exp(lv[0] + lv[1] * eps.double()))
+    yd = y.double()
+    ref = (torch.distributions.Poisson(rate).log_prob(yd) if with_lgamma else yd * torch.log(rate) - rate).mean(0).sum()
+    ref.backward()
+    tag = dict(D=D, N=N, Lt=Lt, E=E, with_lgamma=with_lgamma)
+    assert float(ll.detach()) == pytest.approx(float(ref), rel=5e-5, abs=1e-3), tag
+    for got, want, nm in zip((dmean, dscale, dW, dV), lv, ("dmean", "dscale", "dW", "dV")):
+        sc = float(want.grad.abs().max()) + 1e-30
+        torch.testing.assert_close(got.double().cpu(), want.grad, rtol=1e-3, atol=1e-3 * sc, msg=lambda m: f"{nm} {tag}: {m}")
+
+
+def test_factor_count_limit_is_reported():
+    from gpzoo_amd import ops
+    Lt, N, D = 65, 10, 4
+    with pytest.raises(RuntimeError, match="65 factors unsupported"):
+        ops.poisson_nsf(torch.zeros(Lt, N).cuda(), torch.ones(Lt, N).cuda(), torch.zeros(1, Lt, N).cuda(),
+                        torch.ones(D, Lt).cuda(), torch.ones(N).cuda(), torch.ones(D, N).cuda())
