@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 def golden_cases():
     names = sorted(f[:-4] for f in os.listdir(GOLDEN)
-                   if f.endswith(".npz") and f != "kernels_only.npz" and not f.startswith(("poisson_", "vnngp_", "ref_checkpoint_", "ref_trajectory_")))
+                   if f.endswith(".npz") and f != "kernels_only.npz" and not f.startswith(("poisson_", "vnngp_", "ref_checkpoint_", "ref_trajectory_", "extra_")))
     return names
 
 

@@ -491,6 +491,28 @@ def poisson_trajectory_cases():
         print(f"trajectory {name} losses:", [round(v, 3) for v in losses])
 
 
+def scalar_kernel_batched_q_cases():
+    """A scalar-parameter RBF shared by L variational posteriors (mu (L,M), Lu (L,M,M) assigned after
+    construction): the reference broadcasts the single kernel matrix over the latents."""
+    inp = make_inputs(970, N=70, M=18, d=2, L=3)
+    for cls_name in ("WSVGP", "SVGP"):
+        gp = getattr(rgp, cls_name)(rk.RBF(sigma=1.2, lengthscale=2.5), dim=2, M=18, jitter=1e-2)
+        gp.Z = nn.Parameter(inp["Z"].clone()); gp.mu = nn.Parameter(inp["mu"].clone()); gp.Lu = nn.Parameter(inp["Lu_raw"].clone())
+        gp = gp.double()
+        qF, qU, pU = gp(inp["X"])
+        loss = (qF.mean * inp["y"]).sum() + (qF.scale ** 2).sum()
+        loss.backward()
+        np.savez_compressed(os.path.join(HERE, f"extra_scalar_rbf_batched_{cls_name.lower()}_f64.npz"),
+                            X=inp["X"].numpy(), y=inp["y"].numpy(), Z=inp["Z"].numpy(), mu=inp["mu"].numpy(), Lu_raw=inp["Lu_raw"].numpy(),
+                            mean=qF.mean.detach().numpy(), scale=qF.scale.detach().numpy(), grad_mu=gp.mu.grad.numpy(),
+                            grad_Lu=gp.Lu.grad.numpy(), grad_Z=gp.Z.grad.numpy(), grad_sigma=gp.kernel.sigma.grad.numpy(),
+                            grad_lengthscale=gp.kernel.lengthscale.grad.numpy(), jitter=np.float64(1e-2))
+        print(cls_name, "scalar RBF, batched q:", tuple(qF.mean.shape), float(loss))
+
+
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "extra"):
+    scalar_kernel_batched_q_cases()
+
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "trajectory"):
     trajectory_case()
     poisson_trajectory_cases()
@@ -498,7 +520,7 @@ if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "tra
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "state_dict"):
     state_dict_cases()
 
-if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1" and os.environ.get("GPZ_GOLDEN_ONLY", "") not in ("state_dict", "trajectory"):
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1" and os.environ.get("GPZ_GOLDEN_ONLY", "") not in ("state_dict", "trajectory", "extra"):
     if os.environ.get("GPZ_GOLDEN_ONLY", "") != "vnngp":
         poisson_cases()
     vnngp_cases()

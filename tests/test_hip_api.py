@@ -229,3 +229,27 @@ def test_two_streams_do_not_share_scratch():
     torch.cuda.synchronize()
     for o, r in zip(outs, ref):
         assert torch.equal(o["mean"], r["mean"]) and torch.equal(o["scale"], r["scale"]) and float(o["elbo"]) == float(r["elbo"])
+
+
+@pytest.mark.parametrize("cls_name", ["WSVGP", "SVGP"])
+def test_scalar_kernel_shared_by_batched_posteriors(cls_name):
+    """RBF with scalar sigma / lengthscale under mu (L,M), Lu (L,M,M): the reference broadcasts one kernel
+    matrix over the L posteriors; moments and every gradient (incl. the scalar hyper-parameters') match."""
+    import os
+    import numpy as np
+    import gpzoo.gp as G
+    from gpzoo.kernels import RBF
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, f"extra_scalar_rbf_batched_{cls_name.lower()}_f64.npz"))
+    t = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    gp = getattr(G, cls_name)(RBF(sigma=1.2, lengthscale=2.5), dim=2, M=z["Z"].shape[0], jitter=float(z["jitter"]))
+    gp.Z = nn.Parameter(t("Z").clone()); gp.mu = nn.Parameter(t("mu").clone()); gp.Lu = nn.Parameter(t("Lu_raw").clone())
+    gp = gp.double().cuda()
+    qF, qU, pU = gp(t("X").cuda())
+    torch.testing.assert_close(qF.mean.detach().cpu(), t("mean"), rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(qF.scale.detach().cpu(), t("scale"), rtol=1e-5, atol=1e-8)
+    ((qF.mean * t("y").cuda()).sum() + (qF.scale ** 2).sum()).backward()
+    for got, key in ((gp.mu.grad, "grad_mu"), (gp.Lu.grad, "grad_Lu"), (gp.Z.grad, "grad_Z"), (gp.kernel.sigma.grad, "grad_sigma"),
+                     (gp.kernel.lengthscale.grad, "grad_lengthscale")):
+        ref = t(key)
+        torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()), msg=lambda m: f"{key}: {m}")
