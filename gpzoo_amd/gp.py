@@ -162,14 +162,11 @@ class _FusedGP(nn.Module):
     def _forward(self, X, groupsX=None, verbose=False):
         if verbose:
             print('gpz_svgp_forward: kernels, cholesky, solves and moments in one fused pass')
-        train = torch.is_grad_enabled() and (self.mu.requires_grad or self.Lu.requires_grad)
-        if not train:
+        gparam = getattr(self.kernel, "group_diff_param", None)
+        trainable = [self.mu, self.Lu, self.Z, self.kernel.sigma, self.kernel.lengthscale] + ([gparam] if gparam is not None else [])
+        if not (torch.is_grad_enabled() and any(t.requires_grad for t in trainable)):
             _, out = self._evaluate(X, groupsX, want_chol=not self._whitened)
             return self._distributions(out)
-        kparams = [self.Z, self.kernel.sigma, self.kernel.lengthscale]
-        gparam = getattr(self.kernel, "group_diff_param", None)
-        if gparam is not None:
-            kparams.append(gparam)
         spec = kernel_spec(self.kernel, X, self._latents())
         gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
         args = (spec, X, self.Z)

@@ -303,3 +303,22 @@ def test_training_steps_do_not_accumulate_device_memory(whitened):
     finally:
         gc.enable()
     assert mem[-1] == mem[1], mem
+
+
+def test_only_hyperparameters_trainable():
+    """mu and Lu frozen, lengthscale / sigma / Z trainable (the length-scale estimation notebooks' mode): the
+    gradients still flow, and equal those of the all-trainable run."""
+    c = load_case("wsvgp_nsf_rbf_f64")
+    X = c["X"].cuda()
+    grads = []
+    for freeze in (False, True):
+        model = build("wsvgp_nsf_rbf_f64", c)
+        gp = model.gp
+        if freeze:
+            gp.mu.requires_grad_(False); gp.Lu.requires_grad_(False)
+        pY, qF, qU, pU = model(X=X, E=1)
+        ((qF.mean * c["y"].cuda()).sum() + (qF.scale ** 2).sum()).backward()
+        assert (gp.mu.grad is None) == freeze
+        grads.append([gp.kernel.lengthscale.grad.clone(), gp.kernel.sigma.grad.clone(), gp.Z.grad.clone()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
