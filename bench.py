@@ -54,7 +54,10 @@ def cpu_baseline(cfg_id: int, c: dict, sample: int) -> dict:
     the reference's own minibatch usage (utilities.py:605-609)."""
     from oracle import svgp_oracle as O
     n = min(sample, c["X"].shape[0])
-    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))          # the cores this process may actually run on
+    except AttributeError:
+        threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     kw = {}
     if "gX" in c:
