@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """ELBO-evaluation benchmark of the SVGP/WSVGP hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]        (N > 1: starts its own N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Typed without a launcher, `--gpus N` (N > 1) re-runs this file under torch.distributed.run in a child
+process before anything touches the GPU and hands back rank 0's JSON line and the exit code.  Backend:
+nccl (= RCCL over xGMI); when fewer than N GPUs are visible the ranks share the devices and the
+rendezvous / scalar all-reduce fall back to gloo (a rehearsal -- the JSON says so in `backend` and
+`devices`, and its `value` is not a scaling number).
 
 One "step" = one closed-form Gaussian ELBO evaluation on the
 Slide-seq-shaped synthetic workload of BASELINE.json configs[2]: N=200k spots,
@@ -110,28 +116,49 @@ def pmc_traffic(cfg_id, N, M, L, chunk):
     return None
 
 
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as a child torch.distributed.run
+    job (this process has not touched the GPU: device_count() does not initialise it) and return its exit
+    code; rank 0 of the child prints the JSON line on the shared stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 as `python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
+    backend = os.environ.get("GPZ_DIST_BACKEND") or ("nccl" if ndev >= world else "gloo")   # nccl == RCCL over xGMI
     local = local % max(ndev, 1)          # rehearsals may run several ranks on one GPU (gloo only)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ranks = 1
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("GPZ_DIST_BACKEND", "nccl")   # nccl == RCCL over xGMI on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        ranks = dist.get_world_size()
 
     from gpzoo_amd import ops
     from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.parallel import _allreduce_scalar
     from gpzoo_amd.synthetic import CONFIGS, make_config
 
     cfg_id = a.config
@@ -148,9 +175,9 @@ def main():
     def step():
         out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
                                y=g["y"], noise_sd=c["noise_sd"], chunk=a.chunk, want_Lu=False, **extra)
-        e = out["elbo"].clone()
+        e = out["elbo"]
         if world > 1:
-            dist.all_reduce(e)
+            e = _allreduce_scalar(e)      # RCCL on the device scalar (nccl); through the host for gloo rehearsals
         return e
 
     def fence():
@@ -169,7 +196,7 @@ def main():
     dt_s = time.perf_counter() - t0
     prof = ops.profile_read()
     ops.profile_enable(False)
-    tmax = torch.tensor([dt_s], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     t = float(tmax)
@@ -226,7 +253,8 @@ def main():
         res = {
             "metric": "ELBO evals/sec (L=%d-latent evaluations, all GPUs) at M=%d inducing, N=%d, L=%d per GPU"
                       % (Lper, M, N, Lper),
-            "value": a.steps * world / t, "unit": "ELBO evals/s", "n_gpus": world, "steps": a.steps,
+            "value": a.steps * world / t, "unit": "ELBO evals/s", "n_gpus": world, "ranks": ranks,
+            "backend": backend if world > 1 else None, "devices": ndev, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dname, "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %s, N=%d spots, M=%d, L=%d latents/GPU x %d GPU(s), %s, %s"
@@ -238,7 +266,16 @@ def main():
         if train_ms is not None:
             res["forward_backward_ms"] = train_ms
         if not a.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(cfg_id, c, a.cpu_sample)
+            cb = cpu_baseline(cfg_id, c, a.cpu_sample)
+            # parity on the driver-run line: the HIP path on the very slice the CPU port just evaluated
+            # (outside the timed region), same dtype, all latents and inducing points
+            n = min(a.cpu_sample, N)
+            ex = {k: (v[:n] if k == "gX" else v) for k, v in extra.items()}
+            o = ops.svgp_forward(spec, g["X"][:n], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
+                                 y=g["y"][..., :n].contiguous(), noise_sd=c["noise_sd"], want_Lu=False, **ex)
+            cb["sample_elbo_hip"] = float(o["elbo"])
+            cb["sample_rel_diff"] = abs(cb["sample_elbo_hip"] - cb["sample_elbo"]) / abs(cb["sample_elbo"])
+            res["cpu_baseline"] = cb
         elif not a.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

@@ -53,12 +53,16 @@ _SIGNATURES = {
     "gpz_kfill": (C.c_int, [C.POINTER(KernelDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_int32,
                             C.c_void_p]),
+    "gpz_kgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "gpz_kgrad": (C.c_int, [C.POINTER(KernelDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                            C.c_void_p]),
     "gpz_potrf_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
-    "gpz_potrf_batched": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
-                                    C.c_size_t, C.c_void_p]),
+    "gpz_potrf_batched": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpz_trsm_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
-    "gpz_trsm_lln_batched": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                                       C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gpz_trsm_lln_batched": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                       C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpz_svgp_factor_cache_bytes": (C.c_size_t, [C.POINTER(SvgpProblem)]),
     "gpz_svgp_wt_cache_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
     "gpz_svgp_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
@@ -79,6 +83,13 @@ _SIGNATURES = {
     "gpz_wsvgp_precomputed_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "gpz_wsvgp_precomputed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gpz_wsvgp_precomputed_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
+    "gpz_wsvgp_precomputed_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int64, C.c_int64, C.c_int32] +
+                                       [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),
+    "gpz_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "gpz_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
+    "gpz_allreduce_sum_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gpz_comm_destroy": (C.c_int, [C.c_void_p]),
     "gpz_profile_enable": (C.c_int, [C.c_int32]),
     "gpz_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32]),
 }

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpzoo_hip.so")
-SOURCES = ["runtime.hip", "kfill.hip", "gemm.hip", "diag128.hip", "factor.hip", "kgrad.hip", "poisson.hip", "svgp.hip", "vnngp.hip"]
+SOURCES = ["runtime.hip", "kfill.hip", "gemm.hip", "diag128.hip", "factor.hip", "kgrad.hip", "poisson.hip", "svgp.hip", "vnngp.hip", "collective.hip"]
 HEADERS = ["common.h", "gemm.h", os.path.join("..", "..", "include", "gpzoo_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -51,6 +51,13 @@ struct Carver {
   size_t used() const { return (off + 255) & ~size_t(255); }
 };
 
+// Covariance fill with padded extents (csrc/kfill.hip): rows/columns beyond the real extents are written as
+// zero (identity on the diagonal when pad_identity).  `bad_group`: device int32 that is set to -1 when a group
+// id of a multi-group kernel lies outside [0, n_groups) (the id is then read as 0: no out-of-bounds access).
+int kfill_padded(const gpz_kernel_desc* k, const void* A, int64_t nA, int64_t pA, const void* B, int64_t nB,
+                 int64_t pB, int d, const int64_t* gA, const int64_t* gB, void* K, int64_t ldk, int64_t stride,
+                 double jitter, int pad_identity, int out_dtype, hipStream_t s, int32_t* bad_group = nullptr);
+
 // ---- profiling slots (HIP events around the dominant kernels) -------------
 enum ProfSlot { PROF_KFILL = 0, PROF_STAGE1 = 1, PROF_STAGE2 = 2, PROF_POTRF_TRAIL = 3,
                 PROF_POTRF_ALL = 4, PROF_TRTRI = 5, PROF_FINAL = 6, PROF_NSLOTS = 8 };

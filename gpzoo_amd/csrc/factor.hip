@@ -57,13 +57,13 @@ static int diag_lds_attr() {
 // In-place Cholesky of `batch` padded (Mp,Mp) fp64 matrices; Dinv receives the inverse of
 // every diagonal 128-block: (batch, Mp/128, 128, 128).
 int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                 int32_t* info, hipStream_t s) {
+                 int32_t* info, hipStream_t s, bool clear_info) {
   GPZ_REQUIRE(Mp % NB == 0 && Mp > 0, "potrf: padded order %lld is not a multiple of %d", (long long)Mp, NB);
   const int nblk = (int)(Mp / NB);
   const int64_t dstride = (int64_t)nblk * NB * NB;
   const size_t lds = DIAG_LDS_BYTES;
   if (int rc = diag_lds_attr()) return rc;
-  GPZ_HIP_OK(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, s));
+  if (clear_info) GPZ_HIP_OK(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, s));
   prof_begin(PROF_POTRF_ALL, s);
   auto diag = [&](int k) -> int {
     hipLaunchKernelGGL(diag128_kernel, dim3((unsigned)batch), dim3(256), lds, s, A, lda, stride, k, Dinv, dstride, info,
@@ -165,23 +165,56 @@ int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* 
   return 0;
 }
 
-// ---- ragged <-> padded copies for the public entry points ----
-__global__ void pad_copy_in_kernel(const double* __restrict__ src, int64_t ld, int64_t stride, int64_t m,
-                                   double* __restrict__ dst, int64_t mp, int lower_identity) {
+// ---- ragged <-> padded copies for the public entry points (strided-batched, storage type S <-> fp64) ----
+// dst (batch, rp, cp) fp64 = src (batch, m, n) of type S, zero (or identity on the diagonal) outside the real extents
+template <typename S>
+__global__ void pad_copy_in_kernel(const S* __restrict__ src, int64_t ld, int64_t stride, int64_t m, int64_t n,
+                                   double* __restrict__ dst, int64_t rp, int64_t cp, int lower_identity) {
   const int64_t b = blockIdx.z;
   const int64_t i = blockIdx.y;
-  for (int64_t j = threadIdx.x + (int64_t)blockIdx.x * blockDim.x; j < mp; j += (int64_t)blockDim.x * gridDim.x) {
-    double v = (i < m && j < m) ? src[b * stride + i * ld + j] : ((lower_identity && i == j) ? 1.0 : 0.0);
-    dst[b * mp * mp + i * mp + j] = v;
+  for (int64_t j = threadIdx.x + (int64_t)blockIdx.x * blockDim.x; j < cp; j += (int64_t)blockDim.x * gridDim.x) {
+    double v = (i < m && j < n) ? (double)src[b * stride + i * ld + j] : ((lower_identity && i == j) ? 1.0 : 0.0);
+    dst[b * rp * cp + i * cp + j] = v;
   }
 }
 
-__global__ void pad_copy_out_kernel(const double* __restrict__ src, int64_t mp, double* __restrict__ dst, int64_t ld,
-                                    int64_t stride, int64_t m) {
+// dst (batch, m, n) of type S = src (batch, rp, cp) fp64; `lower`: zeros above the diagonal
+template <typename S>
+__global__ void pad_copy_out_kernel(const double* __restrict__ src, int64_t cp, int64_t sstride, S* __restrict__ dst,
+                                    int64_t ld, int64_t stride, int64_t n, int lower) {
   const int64_t b = blockIdx.z;
   const int64_t i = blockIdx.y;
-  for (int64_t j = threadIdx.x + (int64_t)blockIdx.x * blockDim.x; j < m; j += (int64_t)blockDim.x * gridDim.x)
-    dst[b * stride + i * ld + j] = (j <= i) ? src[b * mp * mp + i * mp + j] : 0.0;  // zeros above the diagonal
+  for (int64_t j = threadIdx.x + (int64_t)blockIdx.x * blockDim.x; j < n; j += (int64_t)blockDim.x * gridDim.x)
+    dst[b * stride + i * ld + j] = (!lower || j <= i) ? (S)src[b * sstride + i * cp + j] : (S)0;
+}
+
+// S[k][k] = Dinv_k  (the diagonal blocks of the scaled factor of the substitution solve)
+__global__ void set_diag_blocks_kernel(const double* __restrict__ Dinv, int64_t dinv_stride, double* __restrict__ Sm,
+                                       int64_t ld, int64_t stride) {
+  const int b = blockIdx.y, k = blockIdx.x;
+  const double* src = Dinv + (int64_t)b * dinv_stride + (int64_t)k * NB * NB;
+  double* dst = Sm + (int64_t)b * stride + (int64_t)k * NB * (ld + 1);
+  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) dst[(int64_t)(e >> 7) * ld + (e & 127)] = src[e];
+}
+
+template <typename S>
+static int copy_in(const void* src, int64_t ld, int64_t stride, int64_t m, int64_t n, double* dst, int64_t rp, int64_t cp,
+                   int64_t batch, int ident, hipStream_t s) {
+  dim3 grid((unsigned)((cp + 255) / 256), (unsigned)rp, (unsigned)batch);
+  hipLaunchKernelGGL((pad_copy_in_kernel<S>), grid, dim3(256), 0, s, static_cast<const S*>(src), ld, stride, m, n, dst, rp,
+                     cp, ident);
+  GPZ_LAUNCH_OK();
+  return 0;
+}
+
+template <typename S>
+static int copy_out(const double* src, int64_t cp, int64_t sstride, void* dst, int64_t ld, int64_t stride, int64_t m,
+                    int64_t n, int64_t batch, int lower, hipStream_t s) {
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)m, (unsigned)batch);
+  hipLaunchKernelGGL((pad_copy_out_kernel<S>), grid, dim3(256), 0, s, src, cp, sstride, static_cast<S*>(dst), ld, stride, n,
+                     lower);
+  GPZ_LAUNCH_OK();
+  return 0;
 }
 
 }  // namespace gpz
@@ -196,9 +229,10 @@ extern "C" size_t gpz_potrf_workspace_bytes(int64_t M, int64_t batch) {
   return c.used();
 }
 
-extern "C" int gpz_potrf_batched(double* A, int64_t M, int64_t lda, int64_t stride_a, int64_t batch, int32_t* info,
-                                 void* ws, size_t ws_bytes, void* stream) {
+extern "C" int gpz_potrf_batched(void* A, int32_t dtype, int64_t M, int64_t lda, int64_t stride_a, int64_t batch,
+                                 int32_t* info, void* ws, size_t ws_bytes, void* stream) {
   GPZ_REQUIRE(A && info && ws, "gpz_potrf_batched: null pointer");
+  GPZ_REQUIRE(dtype == GPZ_F32 || dtype == GPZ_F64, "gpz_potrf_batched: bad dtype %d", dtype);
   GPZ_REQUIRE(M >= 1 && lda >= M && batch >= 1, "gpz_potrf_batched: bad extents");
   GPZ_REQUIRE(ws_bytes >= gpz_potrf_workspace_bytes(M, batch), "gpz_potrf_batched: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -206,14 +240,12 @@ extern "C" int gpz_potrf_batched(double* A, int64_t M, int64_t lda, int64_t stri
   Carver c(ws);
   double* Ap = c.take<double>(batch * Mp * Mp);
   double* Dinv = c.take<double>(batch * (Mp / NB) * NB * NB);
-  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp, (unsigned)batch);
-  hipLaunchKernelGGL(pad_copy_in_kernel, grid, dim3(256), 0, s, A, lda, stride_a, M, Ap, Mp, 1);
-  GPZ_LAUNCH_OK();
-  if (int rc = potrf_padded(Ap, Mp, Mp, Mp * Mp, batch, M, Dinv, info, s)) return rc;
-  dim3 grid2((unsigned)((M + 255) / 256), (unsigned)M, (unsigned)batch);
-  hipLaunchKernelGGL(pad_copy_out_kernel, grid2, dim3(256), 0, s, Ap, Mp, A, lda, stride_a, M);
-  GPZ_LAUNCH_OK();
-  return 0;
+  if (int rc = dtype == GPZ_F32 ? copy_in<float>(A, lda, stride_a, M, M, Ap, Mp, Mp, batch, 1, s)
+                                : copy_in<double>(A, lda, stride_a, M, M, Ap, Mp, Mp, batch, 1, s))
+    return rc;
+  if (int rc = potrf_padded(Ap, Mp, Mp, Mp * Mp, batch, M, Dinv, info, s, true)) return rc;
+  return dtype == GPZ_F32 ? copy_out<float>(Ap, Mp, Mp * Mp, A, lda, stride_a, M, M, batch, 1, s)
+                          : copy_out<double>(Ap, Mp, Mp * Mp, A, lda, stride_a, M, M, batch, 1, s);
 }
 
 extern "C" size_t gpz_trsm_workspace_bytes(int64_t M, int64_t N, int64_t batch) {
@@ -221,53 +253,61 @@ extern "C" size_t gpz_trsm_workspace_bytes(int64_t M, int64_t N, int64_t batch) 
   Carver c(nullptr);
   c.take<double>(batch * Mp * Mp);              // padded factor
   c.take<double>(batch * (Mp / NB) * NB * NB);  // Dinv
-  c.take<double>(batch * Mp * Mp);              // Linv
-  c.take<double>(batch * Mp * Mp / 2);          // T
-  c.take<double>(batch * Mp * Np);              // padded B
-  c.take<double>(batch * Mp * Np);              // padded X
+  c.take<double>(batch * Mp * Mp);              // scaled factor S
+  c.take<double>(batch * Mp * Np);              // padded right-hand side, solved in place
   return c.used();
 }
 
-extern "C" int gpz_trsm_lln_batched(const double* Lc, int64_t ldl, int64_t stride_l, double* B, int64_t ldb,
-                                    int64_t stride_b, int64_t M, int64_t N, int64_t batch, void* ws, size_t ws_bytes,
-                                    void* stream) {
+// Blocked forward substitution.  With D_k = inv(L[k][k]) (diag128_kernel, inverse-only mode) and the scaled
+// factor S[k][j] = -D_k L[k][j] (j < k), S[k][k] = D_k, block row k of the solution is
+//   X_k = D_k (B_k - sum_{j<k} L[k][j] X_j) = S[k][0:k+1] * [X_0; ...; X_{k-1}; B_k],
+// one MFMA GEMM per block row, in place (tile (k, j) reads only column strip j, rows 0..k, and writes (k, j)).
+// M^2 N flops like the substitution it is; the fused forward pass uses the explicit inverse instead (one
+// triangular product per N-chunk with every row tile in flight at once).
+extern "C" int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_l, void* B, int64_t ldb,
+                                    int64_t stride_b, int32_t dtype, int64_t M, int64_t N, int64_t batch, void* ws,
+                                    size_t ws_bytes, void* stream) {
   GPZ_REQUIRE(Lc && B && ws, "gpz_trsm_lln_batched: null pointer");
+  GPZ_REQUIRE(dtype == GPZ_F32 || dtype == GPZ_F64, "gpz_trsm_lln_batched: bad dtype %d", dtype);
   GPZ_REQUIRE(M >= 1 && N >= 1 && batch >= 1 && ldl >= M && ldb >= N, "gpz_trsm_lln_batched: bad extents");
   GPZ_REQUIRE(ws_bytes >= gpz_trsm_workspace_bytes(M, N, batch), "gpz_trsm_lln_batched: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t Mp = pad_up(M), Np = pad_up(N);
   const int nblk = (int)(Mp / NB);
+  const int64_t dstride = (int64_t)nblk * NB * NB;
   Carver c(ws);
   double* Lp = c.take<double>(batch * Mp * Mp);
   double* Dinv = c.take<double>(batch * nblk * NB * NB);
-  double* Linv = c.take<double>(batch * Mp * Mp);
-  double* T = c.take<double>(batch * Mp * Mp / 2);
+  double* Sm = c.take<double>(batch * Mp * Mp);
   double* Bp = c.take<double>(batch * Mp * Np);
-  double* Xp = c.take<double>(batch * Mp * Np);
-  dim3 grid((unsigned)((Mp + 255) / 256), (unsigned)Mp, (unsigned)batch);
-  hipLaunchKernelGGL(pad_copy_in_kernel, grid, dim3(256), 0, s, Lc, ldl, stride_l, M, Lp, Mp, 1);
-  GPZ_LAUNCH_OK();
-  const size_t lds = DIAG_LDS_BYTES;
+  if (int rc = dtype == GPZ_F32 ? copy_in<float>(Lc, ldl, stride_l, M, M, Lp, Mp, Mp, batch, 1, s)
+                                : copy_in<double>(Lc, ldl, stride_l, M, M, Lp, Mp, Mp, batch, 1, s))
+    return rc;
+  if (int rc = dtype == GPZ_F32 ? copy_in<float>(B, ldb, stride_b, M, N, Bp, Mp, Np, batch, 0, s)
+                                : copy_in<double>(B, ldb, stride_b, M, N, Bp, Mp, Np, batch, 0, s))
+    return rc;
   if (int rc = diag_lds_attr()) return rc;
-  hipLaunchKernelGGL(diag128_kernel, dim3((unsigned)batch, nblk), dim3(256), lds, s, Lp, Mp, Mp * Mp, -1, Dinv,
-                     (int64_t)nblk * NB * NB, (int32_t*)nullptr, M, 0);
+  hipLaunchKernelGGL(diag128_kernel, dim3((unsigned)batch, nblk), dim3(256), DIAG_LDS_BYTES, s, Lp, Mp, Mp * Mp, -1, Dinv,
+                     dstride, (int32_t*)nullptr, M, 0);
   GPZ_LAUNCH_OK();
-  if (int rc = trtri_padded(Lp, Mp, Mp * Mp, Dinv, Linv, Mp, batch, T, s)) return rc;
-  // padded right-hand side (rows >= M and columns >= N are zero)
-  GPZ_HIP_OK(hipMemsetAsync(Bp, 0, sizeof(double) * batch * Mp * Np, s));
-  GPZ_HIP_OK(hipMemcpy2DAsync(Bp, Np * sizeof(double), B, ldb * sizeof(double), N * sizeof(double), M,
-                              hipMemcpyDeviceToDevice, s));
-  for (int64_t b = 1; b < batch; ++b)
-    GPZ_HIP_OK(hipMemcpy2DAsync(Bp + b * Mp * Np, Np * sizeof(double), B + b * stride_b, ldb * sizeof(double),
-                                N * sizeof(double), M, hipMemcpyDeviceToDevice, s));
-  GemmParams<double> g;
-  g.A = Linv; g.lda = Mp; g.sA0 = Mp * Mp;
-  g.B = Bp; g.ldb = Np; g.sB0 = Mp * Np;
-  g.C = Xp; g.ldc = Np; g.sC0 = Mp * Np;
-  g.nb0 = (int)batch; g.mt = nblk; g.nt = (int)(Np / NB); g.K = (int)Mp; g.flags = GF_A_LOWER;
-  if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
-  for (int64_t b = 0; b < batch; ++b)
-    GPZ_HIP_OK(hipMemcpy2DAsync(B + b * stride_b, ldb * sizeof(double), Xp + b * Mp * Np, Np * sizeof(double),
-                                N * sizeof(double), M, hipMemcpyDeviceToDevice, s));
-  return 0;
+  {  // S[k][:] = -D_k * L[k][:]  (all block rows in one launch; the blocks right of the diagonal are never read)
+    GemmParams<double> g;
+    g.A = Dinv; g.lda = NB; g.sA0 = dstride; g.sA1 = (int64_t)NB * NB;
+    g.B = Lp; g.ldb = Mp; g.sB0 = Mp * Mp; g.sB1 = (int64_t)NB * Mp;
+    g.C = Sm; g.ldc = Mp; g.sC0 = Mp * Mp; g.sC1 = (int64_t)NB * Mp;
+    g.nb0 = (int)batch; g.nb1 = nblk; g.mt = 1; g.nt = nblk; g.K = NB; g.alpha = -1.0;
+    if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
+    hipLaunchKernelGGL(set_diag_blocks_kernel, dim3(nblk, (unsigned)batch), dim3(256), 0, s, Dinv, dstride, Sm, Mp, Mp * Mp);
+    GPZ_LAUNCH_OK();
+  }
+  for (int k = 0; k < nblk; ++k) {
+    GemmParams<double> g;
+    g.A = Sm + (int64_t)k * NB * Mp; g.lda = Mp; g.sA0 = Mp * Mp;
+    g.B = Bp; g.ldb = Np; g.sB0 = Mp * Np;
+    g.C = Bp + (int64_t)k * NB * Np; g.ldc = Np; g.sC0 = Mp * Np;
+    g.nb0 = (int)batch; g.mt = 1; g.nt = (int)(Np / NB); g.K = (k + 1) * NB;
+    if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
+  }
+  return dtype == GPZ_F32 ? copy_out<float>(Bp, Np, Mp * Np, B, ldb, stride_b, M, N, batch, 0, s)
+                          : copy_out<double>(Bp, Np, Mp * Np, B, ldb, stride_b, M, N, batch, 0, s);
 }

@@ -30,6 +30,7 @@ struct KfillArgs {
   int64_t ldk, stride;
   double jitter, gpow;
   int d, L, G, pad_identity;
+  int32_t* bad;        // set to -1 when a group id is outside [0, G) (nullable)
 };
 
 template <typename T> struct VecOf;
@@ -40,6 +41,17 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ double fast_exp(double x) { return exp(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+
+// Group id of a point, range checked: the reference indexes the group embedding with it and raises IndexError
+// for an id outside [0, n_groups) (kernels.py:99-100, 177-178, 209-210); here the launch flags it and reads group 0.
+__device__ __forceinline__ int checked_group(const int64_t* g, int64_t i, int G, int32_t* bad) {
+  const int64_t v = g[i];
+  if (v < 0 || v >= G) {
+    if (bad) atomicMin(bad, -1);
+    return 0;
+  }
+  return (int)v;
+}
 
 // KIND: 0 RBF, 1 Matern-3/2, 2 MGGP RBF, 3 plain distance.  VECST: aligned 16-byte stores allowed.
 template <typename Tin, typename To, int KIND, bool VECST>
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(KF_TX* KF_TY) void kfill_kernel(KfillArgs a) {
     for (int k = 0; k < 4; ++k) bx[v][k] = (To)0;
     if (j < a.nB) {
       for (int k = 0; k < d; ++k) bx[v][k] = (To)Bp[j * d + k];
-      if (KIND == 2) gb[v] = (int)a.gB[j];
+      if (KIND == 2) gb[v] = checked_group(a.gB, j, G, a.bad);
     }
   }
 
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(KF_TX* KF_TY) void kfill_kernel(KfillArgs a) {
     const bool row_real = i < a.nA;
     if (row_real) {
       for (int k = 0; k < d; ++k) ax[k] = (To)Ap[i * d + k];
-      if (KIND == 2) gai = (int)a.gA[i];
+      if (KIND == 2) gai = checked_group(a.gA, i, G, a.bad);
     }
     To d2[VEC];
 #pragma unroll
@@ -187,7 +199,7 @@ static int launch_kfill(const gpz_kernel_desc* k, KfillArgs a, hipStream_t s) {
 // Internal entry: padded extents + identity padding (used by the fused forward).
 int kfill_padded(const gpz_kernel_desc* k, const void* A, int64_t nA, int64_t pA, const void* B, int64_t nB,
                  int64_t pB, int d, const int64_t* gA, const int64_t* gB, void* K, int64_t ldk, int64_t stride,
-                 double jitter, int pad_identity, int out_dtype, hipStream_t s) {
+                 double jitter, int pad_identity, int out_dtype, hipStream_t s, int32_t* bad_group) {
   GPZ_REQUIRE(k && A && B && K, "gpz_kfill: null pointer");
   GPZ_REQUIRE(d >= 1 && d <= 4, "gpz_kfill: input dimension %d unsupported (1..4)", d);
   GPZ_REQUIRE(k->kind >= 0 && k->kind <= 3, "gpz_kfill: unknown kernel kind %d", k->kind);
@@ -202,7 +214,7 @@ int kfill_padded(const gpz_kernel_desc* k, const void* A, int64_t nA, int64_t pA
   a.sigma = k->sigma; a.ell = k->lengthscale; a.ga = k->group_a; a.gr2 = k->group_r2;
   a.K = K; a.nA = nA; a.nB = nB; a.pA = pA; a.pB = pB; a.ldk = ldk; a.stride = stride;
   a.jitter = jitter; a.gpow = k->group_pow; a.d = d; a.L = k->n_latent; a.G = k->n_groups;
-  a.pad_identity = pad_identity;
+  a.pad_identity = pad_identity; a.bad = bad_group;
   if (k->dtype == GPZ_F32 && out_dtype == GPZ_F32) return launch_kfill<float, float>(k, a, s);
   if (k->dtype == GPZ_F32 && out_dtype == GPZ_F64) return launch_kfill<float, double>(k, a, s);
   return launch_kfill<double, double>(k, a, s);

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void kgrad_kernel(KgradArgs a) {
   const double s2 = sig * sig, il2 = 1.0 / (ell * ell);
   double z[4] = {0, 0, 0, 0};
   for (int k = 0; k < d; ++k) z[k] = (double)Zp[m * d + k];
-  const int gz = (KIND == 2) ? (int)a.gZ[m] : 0;
+  // ids were range-checked by the forward fill (IndexError there); clamped here so a stray one cannot read out of bounds
+  const int gz = (KIND == 2) ? ((uint64_t)a.gZ[m] < (uint64_t)a.G ? (int)a.gZ[m] : 0) : 0;
   const double aeff = (KIND == 2) ? (double)static_cast<const T*>(a.ga)[l] : 0.0;
   double dz[4] = {0, 0, 0, 0}, dsig = 0, dell = 0, da = 0;
   for (int64_t c = lane; c < a.ncols; c += 64) {
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(256) void kgrad_kernel(KgradArgs a) {
       dell += g * s2 * v * v * e / ell;
       cz = -s2 * 3.0 * il2 * e;
     } else {
-      const double r2 = (double)static_cast<const T*>(a.gr2)[gz * a.G + (int)a.gX[c]];
+      const int gx = (uint64_t)a.gX[c] < (uint64_t)a.G ? (int)a.gX[c] : 0;
+      const double r2 = (double)static_cast<const T*>(a.gr2)[gz * a.G + gx];
       const double den = aeff * r2 + 1.0;
       const double kv = s2 * exp(-0.5 * d2 * il2 / den) * pow(den, -a.gpow);
       dsig += g * 2.0 * kv / sig;
@@ -92,3 +94,70 @@ int kgrad_launch(int dtype, int kind, const KgradArgs& a, int L, hipStream_t s) 
 }
 
 }  // namespace gpz
+
+// ---- public entry: backward of gpz_kfill ------------------------------------------------------
+namespace gpz {
+// grad_A[m][k] = sum_l acc[l][m][k];  grad_theta[l][0..2] = sum_m acc[l][m][4..6]
+__global__ __launch_bounds__(256) void kgrad_public_finish_kernel(const double* __restrict__ acc, int L, int64_t M, int d,
+                                                                  double* __restrict__ grad_A,
+                                                                  double* __restrict__ grad_theta) {
+  __shared__ double sh[4];
+  if (blockIdx.y == 0) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < M && grad_A)
+      for (int k = 0; k < 4; ++k) {
+        double t = 0.0;
+        if (k < d)
+          for (int l = 0; l < L; ++l) t += acc[((int64_t)l * M + m) * 8 + k];
+        grad_A[m * 4 + k] = t;
+      }
+  } else if ((int)blockIdx.x < L && grad_theta) {
+    const int l = blockIdx.x;
+    for (int q = 0; q < 3; ++q) {
+      double v = 0.0;
+      for (int64_t m = threadIdx.x; m < M; m += 256) v += acc[((int64_t)l * M + m) * 8 + 4 + q];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) grad_theta[l * 4 + q] = sh[0] + sh[1] + sh[2] + sh[3];
+    }
+    if (threadIdx.x == 0) grad_theta[l * 4 + 3] = 0.0;
+  }
+}
+}  // namespace gpz
+
+extern "C" size_t gpz_kgrad_workspace_bytes(int64_t nA, int32_t n_latent) {
+  if (nA < 1 || n_latent < 1) return 0;
+  gpz::Carver c(nullptr);
+  c.take<double>((int64_t)n_latent * nA * 8);
+  return c.used();
+}
+
+extern "C" int gpz_kgrad(const gpz_kernel_desc* k, const void* A, int64_t nA, const void* B, int64_t nB, int32_t d,
+                         const int64_t* gA, const int64_t* gB, const void* Kbar, int64_t ldk, int64_t stride_k,
+                         double* grad_theta, double* grad_A, void* ws, size_t ws_bytes, void* stream) {
+  using namespace gpz;
+  GPZ_REQUIRE(k && A && B && Kbar && ws, "gpz_kgrad: null pointer");
+  GPZ_REQUIRE(nA >= 1 && nB >= 1 && ldk >= nB && d >= 1 && d <= 4, "gpz_kgrad: bad extents nA=%lld nB=%lld ldk=%lld d=%d",
+              (long long)nA, (long long)nB, (long long)ldk, d);
+  GPZ_REQUIRE(k->kind >= 0 && k->kind <= 2, "gpz_kgrad: kernel kind %d has no parameters to differentiate", k->kind);
+  GPZ_REQUIRE(k->n_latent >= 1 && (k->dtype == GPZ_F32 || k->dtype == GPZ_F64), "gpz_kgrad: bad kernel description");
+  if (k->kind == GPZ_KERNEL_MGGP_RBF)
+    GPZ_REQUIRE(gA && gB && k->group_a && k->group_r2 && k->n_groups >= 1, "gpz_kgrad: MGGP kernel needs groups, group_a, group_r2");
+  GPZ_REQUIRE(ws_bytes >= gpz_kgrad_workspace_bytes(nA, k->n_latent), "gpz_kgrad: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int L = k->n_latent;
+  Carver c(ws);
+  double* acc = c.take<double>((int64_t)L * nA * 8);
+  GPZ_HIP_OK(hipMemsetAsync(acc, 0, sizeof(double) * L * nA * 8, s));
+  KgradArgs a;
+  a.Kbar = Kbar; a.ld = ldk; a.stride = stride_k; a.Z = A; a.X = B; a.gZ = gA; a.gX = gB;
+  a.sigma = k->sigma; a.ell = k->lengthscale; a.ga = k->group_a; a.gr2 = k->group_r2;
+  a.gpow = k->group_pow; a.scalar_scale = 1.0; a.M = nA; a.ncols = nB; a.Mp = nA; a.d = d; a.G = k->n_groups; a.acc = acc;
+  if (int rc = kgrad_launch(k->dtype, k->kind, a, L, s)) return rc;
+  const unsigned fx = (unsigned)((nA + 255) / 256 > L ? (nA + 255) / 256 : L);
+  hipLaunchKernelGGL(kgrad_public_finish_kernel, dim3(fx, 2), dim3(256), 0, s, acc, L, nA, d, grad_A, grad_theta);
+  GPZ_LAUNCH_OK();
+  return 0;
+}

@@ -23,11 +23,8 @@
 
 namespace gpz {
 
-int kfill_padded(const gpz_kernel_desc* k, const void* A, int64_t nA, int64_t pA, const void* B, int64_t nB,
-                 int64_t pB, int d, const int64_t* gA, const int64_t* gB, void* K, int64_t ldk, int64_t stride,
-                 double jitter, int pad_identity, int out_dtype, hipStream_t s);
 int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                 int32_t* info, hipStream_t s);
+                 int32_t* info, hipStream_t s, bool clear_info = true);
 int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* Dinv, double* Linv, int64_t Mp,
                  int64_t batch, double* T, hipStream_t s);
 
@@ -398,6 +395,8 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
   const bool wh = p->whitened != 0;
   const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, mm = Mp * Mp;
   const int L32 = (int)L;
+  // info: 0 = fine, k > 0 = leading minor k not positive-definite (potrf), < 0 = a group id out of range (kfill)
+  GPZ_HIP_OK(hipMemsetAsync(p->info, 0, sizeof(int32_t) * L, s));
   // 1. Kzz + jitter I (fp64, identity padded), Cholesky, inverse -- or the caller's cached copy
   if (p->factor_cache) {
     FactorCache<T> f = carve_cache<T>(pl, p->factor_cache);
@@ -405,9 +404,9 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
   }
   if (!(p->factor_cache && p->factor_cache_valid)) {
     if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, p->gZ, p->gZ, b.Kzz, Mp, mm, p->jitter, 1,
-                              GPZ_F64, s))
+                              GPZ_F64, s, p->info))
       return rc;
-    if (int rc = potrf_padded(b.Kzz, Mp, Mp, mm, L, M, b.Dinv, p->info, s)) return rc;
+    if (int rc = potrf_padded(b.Kzz, Mp, Mp, mm, L, M, b.Dinv, p->info, s, false)) return rc;
     hipLaunchKernelGGL((chol_out_kernel<T>), dim3(p->chol ? 64 : 1, L32), dim3(256), 0, s, b.Kzz, Mp, M,
                        static_cast<T*>(p->chol), b.chol_logdiag);
     GPZ_LAUNCH_OK();
@@ -417,7 +416,6 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
       GPZ_LAUNCH_OK();
     }
   } else {
-    GPZ_HIP_OK(hipMemsetAsync(p->info, 0, sizeof(int32_t) * L, s));
     if (p->chol) {
       hipLaunchKernelGGL((chol_out_kernel<T>), dim3(64, L32), dim3(256), 0, s, b.Kzz, Mp, M, static_cast<T*>(p->chol),
                          b.chol_logdiag);
@@ -480,7 +478,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     prof_begin(PROF_KFILL, s);
     if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
                               p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
-                              pl.f32 ? GPZ_F32 : GPZ_F64, s))
+                              pl.f32 ? GPZ_F32 : GPZ_F64, s, p->info))
       return rc;
     prof_end(PROF_KFILL, s);
     GemmParams<T> g1;  // Wt = Linv * Kzx, with colsum(Wt^2) and muE^T Wt
@@ -1117,6 +1115,99 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   return 0;
 }
 
+// ---- backward of WSVGP.forward_precomputed (gp.py:308-322 under loss.backward()) ----
+// W is the caller's constant; gradients go to mu, the raw Lu and sigma (Kxx = sigma^2):
+//   d/dmu = W^T gm,   d/dLu = tril(W^T-chunk (P diag(gv2))^T) with P = Lu^T W^T,   d/dsigma = sigma sum_n gv2_n [unclamped]
+template <typename T>
+struct PreBwdBuffers { T *Pc, *G, *cs, *csc; double *mu_part, *mu_sum, *sig_direct; size_t bytes; };
+template <typename T>
+static PreBwdBuffers<T> pre_carve_bwd(const PrePlan& pl, int64_t L, void* ws, size_t offset) {
+  PreBwdBuffers<T> b;
+  Carver c(ws);
+  c.off = offset;
+  b.Pc = c.take<T>(L * pl.Mp * pl.nc);
+  b.G = c.take<T>(L * pl.Mp * pl.Mp);
+  b.cs = c.take<T>(L * pl.nc);
+  b.csc = c.take<T>(L * pl.nc);
+  b.mu_part = c.take<double>(L * pl.nchunks * pl.Mp);
+  b.mu_sum = c.take<double>(L * pl.Mp);
+  b.sig_direct = c.take<double>(L);
+  b.bytes = c.used();
+  return b;
+}
+
+__global__ void copy_f64_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+template <typename T>
+static int precomputed_backward_t(const void* W, const void* sigma, const void* mu, const void* Lu_raw, int64_t L,
+                                  int64_t N, int64_t M, const void* g_mean, const void* g_scale, const void* scale,
+                                  void* grad_mu, void* grad_Lu_raw, double* grad_sigma, void* ws, size_t ws_bytes,
+                                  hipStream_t s) {
+  const PrePlan pl = pre_plan(L, N, M, sizeof(T));
+  PreBuffers<T> b = pre_carve<T>(pl, L, ws);
+  PreBwdBuffers<T> w = pre_carve_bwd<T>(pl, L, ws, b.bytes);
+  GPZ_REQUIRE(ws_bytes >= w.bytes, "gpz_wsvgp_precomputed_backward: workspace too small");
+  const int L32 = (int)L;
+  const int64_t Mp = pl.Mp, mm = Mp * Mp;
+  hipLaunchKernelGGL((lu_prepare_kernel<T>), dim3((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32), dim3(256), 0, s,
+                     static_cast<const T*>(Lu_raw), M, Mp, b.LuT, (double*)nullptr, (T*)nullptr, b.lu_part);
+  GPZ_LAUNCH_OK();
+  GPZ_HIP_OK(hipMemsetAsync(w.G, 0, sizeof(T) * L * mm, s));
+  GPZ_HIP_OK(hipMemsetAsync(w.sig_direct, 0, sizeof(double) * L, s));
+  for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
+    const int64_t n0 = ci * pl.nc;
+    const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
+    const int64_t ncp = pad_up(nreal);
+    hipLaunchKernelGGL((w_transpose_kernel<T>), dim3((unsigned)(ncp / 32), (unsigned)(Mp / 32), L32), dim3(256), 0, s,
+                       static_cast<const T*>(W), N, M, n0, Mp, ncp, b.Wc);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL((w_rowstats_kernel<T>), dim3((unsigned)((ncp + 3) / 4), L32), dim3(256), 0, s,
+                       static_cast<const T*>(W), static_cast<const T*>(mu), N, M, n0, ncp, b.ps1, b.pm1);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL((colscale_kernel<T>), dim3((unsigned)((ncp + 255) / 256), L32), dim3(256), 0, s,
+                       static_cast<const T*>(g_scale), static_cast<const T*>(scale), N, n0, ncp, 1, 0.0, w.cs,
+                       (const T*)nullptr, (const T*)b.ps1, 1, static_cast<const T*>(sigma), w.csc, (T*)nullptr);
+    GPZ_LAUNCH_OK();
+    GemmParams<T> g2;  // Pbar = (Lu^T Wt) diag(gv2)
+    g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+    g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+    g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
+    g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = (int)(ncp / NB); g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+    g2.super_cols = 16; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
+    if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
+    GemmParams<T> g3;  // G += Wt Pbar^T  (lower tiles)
+    g3.A = b.Wc; g3.lda = ncp; g3.sA0 = Mp * ncp;
+    g3.B = w.Pc; g3.ldb = ncp; g3.sB0 = Mp * ncp;
+    g3.C = w.G; g3.ldc = Mp; g3.sC0 = mm;
+    g3.nb0 = L32; g3.mt = g3.nt = (int)pl.nblk; g3.K = (int)ncp; g3.flags = GF_B_TRANS | GF_TILES_LOWER;
+    g3.alpha = 1; g3.beta = 1;
+    if (int rc = gemm_launch(g3, EPI_STORE, s)) return rc;
+    hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Wc, Mp, ncp,
+                       static_cast<const T*>(g_mean), N, n0, w.mu_part, pl.nchunks, ci);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL((sigma_direct_kernel<T>), dim3(L32), dim3(256), 0, s, w.csc, ncp, static_cast<const T*>(sigma),
+                       w.sig_direct);
+    GPZ_LAUNCH_OK();
+  }
+  hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.mu_part, pl.nchunks,
+                     Mp, w.mu_sum);
+  GPZ_LAUNCH_OK();
+  hipLaunchKernelGGL((mu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, w.mu_sum,
+                     (const double*)nullptr, Mp, M, static_cast<T*>(grad_mu), (const double*)nullptr, static_cast<const T*>(mu));
+  GPZ_LAUNCH_OK();
+  hipLaunchKernelGGL((lu_grad_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)M, L32), dim3(256), 0, s, w.G, Mp, M,
+                     static_cast<const T*>(Lu_raw), static_cast<T*>(grad_Lu_raw), (const double*)nullptr, 0);
+  GPZ_LAUNCH_OK();
+  if (grad_sigma) {
+    hipLaunchKernelGGL(copy_f64_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, w.sig_direct, grad_sigma, L32);
+    GPZ_LAUNCH_OK();
+  }
+  return 0;
+}
+
 static int check_problem(const gpz_svgp_problem* p) {
   GPZ_REQUIRE(p, "gpz_svgp: null problem");
   GPZ_REQUIRE(p->dtype == GPZ_F32 || p->dtype == GPZ_F64, "gpz_svgp: bad dtype %d", p->dtype);
@@ -1163,6 +1254,28 @@ extern "C" int gpz_wsvgp_precomputed(const void* W, const void* sigma, const voi
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == GPZ_F32 ? precomputed_t<float>(W, sigma, mu, Lu_raw, L, N, M, mean, scale, Lu, ws, ws_bytes, s)
                           : precomputed_t<double>(W, sigma, mu, Lu_raw, L, N, M, mean, scale, Lu, ws, ws_bytes, s);
+}
+
+extern "C" size_t gpz_wsvgp_precomputed_backward_workspace_bytes(int64_t L, int64_t N, int64_t M, int32_t dtype) {
+  if (L < 1 || N < 1 || M < 1) return 0;
+  const PrePlan pl = pre_plan(L, N, M, dtype == GPZ_F32 ? 4 : 8);
+  return dtype == GPZ_F32 ? pre_carve_bwd<float>(pl, L, nullptr, pre_carve<float>(pl, L, nullptr).bytes).bytes
+                          : pre_carve_bwd<double>(pl, L, nullptr, pre_carve<double>(pl, L, nullptr).bytes).bytes;
+}
+
+extern "C" int gpz_wsvgp_precomputed_backward(const void* W, const void* sigma, const void* mu, const void* Lu_raw,
+                                              int64_t L, int64_t N, int64_t M, int32_t dtype, const void* g_mean,
+                                              const void* g_scale, const void* scale, void* grad_mu, void* grad_Lu_raw,
+                                              double* grad_sigma, void* ws, size_t ws_bytes, void* stream) {
+  GPZ_REQUIRE(W && sigma && mu && Lu_raw && g_mean && g_scale && scale && grad_mu && grad_Lu_raw && ws,
+              "gpz_wsvgp_precomputed_backward: null pointer");
+  GPZ_REQUIRE(L >= 1 && N >= 1 && M >= 1, "gpz_wsvgp_precomputed_backward: bad extents");
+  GPZ_REQUIRE(dtype == GPZ_F32 || dtype == GPZ_F64, "gpz_wsvgp_precomputed_backward: bad dtype");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == GPZ_F32 ? precomputed_backward_t<float>(W, sigma, mu, Lu_raw, L, N, M, g_mean, g_scale, scale, grad_mu,
+                                                          grad_Lu_raw, grad_sigma, ws, ws_bytes, s)
+                          : precomputed_backward_t<double>(W, sigma, mu, Lu_raw, L, N, M, g_mean, g_scale, scale, grad_mu,
+                                                           grad_Lu_raw, grad_sigma, ws, ws_bytes, s);
 }
 
 extern "C" size_t gpz_svgp_backward_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk) {

@@ -28,11 +28,8 @@
 
 namespace gpz {
 
-int kfill_padded(const gpz_kernel_desc* k, const void* A, int64_t nA, int64_t pA, const void* B, int64_t nB,
-                 int64_t pB, int d, const int64_t* gA, const int64_t* gB, void* K, int64_t ldk, int64_t stride,
-                 double jitter, int pad_identity, int out_dtype, hipStream_t s);
 int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                 int32_t* info, hipStream_t s);
+                 int32_t* info, hipStream_t s, bool clear_info = true);
 int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* Dinv, double* Linv, int64_t Mp,
                  int64_t batch, double* T, hipStream_t s);
 
@@ -50,14 +47,30 @@ int kgrad_launch(int dtype, int kind, const KgradArgs& a, int L, hipStream_t s);
 
 constexpr int KNN_MAX = 32;
 
-template <typename T, int KM>
+// v*v rounded on its own (x.pow(2) in the reference is a separate op): kept out of fma contraction
+__device__ __forceinline__ float __fmul_or(float v) { return __fmul_rn(v, v); }
+__device__ __forceinline__ double __fmul_or(double v) { return __dmul_rn(v, v); }
+
+// MM: rank by the distances torch.cdist produces on its matmul-expansion path (the one the reference takes whenever
+// either point set has more than 25 rows: kernels.py:118 -> cdist -> _euclidean_dist): with xn = sum_k x_k^2 and
+// zn = sum_k z_k^2 (squares rounded, then added in order), d^2 = the dot product of [-2x, xn, 1] and [z, 1, zn]
+// accumulated as a k-ordered fma chain from zero (what the CPU GEMM does for this 4..6-long inner dimension; verified
+// bit for bit against torch 2.10 fp32 on 2M pairs), clamped at 1e-30, then sqrt.  In fp32 at |x| <= 100 these differ
+// from the true distances by up to 0.06, so near-ties order differently than with direct differences:
+// the neighbour TABLE is index bookkeeping and has to follow the reference's arithmetic, not the better one.
+template <typename T, int KM, bool MM>
 __global__ __launch_bounds__(256) void knn_kernel(const T* __restrict__ X, int64_t N, const T* __restrict__ Z, int64_t M,
                                                  int d, int K, int64_t* __restrict__ idx) {
   __shared__ T sz[256 * 4];
+  __shared__ T szn[256];
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   T x[4] = {0, 0, 0, 0};
   if (n < N)
     for (int k = 0; k < d; ++k) x[k] = X[n * d + k];
+  T xn = 0, xm2[4];
+  for (int k = 0; k < 4; ++k) xm2[k] = (T)-2 * x[k];
+  if (MM)
+    for (int k = 0; k < d; ++k) xn = (k == 0) ? __fmul_or(x[k]) : xn + __fmul_or(x[k]);
   T bd[KM];
   int bi[KM];
 #pragma unroll
@@ -66,11 +79,25 @@ __global__ __launch_bounds__(256) void knn_kernel(const T* __restrict__ X, int64
     __syncthreads();
     const int cnt = (int)((M - m0 < 256) ? M - m0 : 256);
     for (int i = threadIdx.x; i < cnt * d; i += 256) sz[i] = Z[m0 * d + i];
+    if (MM && (int)threadIdx.x < cnt) {
+      T zn = 0;
+      for (int k = 0; k < d; ++k) { const T zk = Z[(m0 + threadIdx.x) * d + k]; zn = (k == 0) ? __fmul_or(zk) : zn + __fmul_or(zk); }
+      szn[threadIdx.x] = zn;
+    }
     __syncthreads();
     for (int c = 0; c < cnt; ++c) {
-      T d2 = 0;
-      for (int k = 0; k < d; ++k) { const T df = x[k] - sz[c * d + k]; d2 = fma(df, df, d2); }
-      const T dist = sqrt(d2);                       // the reference ranks cdist's distances
+      T dist;
+      if (MM) {
+        T acc = 0;
+        for (int k = 0; k < d; ++k) acc = fma(xm2[k], sz[c * d + k], acc);
+        acc = fma(xn, (T)1, acc);
+        acc = fma((T)1, szn[c], acc);
+        dist = sqrt(acc > (T)1e-30 ? acc : (T)1e-30);
+      } else {
+        T d2 = 0;
+        for (int k = 0; k < d; ++k) { const T df = x[k] - sz[c * d + k]; d2 = fma(df, df, d2); }
+        dist = sqrt(d2);                             // the reference ranks cdist's distances
+      }
       if (dist < bd[KM - 1]) {
         bd[KM - 1] = dist; bi[KM - 1] = (int)(m0 + c);
 #pragma unroll
@@ -323,8 +350,16 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
 template <typename T>
 static int knn_t(const void* X, int64_t N, const void* Z, int64_t M, int d, int K, int64_t* idx, hipStream_t s) {
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
-#define GPZ_KNN(KM) hipLaunchKernelGGL((knn_kernel<T, KM>), grid, block, 0, s, static_cast<const T*>(X), N, \
-                                       static_cast<const T*>(Z), M, d, K, idx)
+  // torch.cdist (compute mode "use_mm_for_euclid_dist_if_necessary", the default the reference gets) takes the
+  // matmul-expansion path when either side has more than 25 rows and plain differences otherwise
+  const bool mm = N > 25 || M > 25;
+#define GPZ_KNN(KM)                                                                                                   \
+  do {                                                                                                                \
+    if (mm) hipLaunchKernelGGL((knn_kernel<T, KM, true>), grid, block, 0, s, static_cast<const T*>(X), N,             \
+                               static_cast<const T*>(Z), M, d, K, idx);                                               \
+    else hipLaunchKernelGGL((knn_kernel<T, KM, false>), grid, block, 0, s, static_cast<const T*>(X), N,               \
+                            static_cast<const T*>(Z), M, d, K, idx);                                                  \
+  } while (0)
   // a sorted list of KM >= K entries keeps the K smallest in its first K slots
   if (K <= 4) GPZ_KNN(4); else if (K <= 8) GPZ_KNN(8); else if (K <= 16) GPZ_KNN(16); else GPZ_KNN(32);
 #undef GPZ_KNN

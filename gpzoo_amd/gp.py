@@ -22,14 +22,7 @@ from torch import distributions
 from torch.distributions import constraints
 
 from . import ops
-from .kernels import kernel_spec
-
-
-def _like(grad_l: torch.Tensor, param: torch.Tensor) -> torch.Tensor:
-    """Per-latent gradient (L,) -> the parameter's own shape: (), (L,) or (L,1,1)."""
-    if param.numel() == 1:
-        return grad_l.sum().reshape(param.shape).to(param.dtype)
-    return grad_l.reshape(param.shape).to(param.dtype)
+from .kernels import _like, kernel_spec
 
 
 class _QFMoments(torch.autograd.Function):
@@ -70,6 +63,28 @@ class _QFMoments(torch.autograd.Function):
             if ctx.has_group:
                 grads[5] = _like(gth[:, 2], group_param) * ctx.call["group_chain"]
         return tuple(grads)
+
+
+class _PrecomputedMoments(torch.autograd.Function):
+    """(mean, scale) of WSVGP.forward_precomputed as a differentiable function of mu, the raw Lu and sigma
+    (reference gp.py:308-322 under autograd); W is the caller's constant."""
+
+    @staticmethod
+    def forward(ctx, W, sigma, mu, Lu_raw):
+        out = ops.wsvgp_precomputed(W, sigma, mu, Lu_raw)
+        ctx.save_for_backward(W, sigma, mu, Lu_raw, out["scale"])
+        return out["mean"], out["scale"]
+
+    @staticmethod
+    def backward(ctx, g_mean, g_scale):
+        W, sigma, mu, Lu_raw, scale = ctx.saved_tensors
+        g_mean = torch.zeros_like(scale) if g_mean is None else g_mean
+        g_scale = torch.zeros_like(scale) if g_scale is None else g_scale
+        gmu, gLu, gsig = ops.wsvgp_precomputed_backward(W, sigma, mu, Lu_raw, g_mean, g_scale, scale)
+        L = gmu.shape[0]
+        if mu.numel() != gmu.numel():          # one q(U) shared by the L rows of W
+            gmu, gLu = gmu.sum(0), gLu.sum(0)
+        return None, _like(gsig, sigma) if ctx.needs_input_grad[1] else None, gmu.reshape(mu.shape), gLu.reshape(Lu_raw.shape)
 
 
 class _FusedQU(distributions.MultivariateNormal):
@@ -124,16 +139,13 @@ class _FusedGP(nn.Module):
         return 1 if self.mu.dim() == 1 else int(self.mu.shape[0])
 
     def _cache_args(self, spec, X) -> dict:
-        """Factor cache keyed on everything chol(Kzz) depends on (identity + in-place version of Z and
-        the kernel tensors, jitter, dtype): frozen hyper-parameters => one factorisation per model,
-        not one per step.  ``gp.cache_factor = False`` restores the
-        reference's recompute-every-call behaviour."""
+        """Factor cache validated by the CONTENT of everything chol(Kzz) depends on (Z, the kernel tensors,
+        the group table, groupsZ, jitter, dtype -- ``ops.FactorCache``): frozen hyper-parameters => one
+        factorisation per model, not one per step; any edit, also through ``.data``,
+        refactors.  ``gp.cache_factor = False`` restores the reference's recompute-every-call behaviour."""
         if not getattr(self, "cache_factor", True):
             return {}
-        cache = self.__dict__.setdefault("_factor_cache", ops.FactorCache())
-        deps = [self.Z, *self.kernel.parameters(), getattr(self.kernel, "embedding", None),
-                getattr(self, "groupsZ", None)]
-        return dict(cache=cache, cache_key=ops.factor_key(spec, self.Z, self.jitter, X.dtype, deps))
+        return dict(cache=self.__dict__.setdefault("_factor_cache", ops.FactorCache()))
 
     def _evaluate(self, X, groupsX=None, y=None, noise_sd=None, want_moments=True, want_Lu=True,
                   want_chol=False, chunk=0):
@@ -321,9 +333,18 @@ class WSVGP(_FusedGP):
         return self._forward(X, args.get('groupsX'), verbose)
 
     def forward_precomputed(self, W, **args):
-        """q(F) from a caller-supplied W (L,N,M) (gp.py:308-322)."""
-        out = ops.wsvgp_precomputed(W, self.kernel.sigma, self.mu, self.Lu)
-        return self._distributions(out)
+        """q(F) from a caller-supplied W (L,N,M) (gp.py:308-322); differentiable w.r.t. mu, Lu and the kernel's
+        sigma like the reference's expression (gpz_wsvgp_precomputed_backward).  W itself is a constant here."""
+        trainable = (self.mu, self.Lu, self.kernel.sigma)
+        if not (torch.is_grad_enabled() and any(t.requires_grad for t in trainable)):
+            return self._distributions(ops.wsvgp_precomputed(W, self.kernel.sigma, self.mu, self.Lu))
+        if W.requires_grad:
+            raise NotImplementedError("forward_precomputed treats W as a constant: detach it (gradients w.r.t. the kernel "
+                                      "hyper-parameters and Z flow through forward())")
+        mean, scale = _PrecomputedMoments.apply(W, self.kernel.sigma, self.mu, self.Lu)
+        Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
+        pick = (lambda t: t[0]) if self.mu.dim() == 1 else (lambda t: t)
+        return distributions.Normal(pick(mean), pick(scale)), _FusedQU(self.mu, scale_tril=Lu, validate_args=False), None
 
 
 class SVGP(_FusedGP):

@@ -13,8 +13,12 @@ Deviations from the reference at HEAD, all documented in SURVEY.md §8a:
   * ``NSF_RBF(L=1).forward(diag=True)`` returns ``(1, N)`` instead of raising;
   * squared distances are formed by direct differencing (more accurate than
     cdist's / _squared_dist's matmul expansion in fp32).
-``forward`` itself returns plain tensors; gradients w.r.t. sigma / lengthscale / group_diff_param / Z
-flow through the GP modules' fused backward (gp.py), not through these standalone matrices.
+``forward`` is differentiable like the reference's traced modules (kernels.py:114-130, 139-155, 176-228):
+``kernel(X, Z).sum().backward()`` sends gradients to sigma, lengthscale, group_diff_param, X and Z through
+``gpz_kgrad`` (csrc/kgrad.hip), so notebook code that builds its own model from kernel matrices (the
+inline ExactGP of exact_mggp.ipynb) trains.  The GP modules do not use this route: their fused
+backward (gp.py) differentiates the whole pass.  The distance matrix of ``return_distance=True`` is a
+constant (the reference only sorts it, gp.py:64).
 """
 from __future__ import annotations
 
@@ -27,11 +31,54 @@ from .utilities import _embed_distance_matrix
 
 
 def _sq(v: torch.Tensor, n: int) -> torch.Tensor:
-    """sigma^2 broadcast over n points: (n,) for a scalar parameter, (L, n) otherwise."""
-    s2 = v.detach().reshape(-1) ** 2
+    """sigma^2 broadcast over n points: (n,) for a scalar parameter, (L, n) otherwise (differentiable)."""
+    s2 = v.reshape(-1) ** 2
     if v.dim() == 0:
         return s2.expand(n)
     return s2[:, None].expand(-1, n)
+
+
+def _like(grad_l: torch.Tensor, param: torch.Tensor) -> torch.Tensor:
+    """Per-latent gradient (L,) -> the parameter's own shape: (), (L,) or (L,1,1)."""
+    if param.numel() == 1:
+        return grad_l.sum().reshape(param.shape).to(param.dtype)
+    return grad_l.reshape(param.shape).to(param.dtype)
+
+
+class _KernelMatrix(torch.autograd.Function):
+    """K = kernel(A, B) as a differentiable function of A, B, sigma, lengthscale and the group parameter:
+    forward = gpz_kfill, backward = gpz_kgrad (one contraction per point set that needs a gradient)."""
+
+    @staticmethod
+    def forward(ctx, A, B, sigma, lengthscale, group_param, meta):
+        ctx.meta = meta
+        ctx.save_for_backward(A, B, sigma, lengthscale, group_param if group_param is not None else A.new_empty(0))
+        return ops.kfill(meta["spec"], A, B, gA=meta.get("gA"), gB=meta.get("gB"))
+
+    @staticmethod
+    def backward(ctx, gK):
+        A, B, sigma, lengthscale, group_param = ctx.saved_tensors
+        m = ctx.meta
+        spec, gA, gB = m["spec"], m.get("gA"), m.get("gB")
+        gK3 = gK.reshape(spec.L, A.shape[0], B.shape[0])
+        need_A, need_B = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gth, gpa = ops.kgrad(spec, A, B, gK3, gA, gB, want_points=need_A)
+        gpb = None
+        if need_B:
+            _, gpb = ops.kgrad(spec, B.to(A.dtype), A, gK3.transpose(-1, -2), gB, gA)
+        grads = [gpa.to(A.dtype) if need_A else None, gpb.to(B.dtype) if need_B else None,
+                 _like(gth[:, 0], sigma) if ctx.needs_input_grad[2] else None,
+                 _like(gth[:, 1], lengthscale) if ctx.needs_input_grad[3] else None, None, None]
+        if m.get("chain") is not None and ctx.needs_input_grad[4]:
+            grads[4] = _like(gth[:, 2], group_param) * m["chain"]
+        return tuple(grads)
+
+
+def _kernel_matrix(spec: KernelSpec, A, B, sigma, lengthscale, group_param=None, chain=None, gA=None, gB=None):
+    ts = [A, B, sigma, lengthscale] + ([group_param] if group_param is not None else [])
+    if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+        return _KernelMatrix.apply(A, B, sigma, lengthscale, group_param, dict(spec=spec, gA=gA, gB=gB, chain=chain))
+    return ops.kfill(spec, A, B, gA=gA, gB=gB)
 
 
 class _HipKernel(nn.Module):
@@ -46,7 +93,7 @@ class _HipKernel(nn.Module):
     def forward(self, X, Z, diag=False, return_distance=False):
         if diag:
             return _sq(self.sigma, X.size(0))
-        K = ops.kfill(self._spec(), X, Z)
+        K = _kernel_matrix(self._spec(), X, Z, self.sigma, self.lengthscale)
         if return_distance:
             return K, ops.pairwise_distance(X, Z)
         return K
@@ -137,7 +184,8 @@ class _MGGPMixin:
     def _mggp_forward(self, X, Z, groupsX, groupsZ, diag=False):
         if diag:
             return _sq(self.sigma, X.size(0))
-        return ops.kfill(self._mggp_spec(X), X, Z, gA=groupsX, gB=groupsZ)
+        return _kernel_matrix(self._mggp_spec(X), X, Z, self.sigma, self.lengthscale, self.group_diff_param,
+                              self._group_a_chain(), gA=groupsX, gB=groupsZ)
 
 
 class MGGP_RBF(_MGGPMixin, RBF):

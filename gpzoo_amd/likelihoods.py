@@ -3,7 +3,9 @@
 Thin consumers of the hot path's outputs (they stay torch):
 ``forward`` calls the GP once -- one fused HIP pass -- and wraps the result in
 torch distributions exactly like reference likelihoods.py:7-36.  The Poisson
-factor models of the reference are outside the path (SURVEY §8f "next" #2).
+factor models (SURVEY §8f "next" #2) follow below: same classes and return tuples
+as the reference, plus ``expected_loglik`` -- the fused fp32 training-step form
+(``gpz_poisson_nsf``; fp64 models are evaluated in fp32 there and cast back).
 """
 from __future__ import annotations
 
@@ -190,6 +192,18 @@ class MGGP_NSF(NSF):
     def forward_batched(self, X, groupsX, idx, E=10, verbose=False):
         qF, qU, pU = self._gp(X[idx], groupsX[idx], verbose)
         return distributions.Poisson(self._rate(qF, torch.nn.functional.softplus(self.V)[idx], E)), qF, qU, pU
+
+    def expected_loglik(self, X, y, groupsX=None, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
+        """Fused training-step form; the group ids follow the sampled spots (``groupsX[idx]``, as in
+        ``forward_batched`` / reference likelihoods.py:364-366)."""
+        if groupsX is None:
+            raise TypeError("MGGP_NSF.expected_loglik needs groupsX")
+        Xb, gb = (X, groupsX) if idx is None else (X[idx], groupsX[idx])
+        V = torch.nn.functional.softplus(self.V)
+        qF, qU, pU = self._gp(Xb, gb, False)
+        ll = poisson_expected_loglik([qF], [torch.nn.functional.softplus(self.W)], V if idx is None else V[idx], y,
+                                     E=E, with_lgamma=with_lgamma, eps=eps)
+        return ll, qF, qU, pU
 
 
 class Hybrid_NSF2(nn.Module):

@@ -50,8 +50,46 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device: torch.device):
+    """torch's current stream ON THE TENSORS' DEVICE (not the process-wide current device)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _same_device(*ts) -> torch.device:
+    """All tensor arguments must be CUDA tensors of ONE device; returns it.  The library's launches,
+    memsets and event records go to the current HIP device, so every entry point runs under
+    ``torch.cuda.device(dev)`` with this device (a model moved with ``.to('cuda:1')`` while the process's
+    current device is 0 would otherwise launch on GPU 0 against GPU-1 pointers)."""
+    dev = None
+    for t in ts:
+        if t is None or not isinstance(t, torch.Tensor) or not t.is_floating_point():
+            continue                       # integer group ids / index tables are moved by the wrappers
+        if not t.is_cuda:
+            raise RuntimeError("gpzoo_amd computes on the GPU only (HIP kernels, no CPU fallback): "
+                               "move the model and inputs to a cuda device")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"gpzoo_amd: tensor arguments live on different devices ({dev} and {t.device})")
+    if dev is None:
+        raise RuntimeError("gpzoo_amd: no tensor argument to take the device from")
+    return dev
+
+
+def _on_device(fn):
+    """Decorator: validate that every tensor argument shares one CUDA device and make it current for the call."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        flat = [a for a in args if isinstance(a, torch.Tensor)] + [v for v in kwargs.values() if isinstance(v, torch.Tensor)]
+        for a in args:
+            if isinstance(a, KernelSpec):
+                flat += [a.sigma, a.lengthscale, a.group_a, a.group_r2]
+        dev = _same_device(*flat)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 _workspaces: dict = {}
@@ -93,6 +131,7 @@ def _desc(spec: KernelSpec, dtype: torch.dtype, keep: list) -> KernelDesc:
     return d
 
 
+@_on_device
 def kfill(spec: KernelSpec, A: torch.Tensor, B: torch.Tensor, gA=None, gB=None, jitter: float = 0.0,
           out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """K[l,i,j] = k_l(A_i, B_j): (L,nA,nB), or (nA,nB) for scalar-parameter kernels."""
@@ -105,23 +144,69 @@ def kfill(spec: KernelSpec, A: torch.Tensor, B: torch.Tensor, gA=None, gB=None, 
         raise ValueError(f"expected (n,d) inputs with equal d, got {tuple(A.shape)} and {tuple(B.shape)}")
     d = _desc(spec, A.dtype, keep)
     if spec.kind == _lib.KERNEL_MGGP_RBF:
-        gA = gA.detach().to(device=A.device, dtype=torch.int64).contiguous()
-        gB = gB.detach().to(device=A.device, dtype=torch.int64).contiguous()
+        gA, gB = _group_ids(gA, A.shape[0], A.device, "groupsX"), _group_ids(gB, B.shape[0], A.device, "groupsZ")
+        G = int(spec.group_r2.shape[0])
+        for g_ in (gA, gB):     # stand-alone call: checked on the host (the fused pass flags it on the device)
+            if g_.numel() and bool(((g_ < 0) | (g_ >= G)).any()):
+                raise IndexError("index out of range in self: a group id is outside [0, n_groups)")
     else:
         gA = gB = None
     odt = A.dtype if out_dtype is None else out_dtype
     nA, nB = A.shape[0], B.shape[0]
     K = torch.empty((spec.L, nA, nB), dtype=odt, device=A.device)
     rc = lib.gpz_kfill(C.byref(d), _ptr(A), nA, _ptr(B), nB, A.shape[1], _ptr(gA), _ptr(gB), _ptr(K), nB,
-                       nA * nB, float(jitter), _dt(K), _stream())
+                       nA * nB, float(jitter), _dt(K), _stream(A.device))
     _lib.check(rc, "gpz_kfill")
     return K if spec.batched else K[0]
+
+
+@_on_device
+def kgrad(spec: KernelSpec, A: torch.Tensor, B: torch.Tensor, Kbar: torch.Tensor, gA=None, gB=None,
+          want_points: bool = True):
+    """Backward of ``kfill`` (gpz_kgrad): Kbar = dLoss/dK of shape (L,nA,nB) -> (grad_theta (L,3) fp64 =
+    d/d(sigma, lengthscale, effective group multiplier), grad_A (nA,d) fp64 or None)."""
+    lib = _lib.load()
+    keep: list = []
+    A = A.detach().contiguous()
+    B = B.detach().to(A.dtype).contiguous()
+    d = _desc(spec, A.dtype, keep)
+    nA, nB, L = A.shape[0], B.shape[0], spec.L
+    Kbar = Kbar.detach().to(A.dtype).reshape(L, nA, nB).contiguous()
+    if spec.kind == _lib.KERNEL_MGGP_RBF:
+        gA, gB = _group_ids(gA, nA, A.device, "groupsX"), _group_ids(gB, nB, A.device, "groupsZ")
+    else:
+        gA = gB = None
+    gth = torch.empty((L, 4), dtype=torch.float64, device=A.device)
+    gpt = torch.empty((nA, 4), dtype=torch.float64, device=A.device) if want_points else None
+    nbytes = lib.gpz_kgrad_workspace_bytes(nA, L)
+    ws = _workspace(A.device, nbytes)
+    rc = lib.gpz_kgrad(C.byref(d), _ptr(A), nA, _ptr(B), nB, A.shape[1], _ptr(gA), _ptr(gB), _ptr(Kbar), nB, nA * nB,
+                       _ptr(gth), _ptr(gpt), _ptr(ws), ws.numel(), _stream(A.device))
+    _lib.check(rc, "gpz_kgrad")
+    return gth[:, :3], (gpt[:, :A.shape[1]] if want_points else None)
 
 
 def pairwise_distance(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """Euclidean distances (nA,nB) -- what RBF.forward(return_distance=True) hands back."""
     one = torch.ones(1, dtype=A.dtype, device=A.device)
     return kfill(KernelSpec(_lib.KERNEL_DISTANCE, one, one, False), A, B)
+
+
+def _group_ids(g, n: int, dev, name: str) -> torch.Tensor:
+    """int64 group ids on the device, one per point (reference kernels.py:99-100, 177-178, 209-210 index the
+    embedding with them: a wrong length or an id outside [0, n_groups) raises there, and here)."""
+    g = g.detach().to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+    if g.numel() != n:
+        raise IndexError(f"{name} has {g.numel()} entries for {n} points")
+    return g
+
+
+def _raise_info(info: torch.Tensor, what: str):
+    """LAPACK convention: info > 0 = not positive-definite (order of the failing minor), info < 0 = an argument
+    was illegal -- here: a group id outside [0, n_groups), flagged by the covariance fill on the device."""
+    if bool((info < 0).any()):
+        raise IndexError("index out of range in self: a group id (groupsX / groupsZ) is outside [0, n_groups)")
+    _raise_not_pd(info, what)
 
 
 def _raise_not_pd(info: torch.Tensor, what: str):
@@ -134,99 +219,130 @@ def _raise_not_pd(info: torch.Tensor, what: str):
         f"positive-definite (the leading minor of order {k} is not positive-definite).")
 
 
+@_on_device
 def cholesky(A: torch.Tensor) -> torch.Tensor:
-    """Lower Cholesky factor of (M,M) or (L,M,M); raises torch.linalg.LinAlgError
-    when a matrix is not positive-definite (what gp.py:213/270/360 callers see)."""
+    """Lower Cholesky factor of (M,M) or (L,M,M), fp32 or fp64 storage (fp64 arithmetic); raises
+    torch.linalg.LinAlgError when a matrix is not positive-definite (what gp.py:213/270/360 callers see)."""
     _need_cuda(A)
     lib = _lib.load()
-    dt = A.dtype
     M = A.shape[-1]
-    W = A.detach().to(torch.float64).reshape(-1, M, M).contiguous().clone()
+    W = A.detach().reshape(-1, M, M).contiguous().clone()
     batch = W.shape[0]
     info = torch.empty(batch, dtype=torch.int32, device=A.device)
     nbytes = lib.gpz_potrf_workspace_bytes(M, batch)
     ws = _workspace(A.device, nbytes)
-    rc = lib.gpz_potrf_batched(_ptr(W), M, M, M * M, batch, _ptr(info), _ptr(ws), ws.numel(), _stream())
+    rc = lib.gpz_potrf_batched(_ptr(W), _dt(W), M, M, M * M, batch, _ptr(info), _ptr(ws), ws.numel(), _stream(A.device))
     _lib.check(rc, "gpz_potrf_batched")
     if bool(info.any()):
         _raise_not_pd(info, "linalg.cholesky")
-    return W.to(dt).reshape(A.shape)
+    return W.reshape(A.shape)
 
 
+@_on_device
 def solve_triangular_lower(Lc: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
-    """Lc^{-1} B for lower-triangular (.., M, M) and (.., M, N)."""
+    """Lc^{-1} B for lower-triangular (.., M, M) and (.., M, N): blocked forward substitution (gpz_trsm_lln_batched)."""
     _need_cuda(Lc, B)
     lib = _lib.load()
-    dt = B.dtype
     M, N = B.shape[-2], B.shape[-1]
-    Lw = Lc.detach().to(torch.float64).reshape(-1, M, M).contiguous()
-    Bw = B.detach().to(torch.float64).reshape(-1, M, N).contiguous().clone()
+    Lw = Lc.detach().to(B.dtype).reshape(-1, M, M).contiguous()
+    Bw = B.detach().reshape(-1, M, N).contiguous().clone()
     batch = Bw.shape[0]
+    if Lw.shape[0] != batch:
+        Lw = Lw.expand(batch, M, M).contiguous()
     nbytes = lib.gpz_trsm_workspace_bytes(M, N, batch)
     ws = _workspace(B.device, nbytes)
-    rc = lib.gpz_trsm_lln_batched(_ptr(Lw), M, M * M, _ptr(Bw), N, M * N, M, N, batch, _ptr(ws), ws.numel(), _stream())
+    rc = lib.gpz_trsm_lln_batched(_ptr(Lw), M, M * M, _ptr(Bw), N, M * N, _dt(Bw), M, N, batch, _ptr(ws), ws.numel(),
+                                  _stream(B.device))
     _lib.check(rc, "gpz_trsm_lln_batched")
-    return Bw.to(dt).reshape(B.shape)
+    return Bw.reshape(B.shape)
 
 
 class FactorCache:
-    """Device buffer for chol(Kzz), its inverse and log-determinant, valid for one key.
+    """Device buffer for chol(Kzz), its inverse and log-determinant, reused while its inputs are unchanged.
 
-    The key is built by the caller from the identities and in-place version counters of every tensor
-    the factor depends on (Z, sigma, lengthscale, group parameters) plus jitter/dtype/shape, so an
-    optimiser step, a parameter replacement or a jitter change invalidates it (SURVEY §8f "next" #3:
-    the reference refactors Kzz every step even when those are frozen)."""
+    Validity is decided by CONTENT, not by tensor identity: next to the factor the cache keeps a byte copy
+    of everything the factor depends on (Z, sigma, lengthscale, effective group multiplier, the group r^2
+    table, groupsZ) and compares it on the device before every use (one concatenation + one ``torch.equal``,
+    a few KB), plus a host key (kernel family, L, exponent, jitter, dtype, shapes).  In-place edits through
+    ``.data`` (``p.data.fill_()``, ``p.data = ...``), re-created Parameters that land on a freed pointer and
+    optimiser steps are therefore all seen (SURVEY §8f "next" #3: the reference refactors Kzz every step even
+    when those are frozen)."""
 
     def __init__(self):
         self.buf = None
         self.key = None
+        self.snap = None
+        self._pending = None
 
-    def attach(self, lib, p: "SvgpProblem", key, device):
+    @staticmethod
+    def fingerprint(tensors) -> torch.Tensor:
+        return torch.cat([t.reshape(-1).view(torch.uint8) for t in tensors if t is not None])
+
+    def attach(self, lib, p: "SvgpProblem", key, device, deps):
         nbytes = lib.gpz_svgp_factor_cache_bytes(C.byref(p))
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self.key = None
+            self.key = self.snap = None
+        fp = self.fingerprint(deps)
+        valid = (self.key == key and self.snap is not None and self.snap.shape == fp.shape
+                 and bool(torch.equal(self.snap, fp)))
         p.factor_cache = self.buf.data_ptr()
-        p.factor_cache_valid = int(self.key == key)
-        self._pending = key
+        p.factor_cache_valid = int(valid)
+        self._pending = (key, fp)
+        return valid
+
+    def invalidate(self):
+        self.key = self.snap = None
 
     def commit(self):
-        self.key = self._pending
+        self.key, self.snap = self._pending
 
 
-def factor_key(spec: "KernelSpec", Z, jitter, dtype, tensors) -> tuple:
-    ids = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors if t is not None)
-    return (spec.kind, spec.L, float(spec.group_pow), float(jitter), str(dtype), tuple(Z.shape), ids)
+def factor_key(spec: "KernelSpec", Z, jitter, dtype) -> tuple:
+    """Host half of the cache key; the tensor contents are compared on the device (FactorCache.attach)."""
+    G = 0 if spec.group_r2 is None else int(spec.group_r2.shape[0])
+    return (spec.kind, spec.L, float(spec.group_pow), float(jitter), str(dtype), tuple(Z.shape), G)
 
 
 def _problem(spec: KernelSpec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep: list):
-    """Fill a gpz_svgp_problem from tensors (inputs only); returns (problem, prepared tensors)."""
+    """Fill a gpz_svgp_problem from tensors (inputs only); returns (problem, (L, M, N, dtype, device, deps)) where
+    ``deps`` are the prepared tensors chol(Kzz) depends on (what FactorCache fingerprints)."""
     dt = X.dtype
+    if X.dim() != 2 or Z.dim() != 2 or X.shape[1] != Z.shape[1]:
+        raise ValueError(f"expected X (N,d) and Z (M,d) with equal d, got {tuple(X.shape)} and {tuple(Z.shape)}")
     X = X.detach().contiguous()
     Z = Z.detach().to(dt).contiguous()
     L = spec.L
     M, N, dim = Z.shape[0], X.shape[0], X.shape[1]
+    if mu.numel() != L * M or Lu_raw.numel() != L * M * M:
+        raise ValueError(f"mu / Lu of shapes {tuple(mu.shape)} / {tuple(Lu_raw.shape)} do not match L={L} latents "
+                         f"and M={M} inducing points")
     mu = mu.detach().to(dt).reshape(L, M).contiguous()
     Lu_raw = Lu_raw.detach().to(dt).reshape(L, M, M).contiguous()
     dev = X.device
     p = SvgpProblem()
+    n0 = len(keep)
     p.k = _desc(spec, dt, keep)
+    deps = [Z] + keep[n0:]
     p.dtype, p.whitened, p.d = _dt(X), int(whitened), dim
     p.N, p.M = N, M
     p.X, p.Z, p.mu, p.Lu_raw = X.data_ptr(), Z.data_ptr(), mu.data_ptr(), Lu_raw.data_ptr()
     if spec.kind == _lib.KERNEL_MGGP_RBF:
-        gX = gX.detach().to(device=dev, dtype=torch.int64).contiguous()
-        gZ = gZ.detach().to(device=dev, dtype=torch.int64).contiguous()
+        if gX is None or gZ is None:
+            raise ValueError("multi-group kernels need groupsX and groupsZ")
+        gX, gZ = _group_ids(gX, N, dev, "groupsX"), _group_ids(gZ, M, dev, "groupsZ")
         p.gX, p.gZ = gX.data_ptr(), gZ.data_ptr()
+        deps.append(gZ)
     p.jitter, p.var_clamp_min = float(jitter), float(clamp_min)
     keep.extend([X, Z, mu, Lu_raw, gX, gZ])
-    return p, (L, M, N, dt, dev)
+    return p, (L, M, N, dt, dev, deps)
 
 
+@_on_device
 def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, *, gX=None, gZ=None,
                  y=None, noise_sd: Optional[float] = None, clamp_min: float = 1e-6, chunk: int = 0,
                  want_moments: bool = True, want_Lu: bool = True, want_chol: bool = False,
-                 check_info: bool = True, cache: Optional[FactorCache] = None, cache_key=None,
+                 check_info: bool = True, cache: Optional[FactorCache] = None,
                  retain_wt: float = 0.0) -> dict:
     """One fused forward pass (gpz_svgp_forward).  Returns a dict with mean, scale
     (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars.
@@ -235,7 +351,7 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     _need_cuda(X, Z, mu, Lu_raw)
     lib = _lib.load()
     keep: list = []
-    p, (L, M, N, dt, dev) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
+    p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
     out = {}
     if y is not None:
         y = y.detach().to(dt).reshape(L, N).contiguous()
@@ -255,7 +371,7 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     p.kl, p.loglik, p.elbo = scal.data_ptr(), scal.data_ptr() + 8 * L, scal.data_ptr() + 16 * L
     p.info = info.data_ptr()
     if cache is not None:
-        cache.attach(lib, p, cache_key, dev)
+        cache.attach(lib, p, factor_key(spec, Z, jitter, dt), dev, deps)
     if retain_wt > 0:
         need = lib.gpz_svgp_wt_cache_bytes(C.byref(p), int(chunk))
         if 0 < need <= retain_wt * torch.cuda.mem_get_info(dev)[0]:
@@ -265,22 +381,25 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     if nbytes == 0:
         _lib.check(-1, "gpz_svgp_workspace_bytes")
     ws = _workspace(dev, nbytes)
-    rc = lib.gpz_svgp_forward(C.byref(p), int(chunk), _ptr(ws), ws.numel(), _stream())
+    rc = lib.gpz_svgp_forward(C.byref(p), int(chunk), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_svgp_forward")
-    if check_info and bool(info.any()):
-        if cache is not None:
-            cache.key = None
-        _raise_not_pd(info, "linalg.cholesky")
     if cache is not None:
-        cache.commit()
+        # a factor that failed must not be reused; without the host check the cache stays uncommitted
+        if not check_info or bool(info.any()):
+            cache.invalidate()
+        else:
+            cache.commit()
+    if check_info and bool(info.any()):
+        _raise_info(info, "linalg.cholesky")
     out["kl"], out["loglik"], out["elbo"] = scal[:L], scal[L:2 * L], scal[2 * L]
     out["info"] = info
     return out
 
 
+@_on_device
 def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
                   gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0, cache: Optional[FactorCache] = None,
-                  cache_key=None, kernel_grads: bool = False, g_chol=None, wt_cache=None, g_kl=None):
+                  kernel_grads: bool = False, g_chol=None, wt_cache=None, g_kl=None):
     """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) (gpz_svgp_backward); with ``kernel_grads`` also
     dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64.
     ``wt_cache``: the buffer a forward pass on the same inputs and ``chunk`` returned under "wt_cache".
@@ -289,7 +408,7 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
     lib = _lib.load()
     keep: list = []
-    p, (L, M, N, dt, dev) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
+    p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
     info = torch.empty(L, dtype=torch.int32, device=dev)
     p.info = info.data_ptr()
     g = _lib.SvgpGrads()
@@ -313,7 +432,7 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
         keep.append(gk)
         g.g_kl = gk.data_ptr()
     if cache is not None:
-        cache.attach(lib, p, cache_key, dev)
+        cache.attach(lib, p, factor_key(spec, Z, jitter, dt), dev, deps)
     if wt_cache is not None:
         if wt_cache.numel() != lib.gpz_svgp_wt_cache_bytes(C.byref(p), int(chunk)):
             raise ValueError("wt_cache does not belong to this problem / chunking")
@@ -322,15 +441,20 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     if nbytes == 0:
         _lib.check(-1, "gpz_svgp_backward_workspace_bytes")
     ws = _workspace(dev, nbytes)
-    rc = lib.gpz_svgp_backward(C.byref(p), C.byref(g), int(chunk), _ptr(ws), ws.numel(), _stream())
+    rc = lib.gpz_svgp_backward(C.byref(p), C.byref(g), int(chunk), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_svgp_backward")
-    if cache is not None:
-        cache.commit()
+    if cache is not None and not p.factor_cache_valid:
+        # the backward refactored (cache miss): keep the result only if the factorisation succeeded
+        if bool(info.any()):
+            cache.invalidate()
+        else:
+            cache.commit()
     if kernel_grads:
         return grad_mu, grad_Lu, gth[:, :3], gz[:, :X.shape[1]]
     return grad_mu, grad_Lu
 
 
+@_on_device
 def wsvgp_precomputed(W, sigma, mu, Lu_raw) -> dict:
     """q(F) moments from a caller-supplied W (L,N,M) or (N,M): WSVGP.forward_precomputed."""
     _need_cuda(W, mu, Lu_raw)
@@ -347,11 +471,39 @@ def wsvgp_precomputed(W, sigma, mu, Lu_raw) -> dict:
     nbytes = lib.gpz_wsvgp_precomputed_workspace_bytes(L, N, M, _dt(W3))
     ws = _workspace(W.device, nbytes)
     rc = lib.gpz_wsvgp_precomputed(_ptr(W3), _ptr(sig), _ptr(mu2), _ptr(Lu3), L, N, M, _dt(W3), _ptr(out["mean"]),
-                                   _ptr(out["scale"]), _ptr(out["Lu"]), _ptr(ws), ws.numel(), _stream())
+                                   _ptr(out["scale"]), _ptr(out["Lu"]), _ptr(ws), ws.numel(), _stream(W.device))
     _lib.check(rc, "gpz_wsvgp_precomputed")
     return out
 
 
+@_on_device
+def wsvgp_precomputed_backward(W, sigma, mu, Lu_raw, g_mean, g_scale, scale):
+    """dLoss/d(mu (L,M), raw Lu (L,M,M), sigma (L,) fp64) of ``wsvgp_precomputed`` (gpz_wsvgp_precomputed_backward);
+    W is a constant of the graph."""
+    lib = _lib.load()
+    dt = W.dtype
+    M = W.shape[-1]
+    W3 = W.detach().reshape(-1, W.shape[-2], M).contiguous()
+    L, N = W3.shape[0], W3.shape[1]
+    mu2 = mu.detach().to(dt).reshape(-1, M).expand(L, M).contiguous()
+    Lu3 = Lu_raw.detach().to(dt).reshape(-1, M, M).expand(L, M, M).contiguous()
+    sig = sigma.detach().to(dt).reshape(-1).expand(L).contiguous()
+    gm = g_mean.detach().to(dt).reshape(L, N).contiguous()
+    gs = g_scale.detach().to(dt).reshape(L, N).contiguous()
+    sc = scale.detach().to(dt).reshape(L, N).contiguous()
+    grad_mu = torch.empty((L, M), dtype=dt, device=W.device)
+    grad_Lu = torch.empty((L, M, M), dtype=dt, device=W.device)
+    grad_sig = torch.empty(L, dtype=torch.float64, device=W.device)
+    nbytes = lib.gpz_wsvgp_precomputed_backward_workspace_bytes(L, N, M, _dt(W3))
+    ws = _workspace(W.device, nbytes)
+    rc = lib.gpz_wsvgp_precomputed_backward(_ptr(W3), _ptr(sig), _ptr(mu2), _ptr(Lu3), L, N, M, _dt(W3), _ptr(gm), _ptr(gs),
+                                            _ptr(sc), _ptr(grad_mu), _ptr(grad_Lu), _ptr(grad_sig), _ptr(ws), ws.numel(),
+                                            _stream(W.device))
+    _lib.check(rc, "gpz_wsvgp_precomputed_backward")
+    return grad_mu, grad_Lu, grad_sig
+
+
+@_on_device
 def knn(X, Z, K: int) -> torch.Tensor:
     """(N,K) int64 indices of the K nearest rows of Z per row of X, ties to the lower index."""
     _need_cuda(X, Z)
@@ -359,18 +511,19 @@ def knn(X, Z, K: int) -> torch.Tensor:
     X = X.detach().contiguous()
     Z = Z.detach().to(X.dtype).contiguous()
     idx = torch.empty((X.shape[0], K), dtype=torch.int64, device=X.device)
-    rc = lib.gpz_knn(_ptr(X), X.shape[0], _ptr(Z), Z.shape[0], X.shape[1], K, _dt(X), _ptr(idx), _stream())
+    rc = lib.gpz_knn(_ptr(X), X.shape[0], _ptr(Z), Z.shape[0], X.shape[1], K, _dt(X), _ptr(idx), _stream(X.device))
     _lib.check(rc, "gpz_knn")
     return idx
 
 
+@_on_device
 def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, clamp_min: float = 5e-2,
                   check_info: bool = True, idx=None) -> dict:
     """VNNGP forward (gpz_vnngp_forward): mean, scale (L,N), Lu, chol (L,M,M), idx (N,K)."""
     _need_cuda(X, Z, mu, Lu_raw)
     lib = _lib.load()
     keep: list = []
-    p, (L, M, N, dt, dev) = _problem(spec, X, Z, mu, Lu_raw, jitter, False, None, None, clamp_min, keep)
+    p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, False, None, None, clamp_min, keep)
     out = {"mean": torch.empty((L, N), dtype=dt, device=dev), "scale": torch.empty((L, N), dtype=dt, device=dev),
            "Lu": torch.empty((L, M, M), dtype=dt, device=dev), "chol": torch.empty((L, M, M), dtype=dt, device=dev)}
     info = torch.empty(L, dtype=torch.int32, device=dev)
@@ -383,13 +536,14 @@ def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, cla
     if nbytes == 0:
         _lib.check(-1, "gpz_vnngp_workspace_bytes")
     ws = _workspace(dev, nbytes)
-    rc = lib.gpz_vnngp_forward(C.byref(p), K, _ptr(out["idx"]), _ptr(ws), ws.numel(), _stream())
+    rc = lib.gpz_vnngp_forward(C.byref(p), K, _ptr(out["idx"]), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_vnngp_forward")
     if check_info and bool(info.any()):
-        _raise_not_pd(info, "linalg.cholesky")
+        _raise_info(info, "linalg.cholesky")
     return out
 
 
+@_on_device
 def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, idx, g_mean, g_scale, *,
                    clamp_min: float = 5e-2, kernel_grads: bool = False, g_chol=None, g_kl=None):
     """dLoss/dmu (L,M), dLoss/dLu_raw (L,M,M) of VNNGP (gpz_vnngp_backward); with ``kernel_grads`` also
@@ -397,7 +551,7 @@ def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, id
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale, idx)
     lib = _lib.load()
     keep: list = []
-    p, (L, M, N, dt, dev) = _problem(spec, X, Z, mu, Lu_raw, jitter, False, None, None, clamp_min, keep)
+    p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, False, None, None, clamp_min, keep)
     info = torch.empty(L, dtype=torch.int32, device=dev)
     p.info = info.data_ptr()
     g = _lib.SvgpGrads()
@@ -424,13 +578,14 @@ def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, id
     if nbytes == 0:
         _lib.check(-1, "gpz_vnngp_backward_workspace_bytes")
     ws = _workspace(dev, nbytes)
-    rc = lib.gpz_vnngp_backward(C.byref(p), C.byref(g), K, _ptr(idx), _ptr(ws), ws.numel(), _stream())
+    rc = lib.gpz_vnngp_backward(C.byref(p), C.byref(g), K, _ptr(idx), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_vnngp_backward")
     if kernel_grads:
         return grad_mu, grad_Lu, gth[:, :2], gz[:, :X.shape[1]]
     return grad_mu, grad_Lu
 
 
+@_on_device
 def poisson_nsf(mean, scale, eps, W_pos, V_pos, y, with_lgamma: bool = True):
     """Fused Monte-Carlo Poisson log-likelihood of the NSF models and its gradients (gpz_poisson_nsf).
 
@@ -458,7 +613,7 @@ def poisson_nsf(mean, scale, eps, W_pos, V_pos, y, with_lgamma: bool = True):
         ws = _workspace(dev, nbytes)
         rc = lib.gpz_poisson_nsf(_ptr(mean), _ptr(scale), _ptr(eps[e0:e0 + ee]), _ptr(W_pos), _ptr(V_pos), _ptr(y), N, D,
                                  Lt, ee, int(with_lgamma and e0 == 0), _ptr(ll), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
-                                 _ptr(out[3]), _ptr(ws), ws.numel(), _stream())
+                                 _ptr(out[3]), _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "gpz_poisson_nsf")
         wgt = ee / E
         total += wgt * ll[0]

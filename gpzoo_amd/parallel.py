@@ -69,9 +69,55 @@ def hip_local_elbo(p: dict) -> torch.Tensor:
     return ll - kl
 
 
-def _allreduce_scalar(e: torch.Tensor, group=None) -> torch.Tensor:
+class AbiCommunicator:
+    """RCCL communicator held through the C ABI (gpz_comm_init / gpz_allreduce_sum_f64, include/gpzoo_hip.h):
+    the exchange a non-Python client of the library uses.  Rank 0 draws the 128-byte id and it travels over an
+    existing torch.distributed group of ANY backend (gloo is enough: it is only a bootstrap), or is given
+    directly for a one-rank communicator.  One per process, bound to ``device``."""
+
+    def __init__(self, device: torch.device, group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib.load(), C
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            _lib.check(self._lib.gpz_comm_unique_id(buf), "gpz_comm_unique_id")
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world > 1:
+            if dist.get_backend(group) == "nccl":
+                ident = ident.to(device)
+            dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(ident.cpu().numpy().tobytes())
+        self.device, self.world, self.rank = device, world, rank
+        self._comm = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self._lib.gpz_comm_init(C.byref(self._comm), world, rank, raw), "gpz_comm_init")
+
+    def allreduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the ranks of a contiguous fp64 CUDA tensor, on torch's current stream."""
+        from . import _lib
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.device == self.device):
+            raise ValueError("AbiCommunicator.allreduce_sum_ needs a contiguous float64 tensor on its device")
+        with torch.cuda.device(self.device):
+            s = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._lib.gpz_allreduce_sum_f64(self._comm, self._C.c_void_p(t.data_ptr()), t.numel(),
+                                                       self._C.c_void_p(s)), "gpz_allreduce_sum_f64")
+        return t
+
+    def close(self):
+        if self._comm:
+            self._lib.gpz_comm_destroy(self._comm)
+            self._comm = self._C.c_void_p()
+
+
+def _allreduce_scalar(e: torch.Tensor, group=None, comm: Optional["AbiCommunicator"] = None) -> torch.Tensor:
     """Sum one fp64 scalar over the ranks: RCCL on the device tensor (backend nccl), or through the host
-    for gloo rehearsals."""
+    for gloo rehearsals; with ``comm`` the C-ABI collective (gpz_allreduce_sum_f64) instead of torch.distributed."""
+    if comm is not None:
+        return comm.allreduce_sum_(e.detach().to(torch.float64).clone().contiguous())
     if dist.get_backend(group) == "gloo" and e.is_cuda:
         h = e.detach().cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
@@ -82,7 +128,7 @@ def _allreduce_scalar(e: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def sharded_elbo(problem: dict, L: int, local_eval: Callable[[dict], torch.Tensor] = hip_local_elbo,
-                 group=None, local_terms: Optional[Callable] = None) -> torch.Tensor:
+                 group=None, local_terms: Optional[Callable] = None, comm: Optional[AbiCommunicator] = None) -> torch.Tensor:
     """ELBO of an L-latent model summed over all ranks of ``group``.
 
     ``problem`` holds the FULL model (or this rank's latent block with ``presharded``).  L >= world:
@@ -97,13 +143,13 @@ def sharded_elbo(problem: dict, L: int, local_eval: Callable[[dict], torch.Tenso
         if terms is not None:
             ll, kl = terms(shard_spots(problem, world, rank))
             e = (ll.to(torch.float64) - (kl.to(torch.float64) if rank == 0 else 0.0)).reshape(())
-            return _allreduce_scalar(e, group)
+            return _allreduce_scalar(e, group, comm)
     p = problem if problem.get("presharded") else shard_problem(problem, L, world, rank)
     lat = p.get("latents", shard_latents(L, world, rank))
     if len(lat) > 0:
         e = local_eval(p).to(torch.float64).reshape(())
     else:
         e = torch.zeros((), dtype=torch.float64, device=dev)
-    if world > 1:
-        e = _allreduce_scalar(e, group)
+    if dist.is_initialized() or comm is not None:   # also at world size 1: the collective is part of the path
+        e = _allreduce_scalar(e, group, comm)
     return e

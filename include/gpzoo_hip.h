@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPZ_VERSION 100
+#define GPZ_VERSION 200
 
 enum { GPZ_F32 = 0, GPZ_F64 = 1 };
 
@@ -65,27 +65,45 @@ const char* gpz_last_error(void);
 /* K[l][i][j] = k_l(A_i, B_j) (+ jitter where i == j if jitter != 0).
  * Replaces kernel.forward(X, Z) -- kernels.py:29-30, 57-58, 98-104, 118-130,
  * 146-155, 176-191, 211-228 -- and add_jitter (utilities.py:407-418) fused.
- * A (nA,d), B (nB,d) of k->dtype; gA/gB int64 group ids (MGGP only, else NULL).
+ * A (nA,d), B (nB,d) of k->dtype; gA/gB int64 group ids (MGGP only, else NULL).  An id outside
+ * [0, n_groups) -- IndexError in the reference (kernels.py:99-100, 177-178, 209-210) -- is read as group 0
+ * here (no out-of-bounds access); gpz_svgp_forward reports it through info (see there).
  * K has dtype out_dtype, row stride ldk, latent stride stride_k (elements).
  * Distances are evaluated by direct differencing in the output precision. */
 int gpz_kfill(const gpz_kernel_desc* k, const void* A, int64_t nA, const void* B, int64_t nB,
               int32_t d, const int64_t* gA, const int64_t* gB, void* K, int64_t ldk,
               int64_t stride_k, double jitter, int32_t out_dtype, void* stream);
 
-/* In-place lower Cholesky of `batch` (M,M) matrices (fp64), zeros written above
- * the diagonal; info[b] as described above.  Replaces torch.linalg.cholesky at
- * gp.py:213, 270, 360.  Blocked right-looking: LDS-resident diagonal panel,
+/* Backward of gpz_kfill: contracts Kbar = dLoss/dK (L,nA,nB; dtype k->dtype, row stride ldk, latent stride
+ * stride_k) with dK/d(sigma, lengthscale, group_a) and dK/dA -- what torch autograd sends through
+ * kernel.forward in the reference, where kernels are ordinary traced modules (kernels.py:14-30, 42-58,
+ * 75-104, 114-130, 139-155, 176-228; e.g. the inline ExactGP of exact_mggp.ipynb).  Outputs fp64:
+ * grad_theta (L,4) = d/dsigma, d/dlengthscale, d/dgroup_a (effective multiplier), 0;  grad_A (nA,4), first d
+ * columns used, summed over latents (NULL: skipped).  For dLoss/dB call it again with A and B (and the groups)
+ * swapped and Kbar transposed.  Matern-3/2: dK/dA at coincident points is 0 (its limit; the reference's
+ * autograd yields NaN there).  GPZ_KERNEL_DISTANCE is not differentiable here. */
+size_t gpz_kgrad_workspace_bytes(int64_t nA, int32_t n_latent);
+int gpz_kgrad(const gpz_kernel_desc* k, const void* A, int64_t nA, const void* B, int64_t nB, int32_t d,
+              const int64_t* gA, const int64_t* gB, const void* Kbar, int64_t ldk, int64_t stride_k,
+              double* grad_theta, double* grad_A, void* ws, size_t ws_bytes, void* stream);
+
+/* In-place lower Cholesky of `batch` (M,M) matrices stored as `dtype` (the arithmetic is fp64 either way:
+ * "factor precision"), zeros written above the diagonal; info[b] as described above.  Replaces
+ * torch.linalg.cholesky at gp.py:213, 270, 360.  Blocked right-looking: LDS-resident diagonal panel,
  * MFMA (v_mfma_f64_16x16x4_f64) panel solve and trailing SYRK/GEMM update. */
 size_t gpz_potrf_workspace_bytes(int64_t M, int64_t batch);
-int gpz_potrf_batched(double* A, int64_t M, int64_t lda, int64_t stride_a, int64_t batch,
+int gpz_potrf_batched(void* A, int32_t dtype, int64_t M, int64_t lda, int64_t stride_a, int64_t batch,
                       int32_t* info, void* ws, size_t ws_bytes, void* stream);
 
-/* X = Lc^{-1} B for `batch` lower-triangular (M,M) factors and (M,N) right-hand
- * sides (fp64), X written over B.  Replaces torch.linalg.solve_triangular at
- * gp.py:276 (and each half of cholesky_solve at gp.py:218, 365). */
+/* X = Lc^{-1} B for `batch` lower-triangular (M,M) factors and (M,N) right-hand sides stored as `dtype`
+ * (fp64 arithmetic), X written over B.  Replaces torch.linalg.solve_triangular at gp.py:276 (and each half
+ * of cholesky_solve at gp.py:218, 365).  Blocked forward substitution: the 128x128 diagonal blocks are
+ * inverted in LDS, then one MFMA GEMM per block row applies X_k = D_k (B_k - sum_{j<k} L_kj X_j) in place.
+ * (gpz_svgp_forward does not call this: it forms the explicit inverse once per evaluation and applies it to
+ * every N-chunk as one triangular product.) */
 size_t gpz_trsm_workspace_bytes(int64_t M, int64_t N, int64_t batch);
-int gpz_trsm_lln_batched(const double* Lc, int64_t ldl, int64_t stride_l, double* B, int64_t ldb,
-                         int64_t stride_b, int64_t M, int64_t N, int64_t batch, void* ws,
+int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_l, void* B, int64_t ldb,
+                         int64_t stride_b, int32_t dtype, int64_t M, int64_t N, int64_t batch, void* ws,
                          size_t ws_bytes, void* stream);
 
 /* One evaluation of the SVGP / WSVGP forward pass and (optionally) the
@@ -124,7 +142,8 @@ typedef struct gpz_svgp_problem {
   double* kl;            /* (L,) */
   double* loglik;        /* (L,) sum_n log N(y; mean, s^2) - var / (2 s^2) */
   double* elbo;          /* (1,) sum_l loglik - kl */
-  int32_t* info;         /* (L,) potrf info */
+  int32_t* info;         /* (L,) potrf info; info[0] = -1: a group id in gX / gZ is outside [0, n_groups)
+                          * (LAPACK's "illegal argument"; the Python wrapper raises IndexError like the reference) */
   /* optional cache of everything that depends only on (Z, kernel hyper-parameters, jitter):
    * chol(Kzz), its inverse and sum(log diag).  NULL: recompute every call like the reference
    * (SURVEY §3.3).  Non-NULL (gpz_svgp_factor_cache_bytes bytes, caller owned): filled when
@@ -224,6 +243,27 @@ size_t gpz_wsvgp_precomputed_workspace_bytes(int64_t L, int64_t N, int64_t M, in
 int gpz_wsvgp_precomputed(const void* W, const void* sigma, const void* mu, const void* Lu_raw,
                           int64_t L, int64_t N, int64_t M, int32_t dtype, void* mean, void* scale,
                           void* Lu, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of gpz_wsvgp_precomputed -- what loss.backward() sends through gp.py:308-322 to mu, Lu and the
+ * kernel's sigma (W is the caller's constant): given dLoss/dmean, dLoss/dscale and the forward's scale (L,N)
+ * writes grad_mu (L,M), grad_Lu_raw (L,M,M, zeros above the diagonal) and, if non-NULL, grad_sigma (L,) fp64. */
+size_t gpz_wsvgp_precomputed_backward_workspace_bytes(int64_t L, int64_t N, int64_t M, int32_t dtype);
+int gpz_wsvgp_precomputed_backward(const void* W, const void* sigma, const void* mu, const void* Lu_raw,
+                                   int64_t L, int64_t N, int64_t M, int32_t dtype, const void* g_mean,
+                                   const void* g_scale, const void* scale, void* grad_mu, void* grad_Lu_raw,
+                                   double* grad_sigma, void* ws, size_t ws_bytes, void* stream);
+
+/* Multi-GPU: latent GPs shard across ranks with no data-path collective; the only exchange is
+ * the sum of each rank's partial ELBO -- one ncclAllReduce(sum, fp64) over RCCL/xGMI.  The reference has no
+ * distributed code to cite; this is the entry SURVEY §8b proposes.  One communicator per process
+ * (rank <-> GPU): rank 0 calls gpz_comm_unique_id and hands the 128 bytes to every rank (file, socket, MPI,
+ * torch's store, ...), each rank then calls gpz_comm_init with its HIP device current.  `comm` may equally be
+ * an ncclComm_t the caller created itself.  gpz_allreduce_sum_f64 sums buf[0..n) in place over the ranks,
+ * asynchronously on `stream`.  RCCL is bound at run time (dlopen): the rest of the library works without it. */
+int gpz_comm_unique_id(void* id128_host);
+int gpz_comm_init(void** comm_out, int32_t world, int32_t rank, const void* id128_host);
+int gpz_allreduce_sum_f64(void* comm, double* buf, int64_t n, void* stream);
+int gpz_comm_destroy(void* comm);
 
 /* Timing hooks used by bench.py: HIP events recorded on `stream` around the
  * dominant kernels of the last gpz_svgp_forward call (roofline.achieved). */

@@ -524,3 +524,133 @@ if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1" a
     if os.environ.get("GPZ_GOLDEN_ONLY", "") != "vnngp":
         poisson_cases()
     vnngp_cases()
+
+
+def kernel_grad_cases():
+    """Stand-alone kernel calls differentiated by the reference's own autograd (kernels are ordinary traced
+    modules there, kernels.py:114-130, 139-155, 176-228): K = kernel(X, Z[, groups]), loss = sum(K * R) for a
+    fixed R, gradients w.r.t. sigma, lengthscale, group_diff_param, X and Z; plus K(X, X) with the same tensor
+    in both slots.  -> kernel_grads.npz"""
+    out = {}
+    inp = make_inputs(311, N=50, M=14, d=2, L=3, n_groups=3)
+    R = gen(312, 3, 50, 14)
+    R2 = gen(313, 3, 50, 50)
+    out["gX"], out["gZ"] = inp["gX"].numpy(), inp["gZ"].numpy()
+    for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        out[f"{tag}.X"], out[f"{tag}.Z"] = inp["X"].to(dtype).numpy(), inp["Z"].to(dtype).numpy()
+        out[f"{tag}.R"], out[f"{tag}.R2"] = R.to(dtype).numpy(), R2.to(dtype).numpy()
+
+        def vec(v):
+            return nn.Parameter(torch.tensor(v, dtype=dtype))
+
+        def make(kind):
+            if kind == "rbf":
+                return rk.RBF(sigma=1.2, lengthscale=3.0).to(dtype), False
+            if kind == "nsf_rbf":
+                return build_kernel("nsf_rbf", 3).to(dtype), False
+            if kind == "batched_rbf_vec":
+                k = rk.batched_RBF(); k.sigma, k.lengthscale = vec([1.0, 0.8, 1.3]), vec([2.5, 4.0, 6.0])
+                return k, False
+            if kind == "batched_rbf_scalar":
+                return rk.batched_RBF(sigma=1.2, lengthscale=3.0).to(dtype), False
+            if kind == "matern32_vec":
+                k = rk.batched_Matern32(); k.sigma, k.lengthscale = vec([1.0, 0.8, 1.3]), vec([2.5, 4.0, 6.0])
+                return k, False
+            if kind == "matern32_scalar":
+                return rk.batched_Matern32(sigma=0.9, lengthscale=2.0).to(dtype), False
+            if kind == "mggp_rbf":
+                k = rk.MGGP_RBF(sigma=1.1, lengthscale=3.5, group_diff_param=0.6, n_groups=3).to(dtype)
+                k.embedding = k.embedding.to(dtype)
+                return k, True
+            if kind == "mggp_nsf_rbf":
+                return build_kernel("mggp_nsf_rbf", 3).to(dtype), True
+            if kind == "batched_mggp_rbf":
+                return rk.batched_MGGP_RBF(sigma=1.1, lengthscale=3.5, group_diff_param=-0.6, n_groups=3).to(dtype), True
+            raise ValueError(kind)
+
+        for kind in ("rbf", "nsf_rbf", "batched_rbf_vec", "batched_rbf_scalar", "matern32_vec", "matern32_scalar",
+                     "mggp_rbf", "mggp_nsf_rbf", "batched_mggp_rbf"):
+            k, mggp = make(kind)
+            X = inp["X"].to(dtype).clone().requires_grad_(True)
+            Z = inp["Z"].to(dtype).clone().requires_grad_(True)
+            K = k(X, Z, inp["gX"], inp["gZ"]) if mggp else k(X, Z)
+            Rk = R.to(dtype) if K.dim() == 3 else R.to(dtype)[0]
+            (K * Rk).sum().backward()
+            pre = f"{tag}.{kind}."
+            out[pre + "K"] = K.detach().numpy()
+            out[pre + "grad_X"], out[pre + "grad_Z"] = X.grad.numpy(), Z.grad.numpy()
+            out[pre + "grad_sigma"], out[pre + "grad_lengthscale"] = k.sigma.grad.numpy(), k.lengthscale.grad.numpy()
+            if mggp:
+                out[pre + "grad_group_diff_param"] = k.group_diff_param.grad.numpy()
+                out[pre + "embedding"] = k.embedding.detach().numpy()
+            if "matern" in kind:
+                continue        # k(X, X) has r = 0 on the diagonal: NaN gradients in the reference (SURVEY a4)
+            k2, _ = make(kind)
+            X2 = inp["X"].to(dtype).clone().requires_grad_(True)
+            K2 = k2(X2, X2, inp["gX"], inp["gX"]) if mggp else k2(X2, X2)
+            Rk2 = R2.to(dtype) if K2.dim() == 3 else R2.to(dtype)[0]
+            (K2 * Rk2).sum().backward()
+            out[pre + "xx.K"] = K2.detach().numpy()
+            out[pre + "xx.grad_X"] = X2.grad.numpy()
+            out[pre + "xx.grad_sigma"], out[pre + "xx.grad_lengthscale"] = k2.sigma.grad.numpy(), k2.lengthscale.grad.numpy()
+            if mggp:
+                out[pre + "xx.grad_group_diff_param"] = k2.group_diff_param.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "kernel_grads.npz"), **out)
+    print(f"kernel_grads.npz: {len(out)} arrays")
+
+
+def exact_gp_case():
+    """The inline ExactGP of exact_mggp.ipynb (forward: MultivariateNormal(0, kernel(X, X, g, g) + noise^2 I);
+    train: loss = -log_prob(y), loss.backward()) with MGGP_RBF, one step: loss and the gradients the
+    reference's autograd sends to sigma, lengthscale, group_diff_param and the noise.  -> exact_mggp_step_f64.npz"""
+    inp = make_inputs(411, N=40, M=4, d=1, L=0, n_groups=2, span=5.0)
+    X, gX = inp["X"], inp["gX"]
+    y = torch.sin(X[:, 0]) + 0.3 * gX.double() + 0.1 * gen(412, 40)
+    kernel = rk.MGGP_RBF(sigma=1.3, lengthscale=1.7, group_diff_param=0.8, n_groups=2).double()
+    kernel.embedding = kernel.embedding.double()
+    kernel.input_dim = 1                                   # the 1-D notebooks overwrite it (mggp_test.ipynb:54)
+    noise = nn.Parameter(torch.tensor(0.4, dtype=torch.float64))
+    Kxx = kernel.forward(X, X, gX, gX)
+    pY = distributions.MultivariateNormal(torch.zeros(40, dtype=torch.float64), Kxx + (noise ** 2) * torch.eye(40, dtype=torch.float64))
+    loss = -pY.log_prob(y).sum()
+    loss.backward()
+    np.savez_compressed(os.path.join(HERE, "exact_mggp_step_f64.npz"), X=X.numpy(), gX=gX.numpy(), y=y.numpy(),
+                        embedding=kernel.embedding.numpy(), Kxx=Kxx.detach().numpy(), loss=np.float64(float(loss)),
+                        grad_sigma=kernel.sigma.grad.numpy(), grad_lengthscale=kernel.lengthscale.grad.numpy(),
+                        grad_group_diff_param=kernel.group_diff_param.grad.numpy(), grad_noise=noise.grad.numpy())
+    print("exact_mggp_step_f64: loss", float(loss))
+
+
+def vnngp_scale_case():
+    """VNNGP neighbour bookkeeping at Slide-seq-like coordinates in fp32 (|x| <= 100, N=4000, M=500, K=8): the
+    reference orders neighbours by torch.cdist's fp32 matmul-expansion distances (kernels.py:118, gp.py:31, 64),
+    whose error reaches 0.06 there.  Stores the reference's neighbour table and moments.
+    -> vnngp_scale_f32.npz"""
+    import contextlib
+    import io
+    L, N, M, K = 2, 4000, 500, 8
+    inp = make_inputs(811, N=N, M=M, d=2, L=L, span=100.0)
+    kern = rk.NSF_RBF(L=L)
+    kern.sigma = nn.Parameter(per_latent([1.0, 0.8], True)); kern.lengthscale = nn.Parameter(per_latent([6.0, 9.0], True))
+    gp = rgp.VNNGP(kern, dim=2, M=M, K=K, jitter=1e-2)
+    gp.Z = nn.Parameter(inp["Z"].clone()); gp.mu = nn.Parameter(inp["mu"].clone()); gp.Lu = nn.Parameter(inp["Lu_raw"].clone())
+    gp = gp.float()
+    X = inp["X"].float()
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        qF, qU, pU = gp(X)
+        _, dist = kern(X, gp.Z, return_distance=True)
+    idx = torch.argsort(dist, dim=1)[:, :K]
+    np.savez_compressed(os.path.join(HERE, "vnngp_scale_f32.npz"), X=X.numpy(), Z=gp.Z.detach().numpy(),
+                        mu=gp.mu.detach().numpy(), Lu_raw=gp.Lu.detach().numpy(), sigma=kern.sigma.detach().numpy(),
+                        lengthscale=kern.lengthscale.detach().numpy(), idx=idx.numpy().astype(np.int16),
+                        dist_k=torch.gather(dist, 1, idx).numpy(), mean=qF.mean.numpy(), scale=qF.scale.numpy(),
+                        jitter=np.float64(1e-2), K=np.int64(K))
+    print("vnngp_scale_f32: idx", tuple(idx.shape), "mean[0,:3]", qF.mean[0, :3].tolist())
+
+
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "kernel_grads"):
+    kernel_grad_cases()
+    exact_gp_case()
+
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "vnngp_scale"):
+    vnngp_scale_case()

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_string():
     from gpzoo_amd import _lib
     lib = _lib.load()
-    assert lib.gpz_version() == 100
+    assert lib.gpz_version() == 200          # 200: dtype on the factor entries, gpz_kgrad, collective entries
     assert isinstance(lib.gpz_last_error(), bytes)
 
 
@@ -40,6 +40,18 @@ def test_argument_errors_do_not_touch_the_gpu():
     p.dtype = 7
     assert lib.gpz_svgp_workspace_bytes(ctypes.byref(p), 0) == 0
     assert b"dtype" in lib.gpz_last_error()
+
+
+def test_collective_entry_rejects_bad_arguments_on_the_host():
+    """gpz_comm_* / gpz_allreduce_sum_f64 validate their arguments before RCCL is even bound."""
+    from gpzoo_amd import _lib
+    lib = _lib.load()
+    assert lib.gpz_allreduce_sum_f64(None, None, 1, None) < 0 and b"gpz_allreduce_sum_f64" in lib.gpz_last_error()
+    assert lib.gpz_comm_init(None, 1, 0, None) < 0
+    comm = ctypes.c_void_p()
+    ident = (ctypes.c_char * 128)()
+    assert lib.gpz_comm_init(ctypes.byref(comm), 2, 5, ident) < 0 and b"bad rank" in lib.gpz_last_error()
+    assert lib.gpz_comm_destroy(None) == 0
 
 
 def test_struct_layout_matches_header():

@@ -322,3 +322,41 @@ def test_only_hyperparameters_trainable():
         grads.append([gp.kernel.lengthscale.grad.clone(), gp.kernel.sigma.grad.clone(), gp.Z.grad.clone()])
     for a, b in zip(*grads):
         assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize("name,clamp", [("wsvgp_nsf_rbf_f64", False), ("wsvgp_nsf_rbf_f64", True), ("wsvgp_matern32_f32", False),
+                                        ("wsvgp_rbf_f64", False)])
+def test_forward_precomputed_is_differentiable(name, clamp):
+    """WSVGP.forward_precomputed under loss.backward(): gradients to mu, Lu and sigma equal torch autograd
+    through the reference's own expression (gp.py:308-322) evaluated on the same W -- also where the
+    clamp(sigma^2 - sum W^2, min=0) is active (no gradient through a clamped term)."""
+    c = load_case(name)
+    model = build(name, c)
+    gp = model.gp
+    W = torch.linalg.solve_triangular(c["chol"], c["Kzx"], upper=False).transpose(-1, -2).contiguous()
+    if clamp:
+        W = W * 1.6                                  # pushes sigma^2 - sum W^2 below zero for part of the points
+    W = W.cuda()
+    R1, R2 = torch.randn_like(c["mean"]).cuda(), torch.rand_like(c["mean"]).cuda()
+    qF, qU, pU = gp.forward_precomputed(W)
+    assert qF.mean.requires_grad and pU is None
+    loss = (qF.mean * R1).sum() + (qF.scale * R2).sum() + (qU.scale_tril ** 2).sum()
+    loss.backward()
+    got = {n: getattr(t, "grad").clone() for n, t in (("mu", gp.mu), ("Lu", gp.Lu), ("sigma", gp.kernel.sigma))}
+    # the reference's expression, torch autograd
+    mu = gp.mu.detach().clone().requires_grad_(True)
+    Lur = gp.Lu.detach().clone().requires_grad_(True)
+    sig = gp.kernel.sigma.detach().clone().requires_grad_(True)
+    Lu = Lur.tril(-1) + torch.diag_embed(torch.diagonal(Lur, dim1=-2, dim2=-1).exp())
+    s2 = (sig ** 2).reshape(-1, 1) if sig.dim() else sig ** 2
+    cov = s2 - (W ** 2).sum(-1)
+    if clamp:
+        assert 0 < int((cov <= 0).sum()) < cov.numel()
+    cov = cov.clamp(min=0.0) + ((W @ Lu) ** 2).sum(-1)
+    mean = (W @ mu.unsqueeze(-1)).squeeze(-1)
+    ref = (mean * R1).sum() + (cov ** 0.5 * R2).sum() + (Lu ** 2).sum()
+    ref.backward()
+    rt = rtol_for(W.dtype)
+    assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=rt)
+    for n, t in (("mu", mu), ("Lu", Lur), ("sigma", sig)):
+        torch.testing.assert_close(got[n], t.grad, rtol=rt, atol=rt * float(t.grad.abs().max()), msg=lambda m: f"{n}: {m}")

@@ -23,7 +23,7 @@ def test_cholesky_matches_lapack(M, batch):
     assert torch.equal(got.triu(1), torch.zeros_like(got))  # zeros above the diagonal
 
 
-@pytest.mark.parametrize("M,N,batch", [(36, 50, 2), (256, 130, 2), (640, 300, 1)])
+@pytest.mark.parametrize("M,N,batch", [(1, 1, 1), (36, 50, 2), (256, 130, 2), (640, 300, 1), (700, 129, 3), (2048, 512, 2)])
 def test_trsm_matches_lapack(M, N, batch):
     from gpzoo_amd import ops
     Lc = torch.linalg.cholesky(spd(batch, M, 11 + M))
@@ -31,6 +31,32 @@ def test_trsm_matches_lapack(M, N, batch):
     ref = torch.linalg.solve_triangular(Lc, B, upper=False)
     got = ops.solve_triangular_lower(Lc.cuda(), B.cuda()).cpu()
     torch.testing.assert_close(got, ref, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("M,N,batch", [(200, 70, 2), (513, 300, 1)])
+def test_fp32_storage_factor_entries(M, N, batch):
+    """dtype = GPZ_F32 on the stand-alone entries: fp32 in / out, fp64 arithmetic inside -- the result is the fp64
+    answer of the fp32-representable input rounded once."""
+    from gpzoo_amd import ops
+    A32 = spd(batch, M, 3 + M).float()
+    got = ops.cholesky(A32.cuda())
+    assert got.dtype == torch.float32
+    ref = torch.linalg.cholesky(A32.double())
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=2e-7, atol=2e-7)
+    B32 = torch.randn(batch, M, N, generator=torch.Generator().manual_seed(M), dtype=torch.float32)
+    L32 = ref.float()
+    X = ops.solve_triangular_lower(L32.cuda(), B32.cuda())
+    assert X.dtype == torch.float32
+    refX = torch.linalg.solve_triangular(L32.double(), B32.double(), upper=False)
+    torch.testing.assert_close(X.cpu().double(), refX, rtol=1e-6, atol=1e-6 * float(refX.abs().max()))
+
+
+def test_trsm_shared_factor_broadcasts_over_the_batch():
+    from gpzoo_amd import ops
+    Lc = torch.linalg.cholesky(spd(1, 300, 21))[0]
+    B = torch.randn(3, 300, 40, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    got = ops.solve_triangular_lower(Lc.cuda(), B.cuda()).cpu()
+    torch.testing.assert_close(got, torch.linalg.solve_triangular(Lc, B, upper=False), rtol=1e-8, atol=1e-10)
 
 
 def test_not_positive_definite_raises():

@@ -201,3 +201,36 @@ def test_factor_count_limit_is_reported():
     with pytest.raises(RuntimeError, match="65 factors unsupported"):
         ops.poisson_nsf(torch.zeros(Lt, N).cuda(), torch.ones(Lt, N).cuda(), torch.zeros(1, Lt, N).cuda(),
                         torch.ones(D, Lt).cuda(), torch.ones(N).cuda(), torch.ones(D, N).cuda())
+
+
+@pytest.mark.parametrize("whitened", [True, False])
+def test_mggp_nsf_minibatch_groups_follow_the_sampled_spots(whitened):
+    """train_batched on MGGP_NSF: the fused step and the reference's literal forward_batched form see the same
+    sampled spots AND their group ids (groupsX[idx], reference likelihoods.py:344-361); a full-length group vector
+    handed to the batch would silently pair spot i of the batch with group id i of the data set."""
+    import gpzoo.gp as G
+    import gpzoo.kernels as K
+    from gpzoo.likelihoods import MGGP_NSF
+    from gpzoo.utilities import train_batched
+    gen = torch.Generator().manual_seed(5)
+    N, D, L, M, n_groups = 600, 40, 3, 30, 3
+    X = (torch.rand(N, 2, generator=gen) - 0.5) * 20
+    gX = torch.randint(0, n_groups, (N,), generator=gen)
+    y = torch.poisson(3.0 * torch.rand(D, N, generator=gen), generator=gen)
+
+    def run(fused):
+        torch.manual_seed(11)
+        k = K.MGGP_NSF_RBF(sigma=1.0, lengthscale=4.0, group_diff_param=0.8, n_groups=n_groups, L=L)
+        gp = (G.MGGP_WSVGP(k, dim=2, M=M, n_groups=n_groups, jitter=1e-2) if whitened else
+              G.MGGP_SVGP(k, dim=2, M=M, jitter=1e-2, n_groups=n_groups))
+        gp.Z = nn.Parameter(X[:M].clone())
+        gp.groupsZ = nn.Parameter(gX[:M].clone(), requires_grad=False)
+        gp.mu = nn.Parameter(0.1 * torch.randn(L, M))
+        gp.Lu = nn.Parameter(0.05 * torch.randn(L, M, M) - 0.5 * torch.eye(M))
+        model = MGGP_NSF(gp, y, L=L).cuda()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        torch.manual_seed(12)
+        return train_batched(model, opt, X.cuda(), y.cuda(), steps=4, E=3, batch_size=128, fused=fused, groupsX=gX.cuda())
+
+    a, b = run(True), run(False)
+    assert all(abs(u - v) <= 2e-3 * abs(v) for u, v in zip(a, b)), (a, b)

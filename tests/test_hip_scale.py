@@ -55,6 +55,57 @@ def test_config2_scaled():
     check(make_config(2, N=20000), 1e-3, chunk=8192)      # M=512, L=8, NSF_RBF fp32, 3 chunks
 
 
+def test_config2_full_size_against_oracle():
+    """BASELINE configs[1] exactly as stated (N=50 000, M=512, L=8, NSF_RBF, fp32) against the fp64 oracle."""
+    from gpzoo_amd.synthetic import make_config
+    check(make_config(2), 1e-3)
+
+
+def test_config5_multi_panel_fp64_against_oracle():
+    """BASELINE configs[4]'s factor size: M=2048 (16 Cholesky panels, 4 trtri levels), MGGP_NSF_RBF, fp64,
+    N=4096 spots over the 4 groups, L=2 -- element-wise against the oracle at 1e-5."""
+    from gpzoo_amd.synthetic import make_config
+    check(make_config(5, N=4096, M=2048, L=2), 1e-5)
+
+
+@pytest.mark.parametrize("small_Lu", [False, True])
+@pytest.mark.parametrize("M", [512, 2048])
+def test_fp32_at_reference_default_jitter(M, small_Lu):
+    """fp32, RBF, lengthscale 5 on |x| <= 100, the reference's DEFAULT jitter 1e-4 (gp.py:150, 236): the path must
+    either meet north_star's 1e-3 against the fp64 oracle or raise LinAlgError like torch's fp32 Cholesky does --
+    never return silently wrong moments.  The outcome is recorded under gpurun_out/ (DESIGN §2 quotes it)."""
+    import json
+    import os
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(2, N=4000, M=M, L=2)
+    c["lengthscale"] = torch.full_like(c["lengthscale"], 5.0)
+    c["jitter"] = 1e-4
+    if small_Lu:       # q(U) scale 0.1: the variance is then dominated by the cancelling term sigma^2 - colsum(Wt^2)
+        c["Lu_raw"].diagonal(dim1=-2, dim2=-1).fill_(-2.302585)
+    rec = dict(M=M, jitter=1e-4, lengthscale=5.0, small_Lu=small_Lu)
+    try:
+        out = hip_eval(c)
+    except torch.linalg.LinAlgError as e:
+        rec["outcome"] = "LinAlgError: " + str(e)[:120]
+    else:
+        ref, mean, scale = oracle_eval(c)
+        rec["outcome"] = "evaluated"
+        rec["elbo_rel"] = abs(float(out["elbo"]) - float(ref)) / abs(float(ref))
+        rec["scale_max_rel"] = float(((out["scale"].double().cpu() - scale).abs() / scale).max())
+        rec["mean_max_abs"] = float((out["mean"].double().cpu() - mean).abs().max())
+        assert rec["elbo_rel"] < 1e-3
+        torch.testing.assert_close(out["mean"].double().cpu(), mean, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(out["scale"].double().cpu(), scale, rtol=1e-3, atol=1e-3)
+    finally:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "fp32_default_jitter.jsonl"), "a") as f:
+                f.write(json.dumps(rec) + "\n")
+        except OSError:
+            pass
+
+
 def test_config3_scaled():
     from gpzoo_amd.synthetic import make_config
     check(make_config(3, N=6000, M=1024, L=4), 1e-3)      # Matern-3/2 fp32, 8 Cholesky panels
