@@ -16,6 +16,7 @@
 #include "gemm.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace gpz {
@@ -61,7 +62,8 @@ constexpr size_t gemm_lds_bytes() {
 // 64x32 (production).  fp64 MFMAs only reach their rate with >= 3 waves per SIMD (36 TF with one wave,
 // 49 TF with three or more, measured), which the 128 accumulator registers of a 64x64 fp64 wave tile
 // rule out; 64x32 halves them and leaves 4 waves per SIMD in both precisions.
-template <typename T, int KV, int NI, bool BT, int EPI>
+// PIPE: the full-range part of the k-loop runs software-pipelined across the tile barrier (see below).
+template <typename T, int KV, int NI, bool BT, int EPI, bool PIPE>
 __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(const GemmParams<T> p) {
   constexpr int WN = 8 / NI;                // waves along N
   constexpr int NT = 128 * WN;              // threads: 2 x WN waves
@@ -282,7 +284,64 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
     phases(phases, i0{});
   }
   const int t_main_end = nk - n_post - (part_lo ? PT : 0);
-  while (t < t_main_end) { iteration(i0{}, run{}, i0{}, i3{}); iteration(i1{}, run{}, i0{}, i3{}); }
+  if constexpr (PIPE) {
+    // Software pipeline across the barrier.  A staged tile is two 64-byte k-chunks; the fragments of chunk 0 of
+    // tile t+1 are fetched from LDS right AFTER the barrier that publishes the tile, and the MFMAs of chunk 1 of
+    // tile t -- operands already in registers -- are issued behind those reads, so the pipe has 32 MFMAs (1024
+    // cycles) to chew on while the LDS round trip of the new tile is in flight; chunk 1's fragments are fetched
+    // in front of chunk 0's MFMAs the same way.  Without this each wave (and, in lock-step, its partner of the
+    // same workgroup on the same SIMD) starts every tile with all its fragment reads and an exposed LDS latency,
+    // and waits again on the operand reads the compiler places just in time mid-tile.
+    static_assert(KV == 2, "the pipelined loop is written for two k-chunks per staged tile");
+    struct Frag { vec_t a[4]; vec_t bv[NI]; T bs[VEC][NI]; };
+    auto frag_read = [&](int buf, auto kc_c, Frag& f) __attribute__((always_inline)) {
+      constexpr int ko = decltype(kc_c)::value * 4 * VEC;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        f.a[mi] = *reinterpret_cast<const vec_t*>(sA(buf) + (wm * 64 + mi * 16 + r) * LDR + ko + q * VEC);
+      if constexpr (BT) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          f.bv[ni] = *reinterpret_cast<const vec_t*>(sB(buf) + (wn * 16 * NI + ni * 16 + r) * LDR + ko + q * VEC);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) f.bs[j][ni] = sB(buf)[(ko + q * VEC + j) * LDN + wn * 16 * NI + ni * 16 + r];
+      }
+    };
+    auto frag_mma = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            if constexpr (BT) acc[mi][ni] = M::mma(f.a[mi][j], f.bv[ni][j], acc[mi][ni]);
+            else acc[mi][ni] = M::mma(f.a[mi][j], f.bs[j][ni], acc[mi][ni]);
+          }
+    };
+    Frag f0, f1;
+    if (t < t_main_end) frag_read(0, i0{}, f0);       // t is even here: buffer 0
+    auto piter = [&](auto par_c) __attribute__((always_inline)) {
+      constexpr int P = decltype(par_c)::value;
+      if (t + 1 < nk) gload_set(i0{});
+      frag_read(P, i1{}, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(f0);
+      if (t + 1 < nk) sstore_set(P ^ 1, i0{});
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < t_main_end) frag_read(P ^ 1, i0{}, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(f1);
+      ++t;
+    };
+    while (t < t_main_end) { piter(i0{}); piter(i1{}); }
+  } else {
+    while (t < t_main_end) { iteration(i0{}, run{}, i0{}, i3{}); iteration(i1{}, run{}, i0{}, i3{}); }
+  }
   if (part_lo) {
     auto phases = [&](auto self, auto u_c) __attribute__((always_inline)) -> void {
       constexpr int U = decltype(u_c)::value;
@@ -427,37 +486,54 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   // Tile configuration (KV 64-byte k-chunks per staged tile, NI 16-column sub-tiles per wave): both
   // precisions run 8 waves of 64x32 on two-chunk tiles (32-deep fp32, 16-deep fp64), 4 waves per SIMD.
   // Measured against 4 waves of 64x64 on one-chunk tiles in fp32: +0.6 % at M=2048, +4 % at M=512.
-  auto run = [&](auto kv_c, auto ni_c) -> int {
+  auto run = [&](auto kv_c, auto ni_c, auto pipe_c) -> int {
     constexpr int KV = decltype(kv_c)::value, NI = decltype(ni_c)::value;
     dim3 grid((unsigned)nblocks), block(1024 / NI);
     auto launch = [&](auto kernel, size_t lds) -> int {
-      static bool attr_set[64] = {};  // per device; one table per instantiation of this lambda's call operator
+      // dynamic LDS above 64 KB is an opt-in per kernel FUNCTION and device: every variant has the same pointer
+      // type, so the record is keyed on the pointer value (a handful of variants: linear search)
+      struct Seen { const void* fn; int dev; };
+      static Seen seen[256];
+      static int n_seen = 0;
+      static std::mutex mu;
       int dev = 0;
       GPZ_HIP_OK(hipGetDevice(&dev));
-      if (!attr_set[dev & 63] && lds > 64 * 1024) {
-        GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-        attr_set[dev & 63] = true;
+      if (lds > 64 * 1024) {
+        const void* fn = reinterpret_cast<const void*>(kernel);
+        std::lock_guard<std::mutex> lock(mu);
+        bool have = false;
+        for (int i = 0; i < n_seen; ++i) have = have || (seen[i].fn == fn && seen[i].dev == dev);
+        if (!have) {
+          GPZ_HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          if (n_seen < 256) seen[n_seen++] = Seen{fn, dev};
+        }
       }
       hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
       GPZ_LAUNCH_OK();
       return 0;
     };
+    constexpr bool PIPE = decltype(pipe_c)::value;
     if (epilogue == EPI_STORE)
-      return bt ? launch(gemm128_kernel<T, KV, NI, true, EPI_STORE>, gemm_lds_bytes<T, KV, true>())
-                : launch(gemm128_kernel<T, KV, NI, false, EPI_STORE>, gemm_lds_bytes<T, KV, false>());
+      return bt ? launch(gemm128_kernel<T, KV, NI, true, EPI_STORE, PIPE>, gemm_lds_bytes<T, KV, true>())
+                : launch(gemm128_kernel<T, KV, NI, false, EPI_STORE, PIPE>, gemm_lds_bytes<T, KV, false>());
     if (epilogue == EPI_WBAR) {
       GPZ_REQUIRE(p.colscale && p.colvec && p.rowvec && p.aux && p.beta == (T)0, "gemm: W-bar epilogue needs its operands");
-      return launch(gemm128_kernel<T, KV, NI, false, EPI_WBAR>, gemm_lds_bytes<T, KV, false>());
+      return launch(gemm128_kernel<T, KV, NI, false, EPI_WBAR, PIPE>, gemm_lds_bytes<T, KV, false>());
     }
     if (epilogue == EPI_STORE_COLSCALE)
-      return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_COLSCALE>, gemm_lds_bytes<T, KV, false>());
+      return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_COLSCALE, PIPE>, gemm_lds_bytes<T, KV, false>());
     if (epilogue == EPI_STORE_STATS)
-      return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_STATS>, gemm_lds_bytes<T, KV, false>());
-    return launch(gemm128_kernel<T, KV, NI, false, EPI_STATS>, gemm_lds_bytes<T, KV, false>());
+      return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_STATS, PIPE>, gemm_lds_bytes<T, KV, false>());
+    return launch(gemm128_kernel<T, KV, NI, false, EPI_STATS, PIPE>, gemm_lds_bytes<T, KV, false>());
   };
   using std::integral_constant;
-  return run(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+  // the pipelined k-loop needs two fragment sets in registers: fits the 128-VGPR budget of 4 waves per SIMD in fp32,
+  // not in fp64 (accumulators and fragments are twice as wide)
+  static const int pipe_mode = [] { const char* e = getenv("GPZ_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+  if constexpr (sizeof(T) == 4) {
+    if (pipe_mode) return run(integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<bool, true>{});
+  }
+  return run(integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<bool, false>{});
 }
 
 template int gemm_launch<float>(const GemmParams<float>&, int, hipStream_t);
