@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgpzoo_hip.so")
+LIB_PATH = os.environ.get("GPZ_HIP_LIB") or os.path.join(HERE, "libgpzoo_hip.so")   # override: diagnostic builds only
 
 GPZ_F32, GPZ_F64 = 0, 1
 KERNEL_RBF, KERNEL_MATERN32, KERNEL_MGGP_RBF, KERNEL_DISTANCE = 0, 1, 2, 3

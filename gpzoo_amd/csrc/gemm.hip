@@ -2,13 +2,13 @@
 //
 // fp32: v_mfma_f32_16x16x4_f32, fp64: v_mfma_f64_16x16x4_f64 (exact IEEE FMA
 // chains, so results are deterministic and match a plain fp32/fp64 reference to
-// rounding).  256 threads = 4 waves in a 2x2 grid, 64x64 outputs per wave held
-// in 16 accumulator tiles.  A and (transposed) B tiles are staged [row][k] in LDS
+// rounding).  512 threads = 8 waves in a 2x4 grid, 64x32 outputs per wave held
+// in 8 accumulator tiles.  A and (transposed) B tiles are staged [row][k] in LDS
 // and fetched with one 16-byte ds_read per lane covering VEC consecutive k; the
 // non-transposed B tile is staged [k][n].  Because the MFMA sums its four k
 // slots, lane group q may own k = VEC*q .. VEC*q+VEC-1 as long as A and B agree,
-// which is what makes the wide read legal.  Global->LDS staging is double
-// buffered through registers with one barrier per k-tile.
+// which is what makes the wide read legal.  Tiles reach LDS by LDS-DMA (global_load_lds),
+// double buffered, one barrier per k-tile.
 //
 // Triangular structure (L^{-1} and Lu^T are triangular, SYRK only needs the lower
 // tiles) is expressed as a per-tile k-range in units of the 128-block, so no
@@ -48,35 +48,65 @@ template <> struct Mma<double> {
 };
 
 
-// LDS bytes of one instantiation (two buffers of an A and a B tile)
-template <typename T, int KV, bool BT>
-constexpr size_t gemm_lds_bytes() {
-  constexpr int VEC = 16 / sizeof(T), BK = 4 * VEC * KV, LDR = BK + VEC, LDN = 128 + (VEC == 4 ? 4 : 8);
-  return sizeof(T) * 2 * (128 * LDR + (BT ? 128 * LDR : BK * LDN));
-}
+// Timing-only diagnostics (wrong results!): -DGPZ_ABL=<bits> drops parts of the fp32 k-loop to see what the MFMA pipes
+// wait for -- 1: no global loads after the first tile, 2: no LDS staging stores / no LDS-DMA, 4: no per-tile barrier.
+// tools/ablate_gemm.sh builds such variants next to the real library.
+#ifndef GPZ_ABL
+#define GPZ_ABL 0
+#endif
+#ifndef GPZ_SCHED
+#define GPZ_SCHED 0
+#endif
 
-// KV = number of 64-byte k-chunks per staged tile (2 in production: 32-deep f32 / 16-deep f64 tiles,
-// 70 / 74 KB of LDS for the two buffers; with one chunk the one-tile prefetch distance of the fp64
-// kernel was shorter than the memory latency).
-// NI = 16-column sub-tiles per wave: 4 gives 4 waves (2x2) of 64x64, 2 gives 8 waves (2x4) of
-// 64x32 (production).  fp64 MFMAs only reach their rate with >= 3 waves per SIMD (36 TF with one wave,
-// 49 TF with three or more, measured), which the 128 accumulator registers of a 64x64 fp64 wave tile
-// rule out; 64x32 halves them and leaves 4 waves per SIMD in both precisions.
-// PIPE: the full-range part of the k-loop runs software-pipelined across the tile barrier (see below).
-template <typename T, int KV, int NI, bool BT, int EPI, bool PIPE>
-__global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(const GemmParams<T> p) {
+// ---- LDS geometry ----------------------------------------------------------------------------------------------
+// A staged tile is 128 rows x BK of A and BK x 128 of op(B), BK = two 64-byte k-chunks (32 fp32 / 16 fp64), so a
+// [row][k] tile row is exactly 128 bytes = eight 16-byte chunks in both precisions.
+//
+// STG = 0 (default): register staging into padded images (16-byte row pad / 4-8 element pad: 2-way on the wide reads).
+// STG = 1: tiles are filled by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write, no wait for load
+// data before an LDS store; 16 fewer VGPRs).  Timing-only builds show that staging costs the MFMA pipes ~10 % of their
+// time in this kernel; LDS-DMA moves the same bytes over the same L2 -> LDS path and measures the same as register
+// staging (gemm_launch), so the cost is the movement, not the instructions.  One wave instruction writes 1 KB of LDS
+// contiguously (lane i -> base + 16 i), so the images are lane-linear and every bank-conflict measure sits on the
+// per-lane SOURCE address or between 1-KB pieces:
+//   [row][k] tiles (A; B when stored (N,K)): unpadded, 8 rows per piece, chunk c of row w stored at slot c ^ (w & 7)
+//     -- the 16 lanes of a ds_read_b128 group then cover all 64 banks exactly once (conflict free; the padded image of
+//     the register-staged variant is 2-way);
+//   [k][n] tile (B stored (K,N)): a k-row is 128 elements = 512 B / 1 KB, a piece holds 2 / 1 rows, and pieces sit
+//     32 / 64 bytes apart so that the two k-rows a 32-lane read group touches (k and k + VEC) fall on disjoint banks.
+template <typename T, bool BT, int STG>
+struct GemmLds {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int BK = 8 * VEC;
+  static constexpr int LDR = STG ? BK : BK + VEC;                        // [row][k] row pitch (elements)
+  static constexpr int LDN = 128 + (VEC == 4 ? 4 : 8);                   // STG 0: [k][n] row pitch
+  static constexpr int RPP = (1024 / (int)sizeof(T)) / 128;             // STG 1: k-rows per 1-KB piece of a [k][n] tile
+  static constexpr int PIECE = 1024 / (int)sizeof(T) + (sizeof(T) == 4 ? 8 : 8);   // piece pitch: 1 KB + 32 B / 64 B
+  static constexpr int A_ELEMS = 128 * LDR;
+  static constexpr int B_ELEMS = BT ? 128 * LDR : (STG ? (BK / RPP) * PIECE : BK * LDN);
+  static constexpr size_t bytes = sizeof(T) * 2 * (A_ELEMS + B_ELEMS);  // two buffers
+};
+
+// 8 waves (2 x 4) of 64 x 32 outputs, 4 waves per SIMD, 2 workgroups per CU in both precisions.  fp64 MFMAs only
+// reach their rate with >= 3 waves per SIMD, which the 128 accumulator registers of a 64 x 64 fp64 wave tile rule out.
+// NI = 16-column sub-tiles per wave: 2 -> 8 waves (2 x 4) of 64 x 32, four waves per SIMD; 4 -> 4 waves (2 x 2) of
+// 64 x 64, two waves per SIMD (one per workgroup: no two waves of a SIMD share a barrier) and a third less LDS read
+// traffic per flop.
+template <typename T, int NI, bool BT, int EPI, int STG>
+__global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / NI, 8 / NI))) void gemm128_kernel(const GemmParams<T> p) {
   constexpr int WN = 8 / NI;                // waves along N
-  constexpr int NT = 128 * WN;              // threads: 2 x WN waves
+  constexpr int NT = 128 * WN;
   using M = Mma<T>;
   using vec_t = typename M::vec_t;
   using acc_t = typename M::acc_t;
+  using G = GemmLds<T, BT, STG>;
   constexpr int VEC = M::VEC;
-  constexpr int BK = 4 * VEC * KV;          // k-depth of a staged tile
-  constexpr int LDR = BK + VEC;             // [row][k] tile row: 16-byte pad (2-way on 16-B reads)
-  constexpr int LDN = 128 + (VEC == 4 ? 4 : 8);  // [k][n] tile row (elements)
-  constexpr int A_ELEMS = 128 * LDR;
-  constexpr int B_ELEMS = BT ? 128 * LDR : BK * LDN;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int KV = 2;                     // 64-byte k-chunks per staged tile
+  constexpr int BK = G::BK;
+  constexpr int LDR = G::LDR, LDN = G::LDN, RPP = G::RPP, PIECE = G::PIECE;
+  constexpr int A_ELEMS = G::A_ELEMS, B_ELEMS = G::B_ELEMS;
+  constexpr bool ABL = GPZ_ABL != 0 && sizeof(T) == 4;
+  extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
   T* const smem = reinterpret_cast<T*>(smem_raw);
   auto sA = [&](int buf) -> T* { return smem + buf * (A_ELEMS + B_ELEMS); };
   auto sB = [&](int buf) -> T* { return smem + buf * (A_ELEMS + B_ELEMS) + A_ELEMS; };
@@ -133,57 +163,82 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
   const int wm = (wave / WN) ^ ((p.flags & (GF_A_LOWER | GF_A_UPPER)) ? ((ti ^ tj) & 1) : 0), wn = wave % WN;
   const int r = lane & 15, q = lane >> 4;
 
-  // ---------------- staging maps (16 bytes per thread per load) ----------------
-  // [row][k] tiles (A, and B when BT): VPR vectors per row, 256/VPR rows per pass
-  constexpr int VPR = BK / VEC;               // 4 (KV=1) / 8 (KV=2)
-  constexpr int RROWS = NT / VPR;             // rows per pass
-  constexpr int RP = 128 / RROWS;             // passes
-  const int ra_row = tid / VPR, ra_vc = (tid % VPR) * VEC;
-  // [k][n] tile: 128/VEC vectors per row
-  constexpr int NV = 128 / VEC;               // 32 / 64 threads per row
-  constexpr int BROWS = NT / NV;              // rows per pass
-  constexpr int NP = BK / BROWS;              // passes
-  static_assert(NP == RP, "A and B staging use the same number of passes");
-  const int rb_row = tid / NV, rb_vc = (tid % NV) * VEC;
-
-  // running global pointers of this thread's 16-byte pieces of each tile
+  // ---------------- staging: this thread's / wave's share of a tile ----------------
+  // STG 0: two 16-byte vectors of A and of B per thread, through registers.
+  // STG 1: two 1-KB pieces of A and of B per wave, by LDS-DMA; the lane's source address carries the swizzle.
+  constexpr int RP = NI;                    // staging passes per thread (STG 0) / 1-KB pieces per wave (STG 1), per operand
   const T* pa[RP];
   const T* pb[RP];
+  const int64_t b_step = BT ? (int64_t)BK : (int64_t)BK * p.ldb;
+  // STG 1: wave-uniform tile bases (advanced by scalar adds) + constant 32-bit lane offsets: no vector ALU work per tile
+  const T* a_base = Ag + k_begin;
+  const T* b_base = BT ? Bg + k_begin : Bg + (int64_t)k_begin * p.ldb;
+  uint32_t a_off[RP], b_off[RP];
+  // STG 0 maps
+  constexpr int VPR = BK / VEC, RROWS = NT / VPR;     // [row][k]: 8 vectors per row, 64 rows per pass
+  constexpr int NV = 128 / VEC, BROWS = NT / NV;      // [k][n]: 32 / 64 vectors per row
+  static_assert(128 / RROWS == RP && BK / BROWS == RP, "staging passes per tile");
+  const int ra_row = tid / VPR, ra_vc = (tid % VPR) * VEC;
+  const int rb_row = tid / NV, rb_vc = (tid % NV) * VEC;
+  // STG 1 maps: piece RP * wave + h; [row][k]: lane -> (row lane / 8, slot lane % 8 holding chunk slot ^ row);
+  // [k][n]: lane -> (k-row lane / CH, chunk lane % CH)
+  constexpr int CH = 128 / VEC;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
   for (int h = 0; h < RP; ++h) {
-    pa[h] = Ag + (int64_t)(ra_row + RROWS * h) * p.lda + k_begin + ra_vc;
-    pb[h] = BT ? Bg + (int64_t)(ra_row + RROWS * h) * p.ldb + k_begin + ra_vc
-               : Bg + (int64_t)(k_begin + rb_row + BROWS * h) * p.ldb + rb_vc;
+    if (STG) {
+      const int piece = RP * wave_u + h;
+      const int prow = piece * 8 + (lane >> 3), pch = ((lane & 7) ^ (lane >> 3)) * VEC;
+      a_off[h] = (uint32_t)(prow * (int)p.lda + pch);
+      b_off[h] = BT ? (uint32_t)(prow * (int)p.ldb + pch) : (uint32_t)((piece * RPP + lane / CH) * (int)p.ldb + (lane % CH) * VEC);
+      pa[h] = pb[h] = nullptr;
+    } else {
+      pa[h] = Ag + (int64_t)(ra_row + RROWS * h) * p.lda + k_begin + ra_vc;
+      pb[h] = BT ? Bg + (int64_t)(ra_row + RROWS * h) * p.ldb + k_begin + ra_vc
+                 : Bg + (int64_t)(k_begin + rb_row + BROWS * h) * p.ldb + rb_vc;
+    }
   }
-  const int64_t b_step = BT ? (int64_t)BK : (int64_t)BK * p.ldb;
-  // Global -> register -> LDS staging, PFD tiles ahead (tile i lives in register set i % PFD).  Two tiles ahead
-  // (fp32 has the registers for it) measured the same as one: the prefetch distance is not what the MFMA pipes
-  // wait for.  Kept at one.
-  constexpr int PFD = 1;
-  vec_t ga[PFD][RP], gb[PFD][RP];
-  auto gload_set = [&](auto set_c) __attribute__((always_inline)) {
-    constexpr int S = decltype(set_c)::value;
+  bool abl_started = false;          // diagnostics only (GPZ_ABL): the prologue's first tile is always staged
+  vec_t ga[RP], gb[RP];
+  // STG 0: global -> registers.  STG 1: global -> LDS buffer `buf`, asynchronously (tracked by vmcnt).
+  auto stage_load = [&](int buf) __attribute__((always_inline)) {
+    if (ABL && (GPZ_ABL & (STG ? 2 : 1)) && abl_started) return;
 #pragma unroll
     for (int h = 0; h < RP; ++h) {
-      ga[S][h] = *reinterpret_cast<const vec_t*>(pa[h]);
-      gb[S][h] = *reinterpret_cast<const vec_t*>(pb[h]);
-      pa[h] += BK;
-      pb[h] += b_step;
+      if constexpr (STG != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)   // a gfx950 builtin: the host pass of this single-source file only needs the kernel's stub
+        typedef __attribute__((address_space(3))) void lds_void;
+        const int piece = RP * wave_u + h;
+        __builtin_amdgcn_global_load_lds(a_base + a_off[h], (lds_void*)(sA(buf) + piece * (1024 / (int)sizeof(T))), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(b_base + b_off[h], (lds_void*)(sB(buf) + piece * (BT ? 1024 / (int)sizeof(T) : PIECE)), 16, 0, 0);
+#endif
+      } else {
+        ga[h] = *reinterpret_cast<const vec_t*>(pa[h]);
+        gb[h] = *reinterpret_cast<const vec_t*>(pb[h]);
+        pa[h] += BK;
+        pb[h] += b_step;
+      }
     }
+    if (STG) { a_base += BK; b_base += b_step; }
   };
-  auto sstore_set = [&](int buf, auto set_c) __attribute__((always_inline)) {
-    constexpr int S = decltype(set_c)::value;
-#pragma unroll
-    for (int h = 0; h < RP; ++h)
-      *reinterpret_cast<vec_t*>(sA(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = ga[S][h];
-    if (BT) {
-#pragma unroll
-      for (int h = 0; h < RP; ++h)
-        *reinterpret_cast<vec_t*>(sB(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = gb[S][h];
+  // STG 0: registers -> LDS buffer `buf`.  STG 1: wait for this wave's pieces to have landed.
+  auto stage_commit = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (STG != 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
+      if (ABL && (GPZ_ABL & 2) && abl_started) return;
 #pragma unroll
       for (int h = 0; h < RP; ++h)
-        *reinterpret_cast<vec_t*>(sB(buf) + (rb_row + BROWS * h) * LDN + rb_vc) = gb[S][h];
+        *reinterpret_cast<vec_t*>(sA(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = ga[h];
+      if (BT) {
+#pragma unroll
+        for (int h = 0; h < RP; ++h)
+          *reinterpret_cast<vec_t*>(sB(buf) + (ra_row + RROWS * h) * LDR + ra_vc) = gb[h];
+      } else {
+#pragma unroll
+        for (int h = 0; h < RP; ++h)
+          *reinterpret_cast<vec_t*>(sB(buf) + (rb_row + BROWS * h) * LDN + rb_vc) = gb[h];
+      }
     }
   };
   using std::integral_constant;
@@ -194,39 +249,92 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc_t{0, 0, 0, 0};
 
-  // One staged tile of MFMAs over the 16-row sub-tiles MI_LO..MI_HI of this wave (compile-time range).
-  // In each 64-byte k-chunk lane (r, q) owns k = VEC*q + j, j < VEC.
+  // fragment addresses (elements): lane (r, q) owns k = VEC * q + j, j < VEC, of each 64-byte k-chunk
+  //   STG 1 [row][k]: row w = base + r, chunk kc * 4 + q at slot (kc * 4 + q) ^ (w & 7) = ((q ^ (r & 7)) ^ (4 kc))
+  const int fr_a = STG ? (wm * 64 + r) * LDR + ((q ^ (r & 7)) * VEC) : (wm * 64 + r) * LDR + q * VEC;
+  const int fr_bt = STG ? (wn * 16 * NI + r) * LDR + ((q ^ (r & 7)) * VEC) : (wn * 16 * NI + r) * LDR + q * VEC;
+  //   [k][n]: STG 1 k-row k lives in piece k / RPP at row k % RPP; q * VEC is a multiple of RPP
+  const int fr_bn = STG ? (q * VEC / RPP) * PIECE + wn * 16 * NI + r : (q * VEC) * LDN + wn * 16 * NI + r;
+
+  // One staged tile of MFMAs over the 16-row sub-tiles MI_LO..MI_HI of this wave (compile-time range).  All fragment
+  // reads of the tile are issued up front (16 LDS instructions, 48 registers) and the MFMAs follow behind counted
+  // waits, so the LDS round trip is paid once per tile and overlaps the first MFMAs instead of recurring in front of
+  // every k-step (left to itself hipcc emits read - wait - 8 MFMAs eight times per tile for this loop).
   auto compute = [&](int buf, auto lo_c, auto hi_c) __attribute__((always_inline)) {
     constexpr int MI_LO = decltype(lo_c)::value, MI_HI = decltype(hi_c)::value;
+    vec_t fa[KV][4];
+    vec_t fbv[KV][NI];
+    T fbs[KV][VEC][NI];
 #pragma unroll
     for (int kc = 0; kc < KV; ++kc) {
-      const int ko = kc * 4 * VEC;
-      vec_t fa[4];
+      const int ko = STG ? 0 : kc * 4 * VEC;                 // STG 1: the chunk index is folded into the slot (xor)
+      const int fa_off = STG ? (fr_a ^ (kc * 4 * VEC)) : fr_a + ko;
 #pragma unroll
       for (int mi = MI_LO; mi <= MI_HI; ++mi)
-        fa[mi] = *reinterpret_cast<const vec_t*>(sA(buf) + (wm * 64 + mi * 16 + r) * LDR + ko + q * VEC);
+        fa[kc][mi] = *reinterpret_cast<const vec_t*>(sA(buf) + fa_off + mi * 16 * LDR);
       if (BT) {
-        vec_t fb[NI];
+        const int fb_off = STG ? (fr_bt ^ (kc * 4 * VEC)) : fr_bt + ko;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          fb[ni] = *reinterpret_cast<const vec_t*>(sB(buf) + (wn * 16 * NI + ni * 16 + r) * LDR + ko + q * VEC);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-#pragma unroll
-          for (int mi = MI_LO; mi <= MI_HI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni][j], acc[mi][ni]);
+          fbv[kc][ni] = *reinterpret_cast<const vec_t*>(sB(buf) + fb_off + ni * 16 * LDR);
       } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          T fb[NI];
+          const int kk = kc * 4 * VEC + j;                   // k-row of lane group q = 0
+          const int off = STG ? (kk / RPP) * PIECE + (kk % RPP) * 128 : kk * LDN;
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) fb[ni] = sB(buf)[(ko + q * VEC + j) * LDN + wn * 16 * NI + ni * 16 + r];
-#pragma unroll
-          for (int mi = MI_LO; mi <= MI_HI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = M::mma(fa[mi][j], fb[ni], acc[mi][ni]);
+          for (int ni = 0; ni < NI; ++ni) fbs[kc][j][ni] = sB(buf)[fr_bn + off + ni * 16];
         }
+      }
+    }
+#pragma unroll
+    for (int kc = 0; kc < KV; ++kc)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int mi = MI_LO; mi <= MI_HI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            if constexpr (BT) acc[mi][ni] = M::mma(fa[kc][mi][j], fbv[kc][ni][j], acc[mi][ni]);
+            else acc[mi][ni] = M::mma(fa[kc][mi][j], fbs[kc][j][ni], acc[mi][ni]);
+          }
+    // Instruction order of the tile (GPZ_SCHED, timing experiments): 0 = hipcc's own, 1 = every read first, 2 = the
+    // first k-step's reads, then three bursts behind the first MFMAs, 3 = first k-step's reads, then one read per MFMA,
+    // 4 = all A fragments + the first B operand, then one B read per k-step
+    {
+      constexpr int NMI = MI_HI - MI_LO + 1;
+      constexpr int FIRST = NMI + (BT ? NI : NI / 2);       // A fragments of chunk 0 + the first B operand (b32 pairs merged)
+      constexpr int REST = KV * NMI + (BT ? KV * NI : KV * VEC * NI) - FIRST;   // upper bound (b32 pairs may merge)
+      if constexpr (GPZ_SCHED == 1) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
+      } else if constexpr (GPZ_SCHED == 2) {
+        __builtin_amdgcn_sched_group_barrier(0x100, FIRST, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (REST + 2) / 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (REST + 2) / 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, REST, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
+      } else if constexpr (GPZ_SCHED == 3) {
+        __builtin_amdgcn_sched_group_barrier(0x100, FIRST, 0);
+#define GPZ_S3(i) if constexpr (REST > i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        GPZ_S3(0) GPZ_S3(1) GPZ_S3(2) GPZ_S3(3) GPZ_S3(4) GPZ_S3(5) GPZ_S3(6) GPZ_S3(7) GPZ_S3(8) GPZ_S3(9) GPZ_S3(10) GPZ_S3(11)
+        GPZ_S3(12) GPZ_S3(13) GPZ_S3(14) GPZ_S3(15) GPZ_S3(16) GPZ_S3(17) GPZ_S3(18) GPZ_S3(19)
+#undef GPZ_S3
+        __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
+      } else if constexpr (GPZ_SCHED == 4) {
+        constexpr int NA = KV * NMI;                         // every A fragment of the tile
+        constexpr int NB = BT ? KV * NI : KV * VEC * NI / 2; // B read instructions (b32 pairs merged)
+        __builtin_amdgcn_sched_group_barrier(0x100, FIRST, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NA - NMI, 0);
+#define GPZ_S4(i) if constexpr (NB > i) { __builtin_amdgcn_sched_group_barrier(0x008, 7, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        GPZ_S4(1) GPZ_S4(2) GPZ_S4(3) GPZ_S4(4) GPZ_S4(5) GPZ_S4(6) GPZ_S4(7) GPZ_S4(8) GPZ_S4(9) GPZ_S4(10) GPZ_S4(11)
+        GPZ_S4(12) GPZ_S4(13) GPZ_S4(14) GPZ_S4(15)
+#undef GPZ_S4
+        __builtin_amdgcn_sched_group_barrier(0x008, 128, 0);
       }
     }
   };
@@ -246,25 +354,23 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
   if ((p.flags & GF_A_LOWER) && k_end == (ti + 1) * 128 && k_begin <= ti * 128) { part_lo = true; n_post = wm_s == 0 ? PT : 0; }
   if ((p.flags & GF_A_UPPER) && k_begin == ti * 128 && k_end >= (ti + 1) * 128) { part_hi = true; n_pre = wm_s == 1 ? PT : 0; }
   if (nk > 0) {
-    gload_set(integral_constant<int, 0>{});
-    sstore_set(0, integral_constant<int, 0>{});
-    if (PFD == 2 && nk > 1) gload_set(integral_constant<int, PFD - 1>{});
+    stage_load(0);
+    stage_commit(0);
   }
   __syncthreads();
+  abl_started = true;
   int t = 0;
-  // Iteration t: fetch tile t + PFD, run tile t (when `run`), stage tile t + 1 into the other LDS buffer.
-  // Every region below starts at an even t and has an even length (k-ranges are multiples of 128 = 4 BK at
-  // most... PT tiles per 64 k), so the parity of t -- the LDS buffer and, with two register sets, which set
-  // is fetched and which is staged -- is a compile-time constant of each iteration: straight-line code, and
-  // the compiler can count exactly how many loads may still be in flight at each LDS store.
+  // Iteration t: start fetching tile t + 1 (STG 1: straight into the other LDS buffer, which every wave finished
+  // reading before the barrier that ended iteration t - 1), run tile t (when `run`), then make tile t + 1 visible
+  // (STG 0: registers -> LDS; STG 1: wait for this wave's pieces) and meet at the barrier.  Every region below starts at an
+  // even t and has an even length (PT tiles per 64 k), so the LDS buffer is a compile-time constant of each iteration.
   static_assert(PT % 2 == 0, "staged tiles come in pairs");
   auto iteration = [&](auto par_c, auto run_c, auto lo_c, auto hi_c) __attribute__((always_inline)) {
     constexpr int P = decltype(par_c)::value;                  // t & 1
-    constexpr int FS = PFD == 1 ? 0 : P, SS = PFD == 1 ? 0 : 1 - P;
-    if (t + PFD < nk) gload_set(integral_constant<int, FS>{});
+    if (t + 1 < nk) stage_load(P ^ 1);
     if constexpr (decltype(run_c)::value) compute(P, lo_c, hi_c);
-    if (t + 1 < nk) sstore_set(P ^ 1, integral_constant<int, SS>{});
-    __syncthreads();
+    if (t + 1 < nk) stage_commit(P ^ 1);
+    if (!(ABL && (GPZ_ABL & 4) && decltype(run_c)::value)) __syncthreads();
     ++t;
   };
   using no_run = integral_constant<bool, false>;
@@ -284,64 +390,7 @@ __global__ __launch_bounds__(1024 / NI, NI == 4 ? 3 : 4) void gemm128_kernel(con
     phases(phases, i0{});
   }
   const int t_main_end = nk - n_post - (part_lo ? PT : 0);
-  if constexpr (PIPE) {
-    // Software pipeline across the barrier.  A staged tile is two 64-byte k-chunks; the fragments of chunk 0 of
-    // tile t+1 are fetched from LDS right AFTER the barrier that publishes the tile, and the MFMAs of chunk 1 of
-    // tile t -- operands already in registers -- are issued behind those reads, so the pipe has 32 MFMAs (1024
-    // cycles) to chew on while the LDS round trip of the new tile is in flight; chunk 1's fragments are fetched
-    // in front of chunk 0's MFMAs the same way.  Without this each wave (and, in lock-step, its partner of the
-    // same workgroup on the same SIMD) starts every tile with all its fragment reads and an exposed LDS latency,
-    // and waits again on the operand reads the compiler places just in time mid-tile.
-    static_assert(KV == 2, "the pipelined loop is written for two k-chunks per staged tile");
-    struct Frag { vec_t a[4]; vec_t bv[NI]; T bs[VEC][NI]; };
-    auto frag_read = [&](int buf, auto kc_c, Frag& f) __attribute__((always_inline)) {
-      constexpr int ko = decltype(kc_c)::value * 4 * VEC;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        f.a[mi] = *reinterpret_cast<const vec_t*>(sA(buf) + (wm * 64 + mi * 16 + r) * LDR + ko + q * VEC);
-      if constexpr (BT) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          f.bv[ni] = *reinterpret_cast<const vec_t*>(sB(buf) + (wn * 16 * NI + ni * 16 + r) * LDR + ko + q * VEC);
-      } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) f.bs[j][ni] = sB(buf)[(ko + q * VEC + j) * LDN + wn * 16 * NI + ni * 16 + r];
-      }
-    };
-    auto frag_mma = [&](const Frag& f) __attribute__((always_inline)) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            if constexpr (BT) acc[mi][ni] = M::mma(f.a[mi][j], f.bv[ni][j], acc[mi][ni]);
-            else acc[mi][ni] = M::mma(f.a[mi][j], f.bs[j][ni], acc[mi][ni]);
-          }
-    };
-    Frag f0, f1;
-    if (t < t_main_end) frag_read(0, i0{}, f0);       // t is even here: buffer 0
-    auto piter = [&](auto par_c) __attribute__((always_inline)) {
-      constexpr int P = decltype(par_c)::value;
-      if (t + 1 < nk) gload_set(i0{});
-      frag_read(P, i1{}, f1);
-      __builtin_amdgcn_sched_barrier(0);
-      frag_mma(f0);
-      if (t + 1 < nk) sstore_set(P ^ 1, i0{});
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < t_main_end) frag_read(P ^ 1, i0{}, f0);
-      __builtin_amdgcn_sched_barrier(0);
-      frag_mma(f1);
-      ++t;
-    };
-    while (t < t_main_end) { piter(i0{}); piter(i1{}); }
-  } else {
-    while (t < t_main_end) { iteration(i0{}, run{}, i0{}, i3{}); iteration(i1{}, run{}, i0{}, i3{}); }
-  }
+  while (t < t_main_end) { iteration(i0{}, run{}, i0{}, i3{}); iteration(i1{}, run{}, i0{}, i3{}); }
   if (part_lo) {
     auto phases = [&](auto self, auto u_c) __attribute__((always_inline)) -> void {
       constexpr int U = decltype(u_c)::value;
@@ -483,11 +532,13 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   if (epilogue != EPI_STORE) GPZ_REQUIRE(!bt, "gemm: stats / column-scale epilogues are NN only");
   if (p.beta != (T)0) GPZ_REQUIRE(bt && epilogue == EPI_STORE, "gemm: accumulation (beta != 0) is built for C += A * B^T only");
   if (epilogue == EPI_STORE_COLSCALE) GPZ_REQUIRE(p.colscale && p.beta == (T)0, "gemm: column-scale epilogue needs factors and beta = 0");
-  // Tile configuration (KV 64-byte k-chunks per staged tile, NI 16-column sub-tiles per wave): both
-  // precisions run 8 waves of 64x32 on two-chunk tiles (32-deep fp32, 16-deep fp64), 4 waves per SIMD.
-  // Measured against 4 waves of 64x64 on one-chunk tiles in fp32: +0.6 % at M=2048, +4 % at M=512.
-  auto run = [&](auto kv_c, auto ni_c, auto pipe_c) -> int {
-    constexpr int KV = decltype(kv_c)::value, NI = decltype(ni_c)::value;
+  // Staging variant (GPZ_GEMM_STG): 0 = through registers (default), 1 = LDS-DMA.  Wave tile (GPZ_GEMM_NI, fp32): 2 = 64 x 32
+  // (default), 4 = 64 x 64.  Measured on config 3 (stage 1 / stage 2 TF): registers 132.6 / 136.2, LDS-DMA 126.4 / 130.8
+  // with hipcc's own instruction order and 131.7 / 136.2 with the order pinned (GPZ_SCHED=4); 64 x 64 wave tiles 129-131 /
+  // 131-133 either way.  The staging data movement itself, not the instructions that carry it, is what costs the MFMA
+  // pipes their ~10 % (timing-only builds without any staging: 144 / 149), so the simpler, longer-proven variant ships.
+  auto run = [&](auto stg_c, auto ni_c) -> int {
+    constexpr int STG = decltype(stg_c)::value, NI = decltype(ni_c)::value;
     dim3 grid((unsigned)nblocks), block(1024 / NI);
     auto launch = [&](auto kernel, size_t lds) -> int {
       // dynamic LDS above 64 KB is an opt-in per kernel FUNCTION and device: every variant has the same pointer
@@ -512,28 +563,28 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
       GPZ_LAUNCH_OK();
       return 0;
     };
-    constexpr bool PIPE = decltype(pipe_c)::value;
     if (epilogue == EPI_STORE)
-      return bt ? launch(gemm128_kernel<T, KV, NI, true, EPI_STORE, PIPE>, gemm_lds_bytes<T, KV, true>())
-                : launch(gemm128_kernel<T, KV, NI, false, EPI_STORE, PIPE>, gemm_lds_bytes<T, KV, false>());
+      return bt ? launch(gemm128_kernel<T, NI, true, EPI_STORE, STG>, GemmLds<T, true, STG>::bytes)
+                : launch(gemm128_kernel<T, NI, false, EPI_STORE, STG>, GemmLds<T, false, STG>::bytes);
     if (epilogue == EPI_WBAR) {
       GPZ_REQUIRE(p.colscale && p.colvec && p.rowvec && p.aux && p.beta == (T)0, "gemm: W-bar epilogue needs its operands");
-      return launch(gemm128_kernel<T, KV, NI, false, EPI_WBAR, PIPE>, gemm_lds_bytes<T, KV, false>());
+      return launch(gemm128_kernel<T, NI, false, EPI_WBAR, STG>, GemmLds<T, false, STG>::bytes);
     }
     if (epilogue == EPI_STORE_COLSCALE)
-      return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_COLSCALE, PIPE>, gemm_lds_bytes<T, KV, false>());
+      return launch(gemm128_kernel<T, NI, false, EPI_STORE_COLSCALE, STG>, GemmLds<T, false, STG>::bytes);
     if (epilogue == EPI_STORE_STATS)
-      return launch(gemm128_kernel<T, KV, NI, false, EPI_STORE_STATS, PIPE>, gemm_lds_bytes<T, KV, false>());
-    return launch(gemm128_kernel<T, KV, NI, false, EPI_STATS, PIPE>, gemm_lds_bytes<T, KV, false>());
+      return launch(gemm128_kernel<T, NI, false, EPI_STORE_STATS, STG>, GemmLds<T, false, STG>::bytes);
+    return launch(gemm128_kernel<T, NI, false, EPI_STATS, STG>, GemmLds<T, false, STG>::bytes);
   };
   using std::integral_constant;
-  // the pipelined k-loop needs two fragment sets in registers: fits the 128-VGPR budget of 4 waves per SIMD in fp32,
-  // not in fp64 (accumulators and fragments are twice as wide)
-  static const int pipe_mode = [] { const char* e = getenv("GPZ_GEMM_PIPE"); return e ? atoi(e) : 1; }();
-  if constexpr (sizeof(T) == 4) {
-    if (pipe_mode) return run(integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<bool, true>{});
+  static const int stg_mode = [] { const char* e = getenv("GPZ_GEMM_STG"); return e ? atoi(e) : 0; }();
+  static const int ni_mode = [] { const char* e = getenv("GPZ_GEMM_NI"); return e ? atoi(e) : 2; }();
+  if constexpr (sizeof(T) == 4) {     // 64 x 64 wave tiles: fp32 only (fp64 accumulators alone would take 128 registers)
+    if (ni_mode == 4) return stg_mode ? run(integral_constant<int, 1>{}, integral_constant<int, 4>{})
+                                      : run(integral_constant<int, 0>{}, integral_constant<int, 4>{});
   }
-  return run(integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<bool, false>{});
+  return stg_mode ? run(integral_constant<int, 1>{}, integral_constant<int, 2>{})
+                  : run(integral_constant<int, 0>{}, integral_constant<int, 2>{});
 }
 
 template int gemm_launch<float>(const GemmParams<float>&, int, hipStream_t);
