@@ -34,7 +34,35 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK = {"f32": 157.3, "f64": 78.6}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md; f64 = datasheet)
+PEAK = {"f32": 157.3, "f64": 78.6}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md; f64 = datasheet: the guide has no fp64 row)
+HBM_PEAK = 8000.0                     # GB/s, spec (MI355X_MICROARCH.md)
+
+
+def gemm_source_hash() -> str:
+    """sha256 (16 hex digits) of the dominant kernel's sources: a PMC traffic file is only quoted for the kernel it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "gemm.h", "common.h"):
+        h.update(open(os.path.join(ROOT, "gpzoo_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def latest_profile(name: str):
+    """profiles/rNN/<name> of the newest round that has it."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", name)))
+    return files[-1] if files else None
+
+
+def measured_peaks() -> dict:
+    """Denominators measured on the box by tools/peaks.sh, committed per round; {} when absent."""
+    f = latest_profile("peaks.json")
+    try:
+        d = json.load(open(f))
+        d["file"] = os.path.relpath(f, ROOT)
+        return d
+    except Exception:
+        return {}
 
 
 def parse():
@@ -102,18 +130,22 @@ def trailing_flops(nblk: int) -> float:
 
 
 def pmc_traffic(cfg_id, N, M, L, chunk):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01/traffic_stage1.json, FETCH_SIZE doubled per the gfx950 note) when this run is the
-    workload those passes measured; null otherwise.  bench.py itself cannot read PMC counters."""
-    f = os.path.join(ROOT, "profiles", "r01", "traffic_stage1.json")
+    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
+    (profiles/rNN/traffic_stage1.json, FETCH_SIZE doubled per the gfx950 note) -- quoted only when this run is the
+    workload those passes measured AND the kernel sources are the ones they measured (sha in the file); null
+    otherwise.  bench.py itself cannot read PMC counters."""
+    f = latest_profile("traffic_stage1.json")
     try:
         t = json.load(open(f))
         w = t["workload"]
-        if (w["config"], w["N"], w["M"], w["L"], w["chunk"]) == (cfg_id, N, M, L, chunk):
-            return t["hbm_bytes_per_launch"]
+        if (w["config"], w["N"], w["M"], w["L"], w["chunk"]) != (cfg_id, N, M, L, chunk):
+            return None, "no PMC passes for this workload"
+        if t.get("gemm_src_sha16") != gemm_source_hash():
+            return None, "%s measured other kernel sources (sha %s, built %s): re-run tools/profile_round.sh" % (
+                os.path.relpath(f, ROOT), t.get("gemm_src_sha16"), gemm_source_hash())
+        return t["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
     except Exception:
-        pass
-    return None
+        return None, "no committed PMC traffic file"
 
 
 def self_launch(a) -> int:
@@ -228,28 +260,44 @@ def main():
         # algorithmic flops = L * M^2 * N per evaluation (SURVEY §8d TRSM count), spread over its launches.
         flops1 = Lper * float(M) * M * N * a.steps
         ach1 = flops1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
+        mp = measured_peaks()
+        traffic, traffic_src = pmc_traffic(cfg_id, N, M, Lper, a.chunk)
         roof = {"bound": "mfma", "kernel": "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx)" % dname,
                 "achieved": ach1, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach1 / PEAK[dname],
-                "traffic": pmc_traffic(cfg_id, N, M, Lper, a.chunk), "launches": n1,
+                "traffic": traffic, "traffic_source": traffic_src, "launches": n1,
                 "avg_launch_ms": ms1 / max(n1, 1)}
+        mpk = mp.get("mfma_%s_TFLOPs" % dname)
+        if mpk:
+            roof["measured_peak"], roof["frac_of_measured_peak"] = mpk, ach1 / mpk
         kms, kn = prof["kfill"]
         esz = 4 if dname == "f32" else 8
         kbytes = (Lper * float(Mp) * N * esz) * a.steps
+        kgbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        tr_tf = (trailing_flops(Mp // 128) * Lper * a.steps / (prof["potrf_trailing"][0] * 1e-3) / 1e12
+                 if prof["potrf_trailing"][0] > 0 else 0.0)
         sub = {
-            "kuf_fill": {"bound": "hbm", "achieved_GBps": kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0, "peak_GBps": 8000.0,
+            "kuf_fill": {"bound": "hbm", "achieved_GBps": kgbs, "peak_GBps": HBM_PEAK, "frac": kgbs / HBM_PEAK,
                          "ms_per_eval": kms / a.steps},
             "stage2_LuT_Wt": {"bound": "mfma", "achieved_TFLOPs": flops1 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0,
                               "peak_TFLOPs": PEAK[dname], "ms_per_eval": ms2 / a.steps},
             "stage1_ms_per_eval": ms1 / a.steps,
             "potrf_ms_per_eval": prof["potrf_all"][0] / a.steps,
-            "potrf_trailing": {"bound": "mfma", "dtype": "f64",
-                               "achieved_TFLOPs": trailing_flops(Mp // 128) * Lper * a.steps / (prof["potrf_trailing"][0] * 1e-3) / 1e12
-                               if prof["potrf_trailing"][0] > 0 else 0.0, "peak_TFLOPs": PEAK["f64"],
+            "potrf_trailing": {"bound": "mfma", "dtype": "f64", "achieved_TFLOPs": tr_tf, "peak_TFLOPs": PEAK["f64"],
+                               "frac": tr_tf / PEAK["f64"],
                                "ms_per_eval": prof["potrf_trailing"][0] / a.steps,
                                "note": "K=256 SYRK launches only (90 % of the M^3/3 factorisation flops at M=2048)"},
             "trtri_ms_per_eval": prof["trtri"][0] / a.steps,
             "finalize_ms_per_eval": prof["finalize"][0] / a.steps,
         }
+        potrf_flops = Lper * float(Mp) ** 3 / 3.0
+        if prof["potrf_all"][0] > 0:
+            sub["potrf_whole_TFLOPs"] = potrf_flops * a.steps / (prof["potrf_all"][0] * 1e-3) / 1e12
+        if mp:   # fractions of the rates measured on the box (tools/peaks.sh), next to the spec / datasheet ones
+            sub["measured_peaks"] = {k: v for k, v in mp.items() if k != "how"}
+            if mp.get("hbm_write_GBps"):
+                sub["kuf_fill"]["frac_of_measured_write_rate"] = kgbs / mp["hbm_write_GBps"]
+            if mp.get("mfma_f64_TFLOPs"):
+                sub["potrf_trailing"]["frac_of_measured_peak"] = tr_tf / mp["mfma_f64_TFLOPs"]
         res = {
             "metric": "ELBO evals/sec (L=%d-latent evaluations, all GPUs) at M=%d inducing, N=%d, L=%d per GPU"
                       % (Lper, M, N, Lper),

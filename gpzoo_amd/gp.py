@@ -182,7 +182,12 @@ class _FusedGP(nn.Module):
         spec = kernel_spec(self.kernel, X, self._latents())
         gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
         args = (spec, X, self.Z)
-        common = dict(clamp_min=self._clamp_min, **self._cache_args(spec, X), **gk)
+        cargs = self._cache_args(spec, X)
+        if not cargs:
+            # cache_factor = False: nothing is kept ACROSS calls, but the backward pass of this very call needs the same
+            # chol(Kzz) / inverse its forward just produced -- hand it over instead of factoring twice per step
+            cargs = dict(cache=ops.FactorCache())
+        common = dict(clamp_min=self._clamp_min, **cargs, **gk)
 
         kept = {}
 

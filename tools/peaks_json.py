@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Turn tools/peaks.sh output into the peaks.json bench.py reads: the best measured rate of each kind.
+
+    python3 tools/peaks_json.py gpurun_out/peaks.txt profiles/r02/peaks.json
+"""
+import json
+import re
+import sys
+
+txt = open(sys.argv[1]).read()
+f32 = [float(m.group(1)) for m in re.finditer(r"pure mfma\s+shape=16.*?([\d.]+) TF", txt)]
+f64 = [float(m.group(1)) for m in re.finditer(r"f64 16x16x4.*?([\d.]+) TF", txt)]
+wr = [float(m.group(1)) for m in re.finditer(r"write (\d+) GB/s", txt)]
+rd = [float(m.group(1)) for m in re.finditer(r"read (\d+) GB/s", txt)]
+cp = [float(m.group(1)) for m in re.finditer(r"copy (\d+) GB/s", txt)]
+out = {"mfma_f32_TFLOPs": max(f32), "mfma_f64_TFLOPs": max(f64), "hbm_write_GBps": max(wr), "hbm_read_GBps": max(rd),
+       "hbm_copy_GBps": max(cp),
+       "how": "tools/peaks.sh on the MI355X box: register-resident v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 loops "
+              "(tools/mfma_probe_f32.hip, _f64.hip) and 16-byte-per-lane streaming kernels over 4 GiB buffers (tools/hbm_probe.hip); "
+              "best of the occupancies tried"}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(out)

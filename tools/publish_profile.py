@@ -22,7 +22,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 subprocess.run([sys.executable, here + "/pmc_summary.py", *(src + "/pmc_" + k for k in ("fetch", "write", "l2", "sq")),
                 "--json", dst + "/pmc_per_dispatch.json"], check=True, stdout=subprocess.DEVNULL)
 pmc = json.load(open(dst + "/pmc_per_dispatch.json"))
-stage1 = [k for k in pmc if "gemm128_kernel<float" in k and k.rstrip(">").endswith(", false, 1")][0]
+stage1 = [k for k in pmc if "gemm128_kernel<float" in k and ", false, 1," in k][0]     # <float, NI, NN, EPI_STORE_STATS, STG>
 v = pmc[stage1]
 cfgs = bench["config"]["workload"]
 N, M, L = (int(cfgs.split(f"{t}=")[1].split()[0].rstrip(",")) for t in ("N", "M", "L"))
@@ -30,7 +30,9 @@ Mp = (M + 127) // 128 * 128
 launches = v["dispatches"] / 3                      # bench.py --steps 2 --warmup 1
 esz = 4
 algo = (2 * L * Mp * N * esz + launches * L * Mp * Mp * esz / 2) / launches    # Kzx read + Wt write + the Linv triangle per launch
-out = {"kernel": stage1, "workload": {"config": 3, "N": N, "M": M, "L": L, "chunk": 0, "launches_per_eval": launches},
+sys.path.insert(0, os.path.dirname(here))
+from bench import gemm_source_hash  # noqa: E402
+out = {"kernel": stage1, "gemm_src_sha16": gemm_source_hash(), "workload": {"config": 3, "N": N, "M": M, "L": L, "chunk": 0, "launches_per_eval": launches},
        "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"],
        "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), averaged over "
