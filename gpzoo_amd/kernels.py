@@ -84,6 +84,19 @@ def _kernel_matrix(spec: KernelSpec, A, B, sigma, lengthscale, group_param=None,
 class _HipKernel(nn.Module):
     _kind = _lib.KERNEL_RBF
 
+    def _check_covariance(self):
+        """The vmap kernels of the reference evaluate ``self.covariance`` (kernels.py:14-20, 42-47, 75-91), which a
+        user may override; only the shipped closed forms have HIP kernels, so an overridden one is refused instead
+        of being silently replaced by the built-in formula."""
+        mine = getattr(type(self), "covariance", None)
+        if mine is None:
+            return
+        shipped = any(mine is getattr(c, "covariance", None) for c in (batched_RBF, batched_Matern32, batched_MGGP_RBF))
+        if not shipped or "covariance" in self.__dict__:
+            raise NotImplementedError(
+                f"{type(self).__name__}.covariance is user-defined: gpzoo_amd evaluates the closed-form RBF / Matern-3/2 / "
+                "multi-group RBF covariances in HIP and has no generic (vmap) path; use the reference package for custom kernels")
+
     def _spec(self, n_latent: int | None = None) -> KernelSpec:
         sig, ell = self.sigma.detach().reshape(-1), self.lengthscale.detach().reshape(-1)
         batched = self.sigma.dim() > 0 or self.lengthscale.dim() > 0
@@ -91,6 +104,7 @@ class _HipKernel(nn.Module):
         return KernelSpec(self._kind, sig.expand(L), ell.expand(L), batched or (n_latent or 1) > 1)
 
     def forward(self, X, Z, diag=False, return_distance=False):
+        self._check_covariance()
         if diag:
             return _sq(self.sigma, X.size(0))
         K = _kernel_matrix(self._spec(), X, Z, self.sigma, self.lengthscale)
@@ -182,6 +196,7 @@ class _MGGPMixin:
                           a.expand(L), r2, self._group_pow(X))
 
     def _mggp_forward(self, X, Z, groupsX, groupsZ, diag=False):
+        _HipKernel._check_covariance(self)
         if diag:
             return _sq(self.sigma, X.size(0))
         return _kernel_matrix(self._mggp_spec(X), X, Z, self.sigma, self.lengthscale, self.group_diff_param,
@@ -265,6 +280,8 @@ class batched_MGGP_RBF(_MGGPMixin, batched_RBF):
 
 def kernel_spec(kernel: nn.Module, X: torch.Tensor, n_latent: int | None = None) -> KernelSpec:
     """KernelSpec of any kernel object above (what the GP classes pass to the fused forward)."""
+    if isinstance(kernel, _HipKernel):
+        kernel._check_covariance()
     if isinstance(kernel, _MGGPMixin):
         return kernel._mggp_spec(X, n_latent)
     if isinstance(kernel, _HipKernel):

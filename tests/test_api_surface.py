@@ -161,3 +161,26 @@ def test_call_signatures_match_reference():
         if g_cmp != w or any(p[2] is None and p[0] != "device" for p in g[len(w):]):
             bad.append(f"{key}: reference {want} != {got}")
     assert not bad, "\n".join(bad)
+
+
+def test_user_defined_covariance_is_refused_not_replaced():
+    """The reference's vmap kernels evaluate an overridable ``covariance`` (kernels.py:14-20, 42-47); only the shipped
+    closed forms run in HIP, so an override must raise (on any device, before any launch) instead of silently
+    computing the built-in formula."""
+    import pytest
+    import torch
+    from gpzoo.kernels import batched_Matern32, batched_RBF
+
+    class MyKernel(batched_RBF):
+        def covariance(self, x1, x2):
+            return (x1 * x2).sum()
+
+    X = torch.zeros(3, 2)
+    with pytest.raises(NotImplementedError, match="user-defined"):
+        MyKernel()(X, X)
+    k = batched_Matern32()
+    k.covariance = lambda a, b: (a - b).abs().sum()
+    with pytest.raises(NotImplementedError, match="user-defined"):
+        k(X, X)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        batched_RBF()(X, X)                      # the shipped form passes the check and then wants CUDA tensors

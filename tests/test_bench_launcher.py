@@ -1,0 +1,58 @@
+"""CPU: `python bench.py --gpus N` typed without a launcher re-runs itself under torch.distributed.run as a CHILD
+process (one rank per GPU, 127.0.0.1 rendezvous) before anything touches the GPU; the traffic file guard and the
+measured-peaks loader are pure host logic too."""
+import json
+import os
+import sys
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+
+
+def test_self_launch_builds_the_driver_command(monkeypatch):
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    a = bench.parse()
+    assert bench.self_launch(a) == 7                      # the child's exit code comes back
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_traffic_file_is_only_quoted_for_the_kernel_it_measured(tmp_path, monkeypatch):
+    import bench
+    d = tmp_path / "profiles" / "r09"
+    d.mkdir(parents=True)
+    rec = {"workload": {"config": 3, "N": 10, "M": 4, "L": 2, "chunk": 0}, "hbm_bytes_per_launch": 123.0,
+           "gemm_src_sha16": bench.gemm_source_hash()}
+    (d / "traffic_stage1.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "latest_profile", lambda name: str(d / name))
+    assert bench.pmc_traffic(3, 10, 4, 2, 0)[0] == 123.0
+    assert bench.pmc_traffic(3, 11, 4, 2, 0)[0] is None              # another workload
+    rec["gemm_src_sha16"] = "0" * 16
+    (d / "traffic_stage1.json").write_text(json.dumps(rec))
+    val, why = bench.pmc_traffic(3, 10, 4, 2, 0)
+    assert val is None and "other kernel sources" in why              # a stale measurement is refused
+
+
+def test_committed_profiles_are_consistent_with_the_sources():
+    """Whatever profiles/rNN/traffic_stage1.json is newest either matches the built GEMM sources or is refused."""
+    import bench
+    f = bench.latest_profile("traffic_stage1.json")
+    if f is None:
+        return
+    t = json.load(open(f))
+    val, _ = bench.pmc_traffic(t["workload"]["config"], t["workload"]["N"], t["workload"]["M"], t["workload"]["L"],
+                               t["workload"]["chunk"])
+    assert (val is not None) == (t.get("gemm_src_sha16") == bench.gemm_source_hash())

@@ -61,3 +61,21 @@ def test_plain_c_program_matches_python_mirror_and_oracle(tmp_path):
     assert float(got["elbo"]) == float(out["elbo"])                 # same library, same chunking: bitwise
     for l in range(L):
         assert float(got[f"kl{l}"]) == float(out["kl"][l]) and float(got[f"loglik{l}"]) == float(out["loglik"][l])
+
+
+def test_plain_c_sharded_client_runs_the_rccl_exchange(tmp_path):
+    """examples/c_abi_shard.c as a one-rank job: communicator from gpz_comm_unique_id / gpz_comm_init, partial ELBO
+    from gpz_svgp_forward, gpz_allreduce_sum_f64 on the device scalar -- all from plain C."""
+    gcc = shutil.which("gcc")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    exe = str(tmp_path / "c_abi_shard")
+    lib = os.path.join(ROOT, "gpzoo_amd")
+    subprocess.run([gcc, "-std=gnu11", "-O2", os.path.join(ROOT, "examples", "c_abi_shard.c"), "-D__HIP_PLATFORM_AMD__",
+                    "-I" + rocm + "/include", "-I" + os.path.join(ROOT, "include"), "-L" + lib, "-lgpzoo_hip",
+                    "-L" + rocm + "/lib", "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath," + rocm + "/lib", "-o", exe],
+                   check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([exe, "1", "0", str(tmp_path / "gpz.id")], capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0, run.stderr[-1500:]
+    got = dict(line.split(" ", 1) for line in run.stdout.strip().splitlines())
+    assert got["world"] == "1" and float(got["total_elbo"]) == float(got["local_elbo"]) and float(got["local_elbo"]) < 0

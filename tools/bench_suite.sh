@@ -30,3 +30,10 @@ echo "== VNNGP: tools/vnngp_step.py"
 python3 tools/vnngp_step.py 2>/dev/null | grep VNNGP
 echo "== batched Cholesky alone, L=32 M=2048 fp64: tools/potrf_only.py"
 python3 tools/potrf_only.py 32 2048 2>/dev/null | tail -2
+echo "== batched Cholesky alone, L=8 M=512 fp64 (config 2's factor): tools/potrf_only.py"
+python3 tools/potrf_only.py 8 512 2>/dev/null | tail -2
+echo "== python bench.py --gpus 2 as typed (two ranks on this one GPU, gloo rendezvous: a rehearsal, not a scaling number)"
+GPZ_DIST_BACKEND=gloo python3 bench.py --gpus 2 --N 40000 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+r=[json.loads(l) for l in sys.stdin if l.startswith('{')][-1]
+print('  n_gpus %d ranks %d backend %s devices %d | value %.3f %s | %.2f ms/step' % (r['n_gpus'], r['ranks'], r['backend'], r['devices'], r['value'], r['unit'], r['ms_per_step']))"

@@ -9,7 +9,7 @@ import sys
 
 txt = open(sys.argv[1]).read()
 f32 = [float(m.group(1)) for m in re.finditer(r"pure mfma\s+shape=16.*?([\d.]+) TF", txt)]
-f64 = [float(m.group(1)) for m in re.finditer(r"f64 16x16x4.*?([\d.]+) TF", txt)]
+f64 = [float(m.group(1)) for m in re.finditer(r"f64 16x16x4 \S+ distinct.*?([\d.]+) TF", txt)]
 wr = [float(m.group(1)) for m in re.finditer(r"write (\d+) GB/s", txt)]
 rd = [float(m.group(1)) for m in re.finditer(r"read (\d+) GB/s", txt)]
 cp = [float(m.group(1)) for m in re.finditer(r"copy (\d+) GB/s", txt)]
