@@ -260,8 +260,11 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
   // reads of the tile are issued up front (16 LDS instructions, 48 registers) and the MFMAs follow behind counted
   // waits, so the LDS round trip is paid once per tile and overlaps the first MFMAs instead of recurring in front of
   // every k-step (left to itself hipcc emits read - wait - 8 MFMAs eight times per tile for this loop).
-  auto compute = [&](int buf, auto lo_c, auto hi_c) __attribute__((always_inline)) {
-    constexpr int MI_LO = decltype(lo_c)::value, MI_HI = decltype(hi_c)::value;
+  // The range may differ between the tile's two k-chunks (lo_c/hi_c: chunk 0, lo1_c/hi1_c: chunk 1): in the diagonal
+  // block of a triangular A the zero boundary moves by one 16-row sub-tile per 16 k, i.e. per fp32 chunk.
+  auto compute = [&](int buf, auto lo_c, auto hi_c, auto lo1_c, auto hi1_c) __attribute__((always_inline)) {
+    constexpr int LO[2] = {decltype(lo_c)::value, decltype(lo1_c)::value}, HI[2] = {decltype(hi_c)::value, decltype(hi1_c)::value};
+    constexpr int MI_LO = LO[0] < LO[1] ? LO[0] : LO[1], MI_HI = HI[0] > HI[1] ? HI[0] : HI[1];
     vec_t fa[KV][4];
     vec_t fbv[KV][NI];
     T fbs[KV][VEC][NI];
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
       const int fa_off = STG ? (fr_a ^ (kc * 4 * VEC)) : fr_a + ko;
 #pragma unroll
       for (int mi = MI_LO; mi <= MI_HI; ++mi)
-        fa[kc][mi] = *reinterpret_cast<const vec_t*>(sA(buf) + fa_off + mi * 16 * LDR);
+        if (mi >= LO[kc] && mi <= HI[kc]) fa[kc][mi] = *reinterpret_cast<const vec_t*>(sA(buf) + fa_off + mi * 16 * LDR);
       if (BT) {
         const int fb_off = STG ? (fr_bt ^ (kc * 4 * VEC)) : fr_bt + ko;
 #pragma unroll
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
         for (int mi = MI_LO; mi <= MI_HI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
+            if (mi < LO[kc] || mi > HI[kc]) continue;        // folded at compile time: the loops are fully unrolled
             if constexpr (BT) acc[mi][ni] = M::mma(fa[kc][mi][j], fbv[kc][ni][j], acc[mi][ni]);
             else acc[mi][ni] = M::mma(fa[kc][mi][j], fbs[kc][j][ni], acc[mi][ni]);
           }
@@ -365,10 +369,10 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
   // (STG 0: registers -> LDS; STG 1: wait for this wave's pieces) and meet at the barrier.  Every region below starts at an
   // even t and has an even length (PT tiles per 64 k), so the LDS buffer is a compile-time constant of each iteration.
   static_assert(PT % 2 == 0, "staged tiles come in pairs");
-  auto iteration = [&](auto par_c, auto run_c, auto lo_c, auto hi_c) __attribute__((always_inline)) {
+  auto iteration = [&](auto par_c, auto run_c, auto lo_c, auto hi_c, auto lo1_c, auto hi1_c) __attribute__((always_inline)) {
     constexpr int P = decltype(par_c)::value;                  // t & 1
     if (t + 1 < nk) stage_load(P ^ 1);
-    if constexpr (decltype(run_c)::value) compute(P, lo_c, hi_c);
+    if constexpr (decltype(run_c)::value) compute(P, lo_c, hi_c, lo1_c, hi1_c);
     if (t + 1 < nk) stage_commit(P ^ 1);
     if (!(ABL && (GPZ_ABL & 4) && decltype(run_c)::value)) __syncthreads();
     ++t;
@@ -378,28 +382,31 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
   using i0 = integral_constant<int, 0>;
   using i1 = integral_constant<int, 1>;
   using i3 = integral_constant<int, 3>;
-  // tile u of the diagonal sub-block covers k in [u*BK, (u+1)*BK): it needs the 16-row sub-tiles
-  // mi >= u*BK/16 when A is lower triangular, mi <= ((u+1)*BK-1)/16 when it is upper triangular
-  for (int u = 0; u < n_pre; u += 2) { iteration(i0{}, no_run{}, i0{}, i3{}); iteration(i1{}, no_run{}, i0{}, i3{}); }
+  // chunk c (c = 0, 1) of tile u of the diagonal sub-block covers k in [u*BK + c*BK/2, u*BK + (c+1)*BK/2): it needs the
+  // 16-row sub-tiles mi >= (first k)/16 when A is lower triangular, mi <= (last k)/16 when it is upper triangular
+  constexpr int HK = BK / 2;                 // k per chunk
+  for (int u = 0; u < n_pre; u += 2) { iteration(i0{}, no_run{}, i0{}, i3{}, i0{}, i3{}); iteration(i1{}, no_run{}, i0{}, i3{}, i0{}, i3{}); }
   if (part_hi) {
     auto phases = [&](auto self, auto u_c) __attribute__((always_inline)) -> void {
       constexpr int U = decltype(u_c)::value;
-      iteration(integral_constant<int, U & 1>{}, run{}, i0{}, integral_constant<int, ((U + 1) * BK - 1) / 16>{});
+      iteration(integral_constant<int, U & 1>{}, run{}, i0{}, integral_constant<int, (U * BK + HK - 1) / 16>{}, i0{},
+                integral_constant<int, ((U + 1) * BK - 1) / 16>{});
       if constexpr (U + 1 < PT) self(self, integral_constant<int, U + 1>{});
     };
     phases(phases, i0{});
   }
   const int t_main_end = nk - n_post - (part_lo ? PT : 0);
-  while (t < t_main_end) { iteration(i0{}, run{}, i0{}, i3{}); iteration(i1{}, run{}, i0{}, i3{}); }
+  while (t < t_main_end) { iteration(i0{}, run{}, i0{}, i3{}, i0{}, i3{}); iteration(i1{}, run{}, i0{}, i3{}, i0{}, i3{}); }
   if (part_lo) {
     auto phases = [&](auto self, auto u_c) __attribute__((always_inline)) -> void {
       constexpr int U = decltype(u_c)::value;
-      iteration(integral_constant<int, U & 1>{}, run{}, integral_constant<int, (U * BK) / 16>{}, i3{});
+      iteration(integral_constant<int, U & 1>{}, run{}, integral_constant<int, (U * BK) / 16>{}, i3{},
+                integral_constant<int, (U * BK + HK) / 16>{}, i3{});
       if constexpr (U + 1 < PT) self(self, integral_constant<int, U + 1>{});
     };
     phases(phases, i0{});
   }
-  while (t < nk) { iteration(i0{}, no_run{}, i0{}, i3{}); iteration(i1{}, no_run{}, i0{}, i3{}); }
+  while (t < nk) { iteration(i0{}, no_run{}, i0{}, i3{}, i0{}, i3{}); iteration(i1{}, no_run{}, i0{}, i3{}, i0{}, i3{}); }
 
   // ---------------- epilogue ----------------
   const int64_t crow0 = (int64_t)ti * 128 + wm * 64;
