@@ -262,7 +262,7 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
   // every k-step (left to itself hipcc emits read - wait - 8 MFMAs eight times per tile for this loop).
   // The range may differ between the tile's two k-chunks (lo_c/hi_c: chunk 0, lo1_c/hi1_c: chunk 1): in the diagonal
   // block of a triangular A the zero boundary moves by one 16-row sub-tile per 16 k, i.e. per fp32 chunk.
-  auto compute = [&](int buf, auto lo_c, auto hi_c, auto lo1_c, auto hi1_c) __attribute__((always_inline)) {
+  auto compute = [&](int buf, auto lo_c, auto hi_c, auto lo1_c, auto hi1_c, auto mid) __attribute__((always_inline)) {
     constexpr int LO[2] = {decltype(lo_c)::value, decltype(lo1_c)::value}, HI[2] = {decltype(hi_c)::value, decltype(hi1_c)::value};
     constexpr int MI_LO = LO[0] < LO[1] ? LO[0] : LO[1], MI_HI = HI[0] > HI[1] ? HI[0] : HI[1];
     vec_t fa[KV][4];
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
       }
     }
 #pragma unroll
-    for (int kc = 0; kc < KV; ++kc)
+    for (int kc = 0; kc < KV; ++kc) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j)
 #pragma unroll
@@ -302,9 +302,12 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
             if constexpr (BT) acc[mi][ni] = M::mma(fa[kc][mi][j], fbv[kc][ni][j], acc[mi][ni]);
             else acc[mi][ni] = M::mma(fa[kc][mi][j], fbs[kc][j][ni], acc[mi][ni]);
           }
+      if (kc == 0) mid();                                    // GPZ_SCHED 5: the next tile's LDS stores, mid-tile
+    }
     // Instruction order of the tile (GPZ_SCHED, timing experiments): 0 = hipcc's own, 1 = every read first, 2 = the
     // first k-step's reads, then three bursts behind the first MFMAs, 3 = first k-step's reads, then one read per MFMA,
-    // 4 = all A fragments + the first B operand, then one B read per k-step
+    // 4 = all A fragments + the first B operand, then one B read per k-step, 5 = hipcc's own order with the staging
+    // stores of the next tile placed between the two k-chunks instead of behind the last MFMA
     {
       constexpr int NMI = MI_HI - MI_LO + 1;
       constexpr int FIRST = NMI + (BT ? NI : NI / 2);       // A fragments of chunk 0 + the first B operand (b32 pairs merged)
@@ -372,8 +375,16 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
   auto iteration = [&](auto par_c, auto run_c, auto lo_c, auto hi_c, auto lo1_c, auto hi1_c) __attribute__((always_inline)) {
     constexpr int P = decltype(par_c)::value;                  // t & 1
     if (t + 1 < nk) stage_load(P ^ 1);
-    if constexpr (decltype(run_c)::value) compute(P, lo_c, hi_c, lo1_c, hi1_c);
-    if (t + 1 < nk) stage_commit(P ^ 1);
+    if constexpr (decltype(run_c)::value && GPZ_SCHED == 5) {
+      compute(P, lo_c, hi_c, lo1_c, hi1_c, [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nk) stage_commit(P ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    } else {
+      if constexpr (decltype(run_c)::value) compute(P, lo_c, hi_c, lo1_c, hi1_c, [] {});
+      if (t + 1 < nk) stage_commit(P ^ 1);
+    }
     if (!(ABL && (GPZ_ABL & 4) && decltype(run_c)::value)) __syncthreads();
     ++t;
   };

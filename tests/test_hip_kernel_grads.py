@@ -143,3 +143,39 @@ def test_exact_mggp_notebook_step():
     for name, got in (("grad_sigma", kernel.sigma.grad), ("grad_lengthscale", kernel.lengthscale.grad),
                       ("grad_group_diff_param", kernel.group_diff_param.grad), ("grad_noise", noise.grad)):
         torch.testing.assert_close(got.cpu(), g[name], rtol=1e-6, atol=1e-9, msg=lambda m: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("d", [1, 3, 4])
+@pytest.mark.parametrize("cls", ["NSF_RBF", "batched_Matern32"])
+def test_kernel_gradients_in_other_input_dimensions(d, cls):
+    """d = 1, 3, 4 inputs (the fixtures are 2-D): gradients of sum(K * R) against torch autograd through the closed
+    form written out in torch (fp64)."""
+    import gpzoo.kernels as K
+    g = torch.Generator().manual_seed(40 + d)
+    L, N, M = 3, 37, 11
+    X = (torch.rand(N, d, generator=g, dtype=torch.float64) - 0.5) * 8
+    Z = (torch.rand(M, d, generator=g, dtype=torch.float64) - 0.5) * 8
+    R = torch.randn(L, N, M, generator=g, dtype=torch.float64)
+    sig = torch.tensor([1.0, 0.8, 1.3], dtype=torch.float64)
+    ell = torch.tensor([2.5, 4.0, 1.5], dtype=torch.float64)
+    if cls == "NSF_RBF":
+        k = K.NSF_RBF(L=L)
+        k.sigma, k.lengthscale = nn.Parameter(sig.reshape(L, 1, 1).clone()), nn.Parameter(ell.reshape(L, 1, 1).clone())
+    else:
+        k = K.batched_Matern32()
+        k.sigma, k.lengthscale = nn.Parameter(sig.clone()), nn.Parameter(ell.clone())
+    k = k.double().cuda()
+    Xg, Zg = X.cuda().requires_grad_(True), Z.cuda().requires_grad_(True)
+    (k(Xg, Zg) * R.cuda()).sum().backward()
+    Xr, Zr = X.clone().requires_grad_(True), Z.clone().requires_grad_(True)
+    sr, lr = sig.clone().requires_grad_(True), ell.clone().requires_grad_(True)
+    d2 = ((Xr[:, None, :] - Zr[None, :, :]) ** 2).sum(-1)
+    if cls == "NSF_RBF":
+        Kr = sr[:, None, None] ** 2 * torch.exp(-0.5 * d2 / lr[:, None, None] ** 2)
+    else:
+        v = (3 ** 0.5) * torch.sqrt(d2) / lr[:, None, None]
+        Kr = sr[:, None, None] ** 2 * (1 + v) * torch.exp(-v)
+    (Kr * R).sum().backward()
+    for got, ref, nm in ((Xg.grad, Xr.grad, "X"), (Zg.grad, Zr.grad, "Z"), (k.sigma.grad.reshape(-1), sr.grad, "sigma"),
+                         (k.lengthscale.grad.reshape(-1), lr.grad, "lengthscale")):
+        torch.testing.assert_close(got.cpu(), ref, rtol=1e-8, atol=1e-10, msg=lambda m: f"{nm} d={d}: {m}")
