@@ -16,7 +16,24 @@
 // [32][32] column buffer and the reciprocal diagonal of the sub-block in flight follow S.
 #include "common.h"
 
+#include <type_traits>
+
 namespace gpz {
+
+// Diagnostic build only (-DGPZ_DIAG_STAMPS, tools/diag_stamps.sh): cycle stamps of workgroup 0 at the phase boundaries.
+#ifdef GPZ_DIAG_STAMPS
+__device__ unsigned long long g_diag_stamps[64];
+#define GPZ_STAMP(i)                                                                  \
+  do {                                                                                \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                     \
+      unsigned long long t_;                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      g_diag_stamps[i] = t_;                                                          \
+    }                                                                                 \
+  } while (0)
+#else
+#define GPZ_STAMP(i) do {} while (0)
+#endif
 
 namespace {
 constexpr int DP = 129;  // LDS pitch
@@ -44,24 +61,32 @@ __device__ __forceinline__ int vzero() {
   return z;
 }
 
-// 1/sqrt(d) in fp64: hardware seed + Newton steps (r <- r (1.5 - 0.5 d r^2)); ~25 instructions less
-// than sqrt followed by a division, and it sits on the critical path of every column.
-__device__ __forceinline__ double rsqrt_nr(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  const double h = 0.5 * d;
+// sqrt(d) and 1/sqrt(d) in fp64 from the hardware seed (v_rsq_f64, relative error ~2^-23) by two coupled Goldschmidt
+// steps  r = 1/2 - g h;  g += g r;  h += h r  (g -> sqrt(d), h -> 1/(2 sqrt(d)); quadratic: 2^-23 -> 2^-45 -> < 2^-53).
+// Both results come out of ONE chain of 6 dependent operations; Newton steps for 1/sqrt(d) followed by a corrected
+// product for sqrt(d) took 13, and this chain sits on the critical path of every column of the factorisation.
+__device__ __forceinline__ void sqrt_rsqrt(double d, double& sq, double& rs) {
+  const double y = __builtin_amdgcn_rsq(d);
+  double g = d * y, h = 0.5 * y;
 #pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const double t = r * r;
-    r = r * fma(-h, t, 1.5);
+  for (int it = 0; it < 2; ++it) {
+    const double r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
   }
-  return r;
+  sq = g;
+  rs = h + h;
 }
 
-// One wave: right-looking Cholesky of the 32x32 block at offset o.  Lane i (and its twin i+32) holds
-// row i in registers.  The running diagonal a_ii - sum_k l_ik^2 is carried separately, so the next
-// pivot (v_readlane) and its reciprocal square root do not wait for the LDS round trip of the
-// finished column; the multipliers l_kj come back from the compact column buffer CB[j][k] as
-// uniform-address (broadcast) reads.  RI[j] = 1 / l_jj for the inverse.
+// One wave: right-looking Cholesky of the 32x32 block at offset o.  Lane i (and its twin i+32) holds row i in
+// registers.  Per column the dependent chain is: pivot (v_readlane of the running diagonal), its reciprocal square
+// root (v_rsq_f64 + Newton steps: ~17 dependent fp64 operations, ~200 cycles), the multipliers l_ij = a_ij r.  What
+// the NEXT column needs from this one is only a_(i,j+1) and the running diagonal a_ii - sum_k l_ik^2, so those two are
+// updated at once (multiplier by v_readlane) and the other 30 - j row updates of the column are deferred into the next
+// column's body, where they issue in the latency shadow of its pivot chain with multipliers read back from the
+// compact column buffer CB[j][k] (uniform-address LDS broadcasts; the write -> read round trip is off the critical
+// path by then).  Stamps (tools/diag_stamps.sh): 600 -> ~250 cycles per column against everything done in place.
+// RI[j] = 1 / l_jj for the inverse.
 __device__ __forceinline__ void factor32(double* S, double* CBu, double* RI, int o, int lane, int32_t* info,
                                          int64_t gbase, int64_t m_real) {
   const int zz = vzero();          // also keeps the 32 lane-compare masks from being hoisted out of the caller's loop
@@ -71,6 +96,7 @@ __device__ __forceinline__ void factor32(double* S, double* CBu, double* RI, int
 #pragma unroll
   for (int k = 0; k < 32; ++k) a[k] = S[(o + i) * DP + o + k];
   double diag = S[(o + i) * DP + o + i];
+  double lprev = 0.0;
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
     double d = bcast(diag, j);
@@ -78,18 +104,20 @@ __device__ __forceinline__ void factor32(double* S, double* CBu, double* RI, int
       if (lane == 0 && gbase + j < m_real) atomicCAS(info, 0, (int)(gbase + j + 1));
       d = 1.0;
     }
-    const double r = rsqrt_nr(d);
-    double sq = d * r;
-    sq = fma(0.5 * r, fma(-sq, sq, d), sq);          // sqrt(d), one correction step
+    // deferred row updates of column j-1 (k = j was done on the spot there): independent of the pivot chain below
+    if (j >= 1) {
+#pragma unroll
+      for (int k = j + 1; k < 32; ++k) a[k] = fma(-lprev, CB[(j - 1) * 32 + k], a[k]);
+    }
+    double sq, r;
+    sqrt_rsqrt(d, sq, r);
     const double lj = (i == j) ? sq : a[j] * r;      // rows i < j carry garbage that is never read back
     diag = fma(-lj, lj, diag);
-    if (lane < 32) {
-      CBu[j * 32 + i] = lj;
-      if (i >= j) S[(o + i) * DP + o + j] = lj;
-      if (i == j) RI[j] = r;
-    }
-#pragma unroll
-    for (int k = j + 1; k < 32; ++k) a[k] = fma(-lj, CB[j * 32 + k], a[k]);
+    if (j + 1 < 32) a[j + 1] = fma(-lj, bcast(lj, j + 1), a[j + 1]);   // what column j+1 needs, now
+    CBu[j * 32 + i] = lj;                             // twin lanes store the same value to the same address
+    RI[j] = r;                                        // wave-uniform
+    if (i >= j) S[(o + i) * DP + o + j] = lj;
+    lprev = lj;
     // pin the updates to this column: LLVM otherwise sinks each one to the column that consumes it and keeps
     // all 496 broadcast values alive until then (spills)
 #pragma unroll
@@ -118,12 +146,23 @@ __device__ __forceinline__ void invert32(double* S, const double* CBu, const dou
   double acc[32];
 #pragma unroll
   for (int m = 0; m < 32; ++m) acc[m] = (m == c) ? 1.0 : 0.0;
+  // column ii of L (the multipliers of step ii) is fetched one step ahead into the other half of cb[][]: the factor is
+  // complete before this loop, so only the order of the loads decides whether each step waits for an LDS round trip
+  double cb[2][32], ri[2];
+#pragma unroll
+  for (int m = 1; m < 32; ++m) cb[0][m] = CB[m];
+  ri[0] = RI[0];
 #pragma unroll
   for (int ii = 0; ii < 32; ++ii) {
-    const double x = acc[ii] * RI[ii];
+    if (ii + 1 < 32) {
+#pragma unroll
+      for (int m = ii + 2; m < 32; ++m) cb[(ii + 1) & 1][m] = CB[(ii + 1) * 32 + m];
+      ri[(ii + 1) & 1] = RI[ii + 1];
+    }
+    const double x = acc[ii] * ri[ii & 1];
     if (lane < 32 && ii >= c) XT(S, o + c, o + ii) = x;
 #pragma unroll
-    for (int m = ii + 1; m < 32; ++m) acc[m] = fma(-CB[ii * 32 + m], x, acc[m]);
+    for (int m = ii + 1; m < 32; ++m) acc[m] = fma(-cb[ii & 1][m], x, acc[m]);
 #pragma unroll
     for (int m = ii + 1; m < 32; ++m) asm volatile("" : "+v"(acc[m]));
     __builtin_amdgcn_sched_barrier(0);
@@ -142,6 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int b = blockIdx.x;
   if (bk < 0) bk = blockIdx.y;   // all diagonal blocks in one launch (inverse-only mode)
   double* Ab = A + (int64_t)b * stride + (int64_t)bk * 128 * (lda + 1);
+  GPZ_STAMP(0);
   {
     // the whole block with 32 independent 16-byte loads per thread in flight (a rolled load -> LDS loop pays
     // one memory round trip per element: 64 x ~0.7 us); the strict upper triangle is zeroed on the way in
@@ -161,13 +201,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   if (tid < 128) S[tid * DP + 128] = 0.0;
   __syncthreads();
+  GPZ_STAMP(1);
 
   for (int s = 0; s < 4; ++s) {
     const int o = 32 * s;
     if (w == 0) {
       if (factor) factor32(S, CB, RI, o, lane, info + b, (int64_t)bk * 128 + o, m_real);
       else stage32(S, CB, RI, o, lane);
+      GPZ_STAMP(2 + 4 * s);
       invert32(S, CB, RI, o, lane);
+      GPZ_STAMP(3 + 4 * s);
     }
     __syncthreads();
     if (!factor || s == 3) continue;
@@ -177,20 +220,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int ntiles = ((128 - R0) / 16) * 2;
       d4 acc[3];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        acc[u] = d4{0, 0, 0, 0};
-        const int t = w + 4 * u;
-        if (t < ntiles) {
-          const int i0 = R0 + 16 * (t >> 1), j = 16 * (t & 1) + r;
+      for (int u = 0; u < 3; ++u) acc[u] = d4{0, 0, 0, 0};
+      // every wave owns ntiles / 4 = 3 - s tiles (t = w, w+4, w+8): advanced together k-step by k-step, as independent
+      // MFMA chains, in a body specialised on that count (MFMAs under a run-time condition make hipcc shuffle the
+      // accumulators through VGPR copies: measured 2x slower)
+      auto panel = [&](auto nu_c) __attribute__((always_inline)) {
+        constexpr int NU = decltype(nu_c)::value;
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            const int k = 4 * kk + q;
+        for (int kk = 0; kk < 8; ++kk) {
+          const int k = 4 * kk + q;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            const int t = w + 4 * u;
+            const int i0 = R0 + 16 * (t >> 1), j = 16 * (t & 1) + r;
             const double av = S[(i0 + r) * DP + o + k];
             const double bv = (j >= k) ? XT(S, o + k, o + j) : 0.0;   // inv(Lss)[j][k]
             acc[u] = mma(av, bv, acc[u]);
           }
         }
-      }
+      };
+      if (s == 0) panel(std::integral_constant<int, 3>{});
+      else if (s == 1) panel(std::integral_constant<int, 2>{});
+      else panel(std::integral_constant<int, 1>{});
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
@@ -203,14 +254,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       __syncthreads();
     }
+    GPZ_STAMP(4 + 4 * s);
     // ---- in-block trailing update: A[a][b] -= L[a][s] L[b][s]^T, 16x16 tiles with a >= b ----
     {
       const int n16 = (128 - R0) / 16;
       const int nl = n16 * (n16 + 1) / 2;
-      for (int t = w; t < nl; t += 4) {
+      // two tiles of a wave at a time (t and t + 4), advanced together as independent MFMA chains; the loop condition
+      // makes both valid, so no MFMA sits under a branch; a possible last single tile follows
+      auto tile_of = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
         int ta = 0, rem = t;
         while (rem > ta) { rem -= ta + 1; ++ta; }
-        const int i0 = R0 + 16 * ta, j0 = R0 + 16 * rem;
+        i0 = R0 + 16 * ta; j0 = R0 + 16 * rem;
+      };
+      int t = w;
+      for (; t + 4 < nl; t += 8) {
+        int ia, ja, ib, jb;
+        tile_of(t, ia, ja);
+        tile_of(t + 4, ib, jb);
+        d4 acc0, acc1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { acc0[g] = S[(ia + q + 4 * g) * DP + ja + r]; acc1[g] = S[(ib + q + 4 * g) * DP + jb + r]; }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int k = o + 4 * kk + q;
+          acc0 = mma(-S[(ia + r) * DP + k], S[(ja + r) * DP + k], acc0);
+          acc1 = mma(-S[(ib + r) * DP + k], S[(jb + r) * DP + k], acc1);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { S[(ia + q + 4 * g) * DP + ja + r] = acc0[g]; S[(ib + q + 4 * g) * DP + jb + r] = acc1[g]; }
+      }
+      if (t < nl) {
+        int i0, j0;
+        tile_of(t, i0, j0);
         d4 acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = S[(i0 + q + 4 * g) * DP + j0 + r];
@@ -224,15 +299,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       __syncthreads();
     }
+    GPZ_STAMP(5 + 4 * s);
   }
+  GPZ_STAMP(18);
 
   // ---- write the factor back (zeros above the diagonal) ----
-  if (factor)
-    for (int e = tid; e < 128 * 128; e += 256) {
-      const int i = e >> 7, j = e & 127;
-      Ab[(int64_t)i * lda + j] = (j <= i) ? S[i * DP + j] : 0.0;
+  if (factor) {
+#pragma unroll 1
+    for (int e0 = tid; e0 < 128 * 128; e0 += 256 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u, i = e >> 7, j = e & 127;
+        v[u] = (j <= i) ? S[i * DP + j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u;
+        Ab[(int64_t)(e >> 7) * lda + (e & 127)] = v[u];
+      }
     }
+  }
 
+  GPZ_STAMP(19);
   // ---- inverse, level 1: 32 -> 64.  wave = (pair p, column tile jt of the left block) ----
   {
     const int p = w >> 1, jt = w & 1;
@@ -269,45 +358,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int g = 0; g < 4; ++g) XT(S, oA + j, oB + 16 * it + q + 4 * g) = X[it][g];
   }
   __syncthreads();
+  GPZ_STAMP(20);
   // ---- inverse, level 2: 64 -> 128.  wave = column tile jt of the left 64 columns ----
   {
     const int jt = w, j = 16 * jt + r;
     d4 T[4], X[4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      T[kt] = d4{0, 0, 0, 0};
+    for (int kt = 0; kt < 4; ++kt) { T[kt] = d4{0, 0, 0, 0}; X[kt] = d4{0, 0, 0, 0}; }
+    // the four tiles of T (and then of X) advance together: independent MFMA chains in flight, B operand shared
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int k = 4 * kk + q;
-        const double av = S[(64 + 16 * kt + r) * DP + k];                      // C = L[64:128][0:64]
-        const double bv = (k >= j) ? XT(S, j, k) : 0.0;                        // A^-1[k][j], A = X[0:64][0:64]
-        T[kt] = mma(av, bv, T[kt]);
-      }
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = 4 * kk + q;
+      const double bv = (k >= j) ? XT(S, j, k) : 0.0;                          // A^-1[k][j], A = X[0:64][0:64]
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) T[kt] = mma(S[(64 + 16 * kt + r) * DP + k], bv, T[kt]);   // C = L[64:128][0:64]
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      X[it] = d4{0, 0, 0, 0};
-      const int i = 16 * it + r;
+    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int kt = 0; kt <= it; ++kt)
+      for (int g = 0; g < 4; ++g) {
+        const int k = 16 * kt + 4 * g + q;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int k = 16 * kt + 4 * g + q;
+        for (int it = kt; it < 4; ++it) {
+          const int i = 16 * it + r;
           const double av = (k <= i) ? XT(S, 64 + k, 64 + i) : 0.0;            // B^-1[i][k], B = X[64:][64:]
           X[it] = mma(-av, T[kt][g], X[it]);
         }
-    }
+      }
 #pragma unroll
     for (int it = 0; it < 4; ++it)
 #pragma unroll
       for (int g = 0; g < 4; ++g) XT(S, j, 64 + 16 * it + q + 4 * g) = X[it][g];
   }
   __syncthreads();
+  GPZ_STAMP(21);
   double* Db = Dinv + (int64_t)b * dinv_stride + (int64_t)bk * 128 * 128;
-  for (int e = tid; e < 128 * 128; e += 256) {
-    const int i = e >> 7, c = e & 127;
-    Db[e] = (c <= i) ? XT(S, c, i) : 0.0;
+#pragma unroll 1
+  for (int e0 = tid; e0 < 128 * 128; e0 += 256 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u, i = e >> 7, c = e & 127;
+      v[u] = (c <= i) ? XT(S, c, i) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) Db[e0 + 256 * u] = v[u];
   }
+  GPZ_STAMP(22);
 }
+
+#ifdef GPZ_DIAG_STAMPS
+extern "C" int gpz_debug_diag_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_diag_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace gpz
