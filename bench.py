@@ -39,10 +39,11 @@ HBM_PEAK = 8000.0                     # GB/s, spec (MI355X_MICROARCH.md)
 
 
 def gemm_source_hash() -> str:
-    """sha256 (16 hex digits) of the dominant kernel's sources: a PMC traffic file is only quoted for the kernel it measured."""
+    """sha256 (16 hex digits) of the dominant kernel's sources and of its launcher (svgp.hip fixes the strip width and the
+    N-chunking): a PMC traffic file is only quoted for the code it measured."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "gemm.h", "common.h"):
+    for f in ("gemm.hip", "gemm.h", "common.h", "svgp.hip"):
         h.update(open(os.path.join(ROOT, "gpzoo_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
