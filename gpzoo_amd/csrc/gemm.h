@@ -34,6 +34,7 @@ struct GemmParams {
   int K = 0;                // contraction extent (multiple of 128 when a triangular flag is set)
   int flags = 0;
   int super_cols = 8;       // GF_GROUP_COLS: column tiles per L2 super-tile
+  int tiles_per_wg = 1;     // GF_GROUP_COLS: column tiles of one row tile a workgroup computes back to back
   T alpha = 1, beta = 0;
   // column statistics (EPI_STORE_STATS / EPI_STATS): partial sums per (outer batch, row tile, column)
   const T* mu = nullptr; int64_t sMu = 0;  // (outer batch, K) vector, padded with zeros

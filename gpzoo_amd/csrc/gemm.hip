@@ -92,7 +92,9 @@ struct GemmLds {
 // NI = 16-column sub-tiles per wave: 2 -> 8 waves (2 x 4) of 64 x 32, four waves per SIMD; 4 -> 4 waves (2 x 2) of
 // 64 x 64, two waves per SIMD (one per workgroup: no two waves of a SIMD share a barrier) and a third less LDS read
 // traffic per flop.
-template <typename T, int NI, bool BT, int EPI, int STG>
+// MULTI: a workgroup may compute several column tiles back to back (GemmParams::tiles_per_wg); a separate instantiation
+// because the outer loop costs registers (the fp64 kernels would spill).
+template <typename T, int NI, bool BT, int EPI, int STG, bool MULTI = false>
 __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / NI, 8 / NI))) void gemm128_kernel(const GemmParams<T> p) {
   constexpr int WN = 8 / NI;                // waves along N
   constexpr int NT = 128 * WN;
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
 
   // ---------------- tile decode ----------------
   int b0, b1, ti, tj;
+  int ntile = 1, tj_step = 0;   // column tiles this workgroup computes, and their distance in tiles
   {
     const int bid = blockIdx.x;
     if (p.flags & GF_GROUP_COLS) {
@@ -120,16 +123,24 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
       // (latent, strip of SUPER_COLS column tiles) units; inside a unit, row tiles go longest
       // k-range first and the SUPER_COLS blocks of one row tile are dispatched together, so they
       // stream the same A panel in lock-step while the unit's B panels stay L2 resident.
+      // With tiles_per_wg = TPW > 1 a workgroup walks TPW column tiles of its row tile one after the other (columns w,
+      // w + W, ... of the strip, W = SUPER_COLS / TPW workgroups per row tile): same A panel, same k-range, and the
+      // first loads of the next tile are in flight while the epilogue of the current one runs.
       const int SUPER_COLS = p.super_cols;
+      const int W = MULTI ? SUPER_COLS / p.tiles_per_wg : SUPER_COLS;
       const int x = bid & 7, s = bid >> 3;
       const int strips = (p.nt + SUPER_COLS - 1) / SUPER_COLS;
-      const int per_unit = p.mt * SUPER_COLS;
+      const int per_unit = p.mt * W;
       const int unit = (s / per_unit) * 8 + x, within = s % per_unit;
       if (unit >= p.nb0 * strips) return;
       b0 = unit / strips; b1 = 0;
-      const int ii = within / SUPER_COLS;
-      tj = (unit - b0 * strips) * SUPER_COLS + within % SUPER_COLS;
+      const int ii = within / W;
+      tj = (unit - b0 * strips) * SUPER_COLS + within % W;
       if (tj >= p.nt) return;
+      if (MULTI) {
+        tj_step = W;
+        ntile = min(p.tiles_per_wg, (p.nt - tj + W - 1) / W);
+      }
       ti = (p.flags & GF_A_LOWER) ? p.mt - 1 - ii : ii;   // longest k-range first
     } else {
       const int per = (p.flags & GF_TILES_LOWER) ? p.mt * (p.mt + 1) / 2 : p.mt * p.nt;
@@ -244,10 +255,6 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
   using std::integral_constant;
 
   acc_t acc[4][NI];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc_t{0, 0, 0, 0};
 
   // fragment addresses (elements): lane (r, q) owns k = VEC * q + j, j < VEC, of each 64-byte k-chunk
   //   STG 1 [row][k]: row w = base + r, chunk kc * 4 + q at slot (kc * 4 + q) ^ (w & 7) = ((q ^ (r & 7)) ^ (4 kc))
@@ -360,13 +367,18 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
   bool part_lo = false, part_hi = false;
   if ((p.flags & GF_A_LOWER) && k_end == (ti + 1) * 128 && k_begin <= ti * 128) { part_lo = true; n_post = wm_s == 0 ? PT : 0; }
   if ((p.flags & GF_A_UPPER) && k_begin == ti * 128 && k_end >= (ti + 1) * 128) { part_hi = true; n_pre = wm_s == 1 ? PT : 0; }
-  if (nk > 0) {
-    stage_load(0);
-    stage_commit(0);
-  }
+  if (nk > 0) stage_load(0);
+  int t = 0;
+  for (int ct = 0;; ++ct) {       // column tiles of this workgroup
+  const int tjc = tj + ct * tj_step;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc_t{0, 0, 0, 0};
+  if (nk > 0) stage_commit(0);
   __syncthreads();
   abl_started = true;
-  int t = 0;
+  t = 0;
   // Iteration t: start fetching tile t + 1 (STG 1: straight into the other LDS buffer, which every wave finished
   // reading before the barrier that ended iteration t - 1), run tile t (when `run`), then make tile t + 1 visible
   // (STG 0: registers -> LDS; STG 1: wait for this wave's pieces) and meet at the barrier.  Every region below starts at an
@@ -419,9 +431,23 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
   }
   while (t < nk) { iteration(i0{}, no_run{}, i0{}, i3{}, i0{}, i3{}); iteration(i1{}, no_run{}, i0{}, i3{}, i0{}, i3{}); }
 
+  // next column tile: operands back to k_begin, B over by tj_step tiles; with register staging its first staged tile
+  // travels while the epilogue below runs (LDS buffer 0 is only written after the barrier that ends the epilogue)
+  const bool more = MULTI && ct + 1 < ntile;
+  if (more && nk > 0) {
+    const int64_t a_back = (int64_t)nk * BK;
+    const int64_t b_fwd = (BT ? (int64_t)tj_step * 128 * p.ldb : (int64_t)tj_step * 128) - (int64_t)nk * b_step;
+    if (STG) { a_base -= a_back; b_base += b_fwd; }
+    else {
+#pragma unroll
+      for (int h = 0; h < RP; ++h) { pa[h] -= a_back; pb[h] += b_fwd; }
+    }
+    abl_started = false;
+    if (STG == 0) stage_load(0);
+  }
   // ---------------- epilogue ----------------
   const int64_t crow0 = (int64_t)ti * 128 + wm * 64;
-  const int64_t ccol0 = (int64_t)tj * 128 + wn * 16 * NI;
+  const int64_t ccol0 = (int64_t)tjc * 128 + wn * 16 * NI;
   if (EPI == EPI_STORE_STATS || EPI == EPI_STATS) {
     // column sums over this block's 128 rows: registers -> lane groups -> the two wm waves
     T* red = smem;  // [2 stats][2 wm][128 cols]; all tile reads are behind the loop's last barrier
@@ -446,7 +472,7 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
     }
     __syncthreads();
     if (tid < 128) {
-      const int64_t o = ((int64_t)b0 * p.mt + ti) * p.ncols + (int64_t)tj * 128 + tid;
+      const int64_t o = ((int64_t)b0 * p.mt + ti) * p.ncols + (int64_t)tjc * 128 + tid;
       p.ps_sq[o] = red[tid] + red[128 + tid];
       if (EPI == EPI_STORE_STATS) p.ps_mu[o] = red[256 + tid] + red[384 + tid];
     }
@@ -527,6 +553,10 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
       }
     }
   }
+  if (!MULTI || !more) break;
+  __syncthreads();                 // every wave is done with the epilogue's LDS scratch (it aliases tile buffer 0)
+  if (STG != 0 && nk > 0) stage_load(0);   // LDS-DMA writes LDS directly: only now
+  }
 }
 
 template <typename T>
@@ -537,10 +567,17 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   int64_t nblocks;
   if (p.flags & GF_GROUP_COLS) {
     GPZ_REQUIRE(p.nb1 == 1 && !(p.flags & GF_TILES_LOWER), "gemm: GROUP_COLS needs a flat batch and a full tile grid");
-    const int sc = p.super_cols;
+    const int sc = p.super_cols, tpw = p.tiles_per_wg;
     GPZ_REQUIRE(sc >= 1, "gemm: super_cols must be >= 1");
+    GPZ_REQUIRE(tpw >= 1 && sc % tpw == 0, "gemm: tiles_per_wg=%d must divide super_cols=%d", tpw, sc);
+    if (tpw > 1) {
+      GPZ_REQUIRE((sc / tpw) % 2 == 0 && !(p.flags & (GF_B_LOWER | GF_B_UPPER)),
+                  "gemm: tiles_per_wg > 1 needs an even number of workgroups per row tile and a dense B");
+      GPZ_REQUIRE(sizeof(T) == 4 && (epilogue == EPI_STORE_STATS || epilogue == EPI_STATS),
+                  "gemm: tiles_per_wg > 1 is built for the fp32 statistics epilogues only");
+    }
     const int64_t units = (int64_t)p.nb0 * ((p.nt + sc - 1) / sc);
-    nblocks = (units + 7) / 8 * 8 * p.mt * sc;
+    nblocks = (units + 7) / 8 * 8 * p.mt * (sc / tpw);
   } else {
     const int64_t per = (p.flags & GF_TILES_LOWER) ? (int64_t)p.mt * (p.mt + 1) / 2 : (int64_t)p.mt * p.nt;
     nblocks = per * p.nb0 * p.nb1;
@@ -555,6 +592,7 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   // with hipcc's own instruction order and 131.7 / 136.2 with the order pinned (GPZ_SCHED=4); 64 x 64 wave tiles 129-131 /
   // 131-133 either way.  The staging data movement itself, not the instructions that carry it, is what costs the MFMA
   // pipes their ~10 % (timing-only builds without any staging: 144 / 149), so the simpler, longer-proven variant ships.
+  const bool multi = (p.flags & GF_GROUP_COLS) && p.tiles_per_wg > 1;
   auto run = [&](auto stg_c, auto ni_c) -> int {
     constexpr int STG = decltype(stg_c)::value, NI = decltype(ni_c)::value;
     dim3 grid((unsigned)nblocks), block(1024 / NI);
@@ -590,6 +628,13 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
     }
     if (epilogue == EPI_STORE_COLSCALE)
       return launch(gemm128_kernel<T, NI, false, EPI_STORE_COLSCALE, STG>, GemmLds<T, false, STG>::bytes);
+    if constexpr (sizeof(T) == 4 && NI == 2 && STG == 0) {
+      if (multi && epilogue == EPI_STORE_STATS)
+        return launch(gemm128_kernel<T, NI, false, EPI_STORE_STATS, STG, true>, GemmLds<T, false, STG>::bytes);
+      if (multi && epilogue == EPI_STATS)
+        return launch(gemm128_kernel<T, NI, false, EPI_STATS, STG, true>, GemmLds<T, false, STG>::bytes);
+    }
+    GPZ_REQUIRE(!multi, "gemm: tiles_per_wg > 1 is built for the fp32 statistics epilogues (register staging, 64 x 32 wave tiles)");
     if (epilogue == EPI_STORE_STATS)
       return launch(gemm128_kernel<T, NI, false, EPI_STORE_STATS, STG>, GemmLds<T, false, STG>::bytes);
     return launch(gemm128_kernel<T, NI, false, EPI_STATS, STG>, GemmLds<T, false, STG>::bytes);

@@ -42,6 +42,18 @@ int kgrad_launch(int dtype, int kind, const KgradArgs& a, int L, hipStream_t s);
 
 constexpr int NB = 128;
 
+// Schedule of the two big products (gemm.h): strips of `cols` column tiles per (latent, XCD) unit, each workgroup
+// computing `tpw` tiles of its row tile back to back (fp32 statistics epilogues only).  Config 3, stage 1 / stage 2:
+// 16 x 1 134.5 / 137.0 TF, 32 x 2 135.0 / 138.9, 16 x 2 133.7 / 137.7, 48 x 3 133.9 / 138.8, 64 x 4 96 / 101.
+struct ProductSchedule { int cols, tpw; };
+template <typename T>
+static ProductSchedule product_schedule(bool stats_epilogue) {
+  static const int env_tpw = [] { const char* e = getenv("GPZ_TPW"); return e ? atoi(e) : 2; }();
+  static const int env_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 0; }();
+  const int tpw = (sizeof(T) == 4 && stats_epilogue && env_tpw >= 1) ? env_tpw : 1;
+  return ProductSchedule{env_cols > 0 ? env_cols : 16 * tpw, tpw};
+}
+
 __device__ __forceinline__ double block_sum(double v, double* sh) {
   // fixed-shape tree: lanes -> waves -> block (deterministic)
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
@@ -465,7 +477,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
   if (int rc = prepare_t<T>(p, pl, b, s)) return rc;
 
   // 3. chunks of columns
-  static const int super_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 16; }();
+  const ProductSchedule sched = product_schedule<T>(true);
   const int64_t esz = sizeof(T);
   const WtCache<T> wtc = wt_cache_of<T>(pl, p->wt_cache);
   for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
@@ -486,7 +498,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
     g1.C = Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
     g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
-    g1.super_cols = super_cols; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
+    g1.super_cols = sched.cols; g1.tiles_per_wg = sched.tpw; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
     prof_begin(PROF_STAGE1, s);
     if (int rc = gemm_launch(g1, EPI_STORE_STATS, s)) return rc;
     prof_end(PROF_STAGE1, s);
@@ -494,7 +506,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
     g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
     g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-    g2.super_cols = super_cols; g2.ps_sq = b.ps2; g2.ncols = ncp;
+    g2.super_cols = sched.cols; g2.tiles_per_wg = sched.tpw; g2.ps_sq = b.ps2; g2.ncols = ncp;
     prof_begin(PROF_STAGE2, s);
     if (int rc = gemm_launch(g2, EPI_STATS, s)) return rc;
     prof_end(PROF_STAGE2, s);
@@ -616,7 +628,8 @@ static int precomputed_t(const void* W, const void* sigma, const void* mu, const
     g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
     g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
     g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = (int)(ncp / NB); g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-    g2.super_cols = 16; g2.ps_sq = b.ps2; g2.ncols = ncp;
+    const ProductSchedule sched = product_schedule<T>(true);
+    g2.super_cols = sched.cols; g2.tiles_per_wg = sched.tpw; g2.ps_sq = b.ps2; g2.ncols = ncp;
     if (int rc = gemm_launch(g2, EPI_STATS, s)) return rc;
     FinalizeArgs<T> f;
     f.ps1 = b.ps1; f.pm1 = b.pm1; f.ps2 = b.ps2; f.sigma = static_cast<const T*>(sigma); f.y = nullptr;
@@ -948,7 +961,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     hipLaunchKernelGGL((transpose_cast_kernel<T>), g32, dim3(256), 0, s, b.Linv, Mp, w.LinvT, (double*)w.D1);
     GPZ_LAUNCH_OK();
   }
-  static const int super_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 16; }();
+  const ProductSchedule sched = product_schedule<T>(true), sched_plain = product_schedule<T>(false);
   const int64_t esz = sizeof(T);
   const bool have_wt = p->wt_cache != nullptr && p->wt_cache_valid != 0;
   const WtCache<T> wtc = wt_cache_of<T>(pl, p->wt_cache);
@@ -972,7 +985,8 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
       g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
       g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
-      g1.super_cols = super_cols; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
+      const ProductSchedule s1 = full ? sched : sched_plain;    // the plain-store epilogue has no multi-tile variant
+      g1.super_cols = s1.cols; g1.tiles_per_wg = s1.tpw; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
       if (int rc = gemm_launch(g1, full ? EPI_STORE_STATS : EPI_STORE, s)) return rc;
     }
     hipLaunchKernelGGL((colscale_kernel<T>), dim3((unsigned)((ncp + 255) / 256), L32), dim3(256), 0, s,
@@ -985,7 +999,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
     g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
     g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-    g2.super_cols = super_cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
+    g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
     if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
     GemmParams<T> g3;  // G += W Pbar^T  (lower tiles)
     g3.A = Wc; g3.lda = ncp; g3.sA0 = Mp * ncp;
@@ -1004,7 +1018,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       g4.B = w.Pc; g4.ldb = ncp; g4.sB0 = Mp * ncp;
       g4.C = b.Kc; g4.ldc = ncp; g4.sC0 = Mp * ncp;
       g4.nb0 = L32; g4.mt = (int)pl.nblk; g4.nt = nt; g4.K = (int)Mp; g4.flags = GF_A_LOWER | GF_GROUP_COLS;
-      g4.super_cols = super_cols; g4.colscale = w.csc; g4.colvec = w.gmc; g4.sCs = ncp; g4.rowvec = b.muE; g4.sRv = Mp;
+      g4.super_cols = sched_plain.cols; g4.colscale = w.csc; g4.colvec = w.gmc; g4.sCs = ncp; g4.rowvec = b.muE; g4.sRv = Mp;
       g4.aux = Wc; g4.ncols = ncp;
       if (int rc = gemm_launch(g4, EPI_WBAR, s)) return rc;
       // Kbar_x = Linv^T Wbar                                   (into the Pbar buffer)
@@ -1013,7 +1027,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       g5.B = b.Kc; g5.ldb = ncp; g5.sB0 = Mp * ncp;
       g5.C = w.Pc; g5.ldc = ncp; g5.sC0 = Mp * ncp;
       g5.nb0 = L32; g5.mt = (int)pl.nblk; g5.nt = nt; g5.K = (int)Mp; g5.flags = GF_A_UPPER | GF_GROUP_COLS;
-      g5.super_cols = super_cols;
+      g5.super_cols = sched_plain.cols;
       if (int rc = gemm_launch(g5, EPI_STORE, s)) return rc;
       // GL += Kbar_x W^T  (lower tiles):  dLoss/dL = -tril(GL)
       GemmParams<T> g6 = g3;
