@@ -35,6 +35,7 @@ struct GemmParams {
   int flags = 0;
   int super_cols = 8;       // GF_GROUP_COLS: column tiles per L2 super-tile
   int tiles_per_wg = 1;     // GF_GROUP_COLS: column tiles of one row tile a workgroup computes back to back
+  int xcd_contiguous = 1;   // without GF_GROUP_COLS: each XCD takes a contiguous range of the tile order (set by gemm_launch)
   T alpha = 1, beta = 0;
   // column statistics (EPI_STORE_STATS / EPI_STATS): partial sums per (outer batch, row tile, column)
   const T* mu = nullptr; int64_t sMu = 0;  // (outer batch, K) vector, padded with zeros

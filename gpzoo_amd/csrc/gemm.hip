@@ -143,9 +143,17 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
       }
       ti = (p.flags & GF_A_LOWER) ? p.mt - 1 - ii : ii;   // longest k-range first
     } else {
+      // Blocks b, b + 8, ... run on one XCD (round-robin dispatch): give XCD x a CONTIGUOUS range of the logical tile
+      // order (batch-major, then row-major tiles), so the tiles that share an operand panel meet in one L2 instead of
+      // pulling it into all eight.
+      int lid = bid;
+      if (p.xcd_contiguous) {
+        const int nb = (int)gridDim.x, q = nb >> 3, rem = nb & 7, x = bid & 7;
+        lid = x * q + min(x, rem) + (bid >> 3);
+      }
       const int per = (p.flags & GF_TILES_LOWER) ? p.mt * (p.mt + 1) / 2 : p.mt * p.nt;
-      const int b = bid / per;
-      int t = bid - b * per;
+      const int b = lid / per;
+      int t = lid - b * per;
       b0 = b / p.nb1; b1 = b - b0 * p.nb1;
       if (p.flags & GF_TILES_LOWER) {
         int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -593,6 +601,9 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
   // 131-133 either way.  The staging data movement itself, not the instructions that carry it, is what costs the MFMA
   // pipes their ~10 % (timing-only builds without any staging: 144 / 149), so the simpler, longer-proven variant ships.
   const bool multi = (p.flags & GF_GROUP_COLS) && p.tiles_per_wg > 1;
+  static const int xcd_mode = [] { const char* e = getenv("GPZ_XCD_CONTIGUOUS"); return e ? atoi(e) : 1; }();
+  GemmParams<T> pp = p;
+  pp.xcd_contiguous = xcd_mode;
   auto run = [&](auto stg_c, auto ni_c) -> int {
     constexpr int STG = decltype(stg_c)::value, NI = decltype(ni_c)::value;
     dim3 grid((unsigned)nblocks), block(1024 / NI);
@@ -615,7 +626,7 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
           if (n_seen < 256) seen[n_seen++] = Seen{fn, dev};
         }
       }
-      hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
+      hipLaunchKernelGGL(kernel, grid, block, lds, s, pp);
       GPZ_LAUNCH_OK();
       return 0;
     };
