@@ -120,6 +120,63 @@ def cpu_baseline(cfg_id: int, c: dict, sample: int) -> dict:
             "sample_elbo": float(e)}
 
 
+class ClockSampler:
+    """Engine clock of the GPU while the timed region runs, from the amdgpu sysfs file rocm-smi itself reads
+    (pp_dpm_sclk: the level marked '*').  Host-side file reads on a side thread, 4 per second: no GPU call, no extra
+    process.  The pool's boxes settle at different clocks under this load (power cap), which moves every MFMA-bound
+    number by the same factor; the sampled clock lets a reader separate the box from the kernel."""
+
+    NOMINAL_MHZ = 2400.0      # the clock the MFMA peaks of MI355X_MICROARCH.md are quoted at
+
+    def __init__(self, device_index: int):
+        import glob
+        import threading
+        self.path, self.samples, self._stop = None, [], threading.Event()
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        for c in cards:
+            if want and want in os.path.realpath(os.path.dirname(c)):
+                self.path = c
+        if self.path is None and len(cards) == 1:
+            self.path = cards[0]
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.path else None
+
+    def _read(self):
+        try:
+            for line in open(self.path):
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            self._stop.wait(0.25)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread:
+            self._thread.join(timeout=2)
+        if not self.samples:
+            return None
+        return {"sclk_MHz_mean": sum(self.samples) / len(self.samples), "sclk_MHz_min": min(self.samples),
+                "sclk_MHz_max": max(self.samples), "samples": len(self.samples), "nominal_MHz": self.NOMINAL_MHZ,
+                "source": self.path}
+
+
 def trailing_flops(nblk: int) -> float:
     """Flops of the timed K=256 trailing SYRK launches of one matrix (csrc/factor.hip): after the two
     block columns (k, k+1) the lower tiles of the remaining (nblk-k-2)^2 blocks get a 128x128x256 update."""
@@ -222,11 +279,15 @@ def main():
         step()
     fence()
     ops.profile_enable(True)
+    clock = ClockSampler(local) if rank == 0 else None
+    if clock:
+        clock.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         elbo = step()
     fence()
     dt_s = time.perf_counter() - t0
+    clocks = clock.stop() if clock else None
     prof = ops.profile_read()
     ops.profile_enable(False)
     tmax = torch.tensor([dt_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -267,6 +328,9 @@ def main():
                 "achieved": ach1, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach1 / PEAK[dname],
                 "traffic": traffic, "traffic_source": traffic_src, "launches": n1,
                 "avg_launch_ms": ms1 / max(n1, 1)}
+        if clocks:     # the same fraction against the peak at the clock this box actually ran the timed region at
+            roof["peak_at_sampled_clock"] = PEAK[dname] * clocks["sclk_MHz_mean"] / ClockSampler.NOMINAL_MHZ
+            roof["frac_at_sampled_clock"] = ach1 / roof["peak_at_sampled_clock"]
         mpk = mp.get("mfma_%s_TFLOPs" % dname)
         if mpk:
             roof["measured_peak"], roof["frac_of_measured_peak"] = mpk, ach1 / mpk
@@ -310,7 +374,7 @@ def main():
                                    % (cfg_id - 1, {2: "2-D synthetic spatial", 5: "MGGP multi-group synthetic (4 groups)"}.get(
                                        cfg_id, "Slide-seq-shaped synthetic"), N, M, Lper, world, c["kind"], dname),
                        "whitened": bool(c["whitened"]), "chunk": a.chunk, "factor_dtype": "f64"},
-            "elbo": elbo, "roofline": roof, "kernels": sub,
+            "elbo": elbo, "roofline": roof, "kernels": sub, "clocks": clocks,
         }
         if train_ms is not None:
             res["forward_backward_ms"] = train_ms

@@ -160,8 +160,14 @@ __global__ __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(8 / N
         while ((i + 1) * (i + 2) / 2 <= t) ++i;
         while (i * (i + 1) / 2 > t) --i;
         ti = i; tj = t - i * (i + 1) / 2;
+      } else if (p.flags & (GF_B_LOWER | GF_B_UPPER)) {
+        // the k-range shrinks with the column tile: column-major, longest range first (greedy placement then ends on
+        // the short tiles instead of starting on them)
+        tj = t / p.mt; ti = t - tj * p.mt;
+        if (p.flags & GF_B_UPPER) tj = p.nt - 1 - tj;
       } else {
         ti = t / p.nt; tj = t - ti * p.nt;
+        if (p.flags & GF_A_LOWER) ti = p.mt - 1 - ti;     // longest k-range first
       }
     }
   }

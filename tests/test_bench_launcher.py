@@ -56,3 +56,24 @@ def test_committed_profiles_are_consistent_with_the_sources():
     val, _ = bench.pmc_traffic(t["workload"]["config"], t["workload"]["N"], t["workload"]["M"], t["workload"]["L"],
                                t["workload"]["chunk"])
     assert (val is not None) == (t.get("gemm_src_sha16") == bench.gemm_source_hash())
+
+
+def test_clock_sampler_reads_the_active_sclk_level(tmp_path):
+    """bench.py's `clocks` object: the level rocm-smi marks with '*' in pp_dpm_sclk; no file -> no object."""
+    import time
+    import bench
+    f = tmp_path / "pp_dpm_sclk"
+    f.write_text("0: 132Mhz \n1: 2383Mhz *\n")
+    s = bench.ClockSampler.__new__(bench.ClockSampler)
+    import threading
+    s.path, s.samples, s._stop = str(f), [], threading.Event()
+    s._thread = threading.Thread(target=s._run, daemon=True)
+    assert s._read() == 2383.0
+    s.start()
+    time.sleep(0.6)
+    out = s.stop()
+    assert out["samples"] >= 2 and out["sclk_MHz_mean"] == 2383.0 and out["nominal_MHz"] == 2400.0
+    none = bench.ClockSampler.__new__(bench.ClockSampler)
+    none.path, none.samples, none._stop, none._thread = None, [], threading.Event(), None
+    none.start()
+    assert none.stop() is None
