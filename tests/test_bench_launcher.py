@@ -70,7 +70,7 @@ def test_clock_sampler_reads_the_active_sclk_level(tmp_path):
     s._thread = threading.Thread(target=s._run, daemon=True)
     assert s._read() == 2383.0
     s.start()
-    time.sleep(0.6)
+    time.sleep(1.0)
     out = s.stop()
     assert out["samples"] >= 2 and out["sclk_MHz_mean"] == 2383.0 and out["nominal_MHz"] == 2400.0
     none = bench.ClockSampler.__new__(bench.ClockSampler)
