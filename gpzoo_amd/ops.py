@@ -154,6 +154,8 @@ def kfill(spec: KernelSpec, A: torch.Tensor, B: torch.Tensor, gA=None, gB=None, 
     odt = A.dtype if out_dtype is None else out_dtype
     nA, nB = A.shape[0], B.shape[0]
     K = torch.empty((spec.L, nA, nB), dtype=odt, device=A.device)
+    if nA == 0 or nB == 0:      # an empty point set gives an empty matrix, as torch.cdist does for the reference
+        return K if spec.batched else K[0]
     rc = lib.gpz_kfill(C.byref(d), _ptr(A), nA, _ptr(B), nB, A.shape[1], _ptr(gA), _ptr(gB), _ptr(K), nB,
                        nA * nB, float(jitter), _dt(K), _stream(A.device))
     _lib.check(rc, "gpz_kfill")
@@ -178,6 +180,8 @@ def kgrad(spec: KernelSpec, A: torch.Tensor, B: torch.Tensor, Kbar: torch.Tensor
         gA = gB = None
     gth = torch.empty((L, 4), dtype=torch.float64, device=A.device)
     gpt = torch.empty((nA, 4), dtype=torch.float64, device=A.device) if want_points else None
+    if nA == 0 or nB == 0:      # nothing to contract
+        return gth.zero_()[:, :3], (gpt.zero_()[:, :A.shape[1]] if want_points else None)
     nbytes = lib.gpz_kgrad_workspace_bytes(nA, L)
     ws = _workspace(A.device, nbytes)
     rc = lib.gpz_kgrad(C.byref(d), _ptr(A), nA, _ptr(B), nB, A.shape[1], _ptr(gA), _ptr(gB), _ptr(Kbar), nB, nA * nB,
@@ -349,6 +353,18 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     ``retain_wt`` > 0: keep Wt of every chunk for ``svgp_backward(wt_cache=out["wt_cache"])`` when it fits
     in that fraction of the free device memory (288 GB HBM: 52 GB at N=200k, M=2048, L=32, fp32)."""
     _need_cuda(X, Z, mu, Lu_raw)
+    if X.dim() == 2 and X.shape[0] == 0 and Z.dim() == 2 and Z.shape[0] > 0:
+        # No data points: q(F) is empty and the ELBO is -sum(KL), as the reference's torch code gives for an (0,d) X.
+        # The library wants N >= 1: evaluate at one stand-in point (the first inducing point) and drop its column.
+        o = svgp_forward(spec, Z[:1].to(X.dtype), Z, mu, Lu_raw, jitter, whitened, gX=None if gZ is None else gZ[:1], gZ=gZ,
+                         clamp_min=clamp_min, want_moments=want_moments, want_Lu=want_Lu, want_chol=want_chol,
+                         check_info=check_info, cache=cache)
+        for k in ("mean", "scale"):
+            if k in o:
+                o[k] = o[k][:, :0]
+        o["loglik"] = torch.zeros_like(o["kl"])
+        o["elbo"] = -o["kl"].sum()
+        return o
     lib = _lib.load()
     keep: list = []
     p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
@@ -406,6 +422,12 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     ``g_kl`` (L,): upstream gradient of the forward's per-latent ``kl``; its own
     gradient is folded into the results."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
+    if X.dim() == 2 and X.shape[0] == 0 and Z.dim() == 2 and Z.shape[0] > 0:
+        # empty X (see svgp_forward): one stand-in point with zero upstream gradients leaves the KL / factor terms
+        zero = torch.zeros((spec.L, 1), dtype=X.dtype, device=X.device)
+        return svgp_backward(spec, Z[:1].to(X.dtype), Z, mu, Lu_raw, jitter, whitened, zero, zero, torch.ones_like(zero),
+                             gX=None if gZ is None else gZ[:1], gZ=gZ, clamp_min=clamp_min, cache=cache,
+                             kernel_grads=kernel_grads, g_chol=g_chol, g_kl=g_kl)
     lib = _lib.load()
     keep: list = []
     p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)

@@ -352,3 +352,45 @@ def test_scalar_kernel_shared_by_batched_posteriors(cls_name):
                      (gp.kernel.lengthscale.grad, "grad_lengthscale")):
         ref = t(key)
         torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()), msg=lambda m: f"{key}: {m}")
+
+
+@pytest.mark.parametrize("name", ["wsvgp_nsf_rbf_f64", "svgp_nsf_rbf_f64", "mggp_svgp_mggp_nsf_rbf_f64"])
+def test_empty_inputs(name):
+    """An X with no rows: the reference's torch code returns empty q(F) moments and the q(U) / p(U) pair as usual;
+    kernel matrices with an empty side are empty.  Here: shapes, q(U) and the KL equal to those of a non-empty call
+    (they do not depend on X), and the gradients of the KL alone equal to a non-empty call's with no q(F) term."""
+    from torch import distributions
+    from gpzoo.utilities import whitened_KL_batched
+    c = load_case(name)
+    X = c["X"].cuda()
+    kw_full = {"groupsX": c["gX"].cuda()} if "gX" in c else {}
+    kw_empty = {"groupsX": c["gX"][:0].cuda()} if "gX" in c else {}
+
+    def kl_of(model, Xin, kw):
+        pY, qF, qU, pU = model(X=Xin, E=1, **kw)
+        kl = whitened_KL_batched(qU.mean, qU.scale_tril).sum() if c["whitened"] else distributions.kl_divergence(qU, pU).sum()
+        return qF, qU, kl
+
+    ref_model = build(name, c)
+    _, qU_ref, kl_ref = kl_of(ref_model, X, kw_full)
+    kl_ref.backward()
+    model = build(name, c)
+    qF, qU, kl = kl_of(model, X[:0], kw_empty)
+    L = c["mu"].shape[0]
+    assert qF.mean.shape == (L, 0) and qF.scale.shape == (L, 0)
+    torch.testing.assert_close(qU.scale_tril, qU_ref.scale_tril, rtol=0, atol=0)
+    torch.testing.assert_close(kl, kl_ref, rtol=1e-12, atol=0)
+    (kl + qF.mean.sum() + qF.scale.sum()).backward()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref_model.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None or not p.grad.abs().sum() > 0, n
+        else:
+            torch.testing.assert_close(p.grad, q.grad, rtol=1e-9, atol=1e-12, msg=lambda m: f"{n}: {m}")
+    k = model.gp.kernel
+    Z = model.gp.Z
+    gk = ({"groupsX": c["gX"][:0].cuda(), "groupsZ": c["gZ"].cuda()} if "gX" in c else {})
+    Kxz = k(X[:0], Z, *gk.values()) if gk else k(X[:0], Z)
+    assert Kxz.shape[-2:] == (0, Z.shape[0]) and Kxz.numel() == 0
+    Kzx = k(Z, X[:0], *reversed(list(gk.values()))) if gk else k(Z, X[:0])
+    assert Kzx.shape[-2:] == (Z.shape[0], 0)
+    Kxz.sum().backward()          # empty sum: gradients exist and are zero
