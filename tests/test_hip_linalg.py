@@ -13,7 +13,7 @@ def spd(batch, M, seed, jitter=0.5):
     return A @ A.transpose(-1, -2) / M + jitter * torch.eye(M, dtype=torch.float64)
 
 
-@pytest.mark.parametrize("M,batch", [(1, 2), (36, 3), (128, 2), (200, 2), (384, 3), (700, 2), (1024, 1)])
+@pytest.mark.parametrize("M,batch", [(1, 2), (36, 3), (128, 2), (200, 2), (384, 3), (700, 2), (1024, 1), (3000, 2), (4096, 1)])
 def test_cholesky_matches_lapack(M, batch):
     from gpzoo_amd import ops
     A = spd(batch, M, 7 + M)

@@ -116,6 +116,16 @@ def test_config5_scaled():
     check(make_config(5, N=6000, M=300, L=3), 1e-5)       # MGGP_NSF_RBF fp64, ragged M, 4 groups
 
 
+@pytest.mark.parametrize("whitened", [True, False])
+def test_notebook_inducing_count(whitened):
+    """M = 3000, the inducing-point count of the Slide-seq notebooks (24 Cholesky panels with a ragged last one, five
+    levels of the triangular inverse with unpaired tail segments), fp64, element-wise against the oracle."""
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(2, N=3500, M=3000, L=2, dtype=torch.float64)
+    c["whitened"] = whitened
+    check(c, 1e-5)
+
+
 def test_unwhitened_multi_panel_fp64():
     from gpzoo_amd.synthetic import make_config
     c = make_config(2, N=3000, M=300, L=3, dtype=torch.float64)
