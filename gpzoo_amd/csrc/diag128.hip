@@ -115,8 +115,12 @@ __device__ __forceinline__ void factor32(double* S, double* CBu, double* RI, int
     diag = fma(-lj, lj, diag);
     if (j + 1 < 32) a[j + 1] = fma(-lj, bcast(lj, j + 1), a[j + 1]);   // what column j+1 needs, now
     CBu[j * 32 + i] = lj;                             // twin lanes store the same value to the same address
-    RI[j] = r;                                        // wave-uniform
     if (i >= j) S[(o + i) * DP + o + j] = lj;
+    // RI[j] doubles as the "column j is in LDS" flag for the wave that inverts this sub-block behind us (it was zeroed
+    // before the sweep; 1 / l_jj > 0).  Stored LAST, as a release at WAVEFRONT scope: that only keeps the compiler from
+    // moving the stores above behind it -- the hardware executes a wave's LDS operations in order -- whereas a
+    // workgroup-scope release would make this wave drain its LDS queue in every column of the pivot chain.
+    __hip_atomic_store(&RI[j], r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WAVEFRONT);   // wave-uniform
     lprev = lj;
     // pin the updates to this column: LLVM otherwise sinks each one to the column that consumes it and keeps
     // all 496 broadcast values alive until then (spills)
@@ -168,6 +172,34 @@ __device__ __forceinline__ void invert32(double* S, const double* CBu, const dou
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+// invert32 run by a SECOND wave while the first one is still factoring the sub-block: step ii needs column ii of L
+// and 1 / l_ii only, which factor32 publishes column by column (RI[ii] turns non-zero last).  The substitution (~220-390 cycles per step) is faster than the factorisation (~415 per column), so this
+// wave trails by one step and the inverse is complete a few hundred cycles after the factor instead of 7 000.
+__device__ __forceinline__ void invert32_follow(double* S, const double* CBu, double* RIu, int o, int lane) {
+  const int z = vzero();
+  const int c = (lane & 31) + z;
+  const double* CB = CBu + z;
+  double* RI = RIu + z;
+  double acc[32];
+#pragma unroll
+  for (int m = 0; m < 32; ++m) acc[m] = (m == c) ? 1.0 : 0.0;
+#pragma unroll
+  for (int ii = 0; ii < 32; ++ii) {
+    double ri;
+    while ((ri = __hip_atomic_load(&RI[ii], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0.0) __builtin_amdgcn_s_sleep(2);
+    double cb[32];
+#pragma unroll
+    for (int m = ii + 1; m < 32; ++m) cb[m] = CB[ii * 32 + m];
+    const double x = acc[ii] * ri;
+    if (lane < 32 && ii >= c) XT(S, o + c, o + ii) = x;
+#pragma unroll
+    for (int m = ii + 1; m < 32; ++m) acc[m] = fma(-cb[m], x, acc[m]);
+#pragma unroll
+    for (int m = ii + 1; m < 32; ++m) asm volatile("" : "+v"(acc[m]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 }  // namespace
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void diag128_kernel(double* __restrict__ A, int64_t lda, int64_t stride, int bk,
@@ -200,19 +232,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
   if (tid < 128) S[tid * DP + 128] = 0.0;
+  if (tid < 32) RI[tid] = 0.0;
   __syncthreads();
   GPZ_STAMP(1);
 
   for (int s = 0; s < 4; ++s) {
     const int o = 32 * s;
-    if (w == 0) {
-      if (factor) factor32(S, CB, RI, o, lane, info + b, (int64_t)bk * 128 + o, m_real);
-      else stage32(S, CB, RI, o, lane);
-      GPZ_STAMP(2 + 4 * s);
+    if (factor) {
+      // wave 0 factors, wave 1 inverts one column behind it.  (Letting the idle waves 2 and 3 write the finished block
+      // column of L back meanwhile was measured: the final write-back shrinks by 3.5 k cycles and factor32 grows by as
+      // much from the LDS contention.)
+      if (w == 0) {
+        factor32(S, CB, RI, o, lane, info + b, (int64_t)bk * 128 + o, m_real);
+        GPZ_STAMP(2 + 4 * s);
+      } else if (w == 1) {
+#ifndef GPZ_DIAG_NOFOLLOW
+        invert32_follow(S, CB, RI, o, lane);
+#endif
+      }
+    } else if (w == 0) {
+      stage32(S, CB, RI, o, lane);
       invert32(S, CB, RI, o, lane);
-      GPZ_STAMP(3 + 4 * s);
     }
     __syncthreads();
+    if (factor && w == 2 && lane < 32) RI[lane] = 0.0;   // flags of the next sub-block (two barriers away)
+    GPZ_STAMP(3 + 4 * s);
     if (!factor || s == 3) continue;
     const int R0 = o + 32;
     // ---- sub-panel: rows R0..127, columns o..o+31, in place: L = A * inv(Lss)^T ----

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 if [ "$1" = "build" ]; then
   python3 -m gpzoo_amd.build > /dev/null
   C=gpzoo_amd/csrc
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -DGPZ_DIAG_STAMPS -c $C/diag128.hip -o /tmp/diag128_st.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -DGPZ_DIAG_STAMPS $GPZ_DIAG_EXTRA -c $C/diag128.hip -o /tmp/diag128_st.o
   objs=$(ls $C/*.o | grep -v "/diag128.o")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpzoo_amd/libgpzoo_hip_stamps.so $objs /tmp/diag128_st.o -ldl
   exit 0
