@@ -26,6 +26,15 @@ struct KgradArgs {
   double* acc;  // (L, Mp, 8): dz0..dz3, dsigma, dlengthscale, da_eff, unused
 };
 
+__device__ __forceinline__ float kg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ double kg_exp(double x) { return exp(x); }
+__device__ __forceinline__ float kg_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double kg_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float kg_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+__device__ __forceinline__ double kg_pow(double x, double y) { return pow(x, y); }
+
+// Per-element arithmetic in the problem's precision T (the reference's autograd differentiates in that precision too;
+// row totals in fp64.
 template <typename T, int KIND>
 __global__ __launch_bounds__(256) void kgrad_kernel(KgradArgs a) {
   const int l = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -35,41 +44,64 @@ __global__ __launch_bounds__(256) void kgrad_kernel(KgradArgs a) {
   const T* Zp = static_cast<const T*>(a.Z);
   const T* Xp = static_cast<const T*>(a.X);
   const int d = a.d;
-  const double sig = (double)static_cast<const T*>(a.sigma)[l];
-  const double ell = (double)static_cast<const T*>(a.ell)[l];
-  const double s2 = sig * sig, il2 = 1.0 / (ell * ell);
-  double z[4] = {0, 0, 0, 0};
-  for (int k = 0; k < d; ++k) z[k] = (double)Zp[m * d + k];
+  const T sig = static_cast<const T*>(a.sigma)[l];
+  const T ell = static_cast<const T*>(a.ell)[l];
+  const T s2 = sig * sig, il2 = (T)1 / (ell * ell);
+  T z[4] = {0, 0, 0, 0};
+  for (int k = 0; k < d; ++k) z[k] = Zp[m * d + k];
   // ids were range-checked by the forward fill (IndexError there); clamped here so a stray one cannot read out of bounds
   const int gz = (KIND == 2) ? ((uint64_t)a.gZ[m] < (uint64_t)a.G ? (int)a.gZ[m] : 0) : 0;
-  const double aeff = (KIND == 2) ? (double)static_cast<const T*>(a.ga)[l] : 0.0;
+  const T aeff = (KIND == 2) ? static_cast<const T*>(a.ga)[l] : (T)0;
+  const T gpow = (T)a.gpow;
   double dz[4] = {0, 0, 0, 0}, dsig = 0, dell = 0, da = 0;
-  for (int64_t c = lane; c < a.ncols; c += 64) {
-    const double g = (double)kb[c];
-    double diff[4] = {0, 0, 0, 0}, d2 = 0;
-    for (int k = 0; k < d; ++k) { diff[k] = z[k] - (double)Xp[c * d + k]; d2 += diff[k] * diff[k]; }
-    double cz;  // dk/dz_m = cz * diff
-    if (KIND == 0) {
-      const double kv = s2 * exp(-0.5 * d2 * il2);
-      dsig += g * 2.0 * kv / sig;
-      dell += g * kv * d2 * il2 / ell;
-      cz = -kv * il2;
-    } else if (KIND == 1) {
-      const double v = 1.7320508075688772935 * sqrt(d2) / ell, e = exp(-v);
-      dsig += g * 2.0 * sig * (1.0 + v) * e;
-      dell += g * s2 * v * v * e / ell;
-      cz = -s2 * 3.0 * il2 * e;
-    } else {
-      const int gx = (uint64_t)a.gX[c] < (uint64_t)a.G ? (int)a.gX[c] : 0;
-      const double r2 = (double)static_cast<const T*>(a.gr2)[gz * a.G + gx];
-      const double den = aeff * r2 + 1.0;
-      const double kv = s2 * exp(-0.5 * d2 * il2 / den) * pow(den, -a.gpow);
-      dsig += g * 2.0 * kv / sig;
-      dell += g * kv * d2 * il2 / (ell * den);
-      da += g * kv * (0.5 * d2 * il2 / (den * den) - a.gpow / den) * r2;
-      cz = -kv * il2 / den;
+  // four columns per lane and trip: their loads are independent (the loop is bound by the latency of its small loads
+  // otherwise), and their contributions are summed in T before they join the fp64 totals
+  constexpr int UN = 4;
+  for (int64_t c0 = lane; c0 < a.ncols; c0 += 64 * UN) {
+    T g[UN], x[UN][4];
+    int gx[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t c = c0 + 64 * u;
+      const bool in = c < a.ncols;
+      g[u] = in ? kb[c] : (T)0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[u][k] = (in && k < d) ? Xp[c * d + k] : (T)0;
+      gx[u] = (KIND == 2 && in) ? ((uint64_t)a.gX[c] < (uint64_t)a.G ? (int)a.gX[c] : 0) : 0;
     }
-    for (int k = 0; k < d; ++k) dz[k] += g * cz * diff[k];
+    T pz[4] = {0, 0, 0, 0}, psig = 0, pell = 0, pa = 0;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      T diff[4], d2 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { diff[k] = (k < d) ? z[k] - x[u][k] : (T)0; d2 = fma(diff[k], diff[k], d2); }
+      T cz;  // dk/dz_m = cz * diff
+      if (KIND == 0) {
+        const T kv = s2 * kg_exp((T)-0.5 * d2 * il2);
+        psig += g[u] * (T)2 * kv / sig;
+        pell += g[u] * kv * d2 * il2 / ell;
+        cz = -kv * il2;
+      } else if (KIND == 1) {
+        const T v = (T)1.7320508075688772935 * kg_sqrt(d2) / ell, e = kg_exp(-v);
+        psig += g[u] * (T)2 * sig * ((T)1 + v) * e;
+        pell += g[u] * s2 * v * v * e / ell;
+        cz = -s2 * (T)3 * il2 * e;
+      } else {
+        const T r2 = static_cast<const T*>(a.gr2)[gz * a.G + gx[u]];
+        const T den = aeff * r2 + (T)1;
+        const T kv = s2 * kg_exp((T)-0.5 * d2 * il2 / den) * kg_pow(den, -gpow);
+        psig += g[u] * (T)2 * kv / sig;
+        pell += g[u] * kv * d2 * il2 / (ell * den);
+        pa += g[u] * kv * ((T)0.5 * d2 * il2 / (den * den) - gpow / den) * r2;
+        cz = -kv * il2 / den;
+      }
+      const T gc = g[u] * cz;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pz[k] = fma(gc, diff[k], pz[k]);
+    }
+    dsig += (double)psig; dell += (double)pell; da += (double)pa;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dz[k] += (double)pz[k];
   }
   double v[7] = {dz[0], dz[1], dz[2], dz[3], dsig * a.scalar_scale, dell * a.scalar_scale, da * a.scalar_scale};
 #pragma unroll
