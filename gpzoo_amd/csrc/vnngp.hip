@@ -404,37 +404,49 @@ static int vnn_prepare(const gpz_svgp_problem* p, VnnPlan& pl, const int64_t* id
 }
 
 // muE = Linv mu (fp64) and, per latent, the un-whitened KL(qU || pU) of utilities.py:481 /
-// torch kl.py:442:  sum log diag L - sum log diag Lu + (|Linv Lu|_F^2 + |Linv mu|^2 - M) / 2.  One block per latent.
+// torch kl.py:442:  sum log diag L - sum log diag Lu + (|Linv Lu|_F^2 + |Linv mu|^2 - M) / 2.
+// One wave per row i (coalesced along the row): muE_i, and the row's share of the KL into part[l][i]; a second kernel
+// adds the shares of a latent in a fixed order (no atomics: bitwise reproducible).  The one-block-per-latent version
+// this replaces walked Linv with a thread per row: 1.45 ms at M=1000, L=10 against 0.03 ms.
 template <typename T>
-__global__ __launch_bounds__(256) void vnn_kl_kernel(const double* __restrict__ Lc, const double* __restrict__ Linv,
-                                                    const double* __restrict__ LuE, const T* __restrict__ raw,
-                                                    const T* __restrict__ mu, int64_t M, int64_t Mp,
-                                                    double* __restrict__ muE, double* __restrict__ kl) {
+__global__ __launch_bounds__(256) void vnn_kl_rows_kernel(const double* __restrict__ Lc, const double* __restrict__ Linv,
+                                                         const double* __restrict__ LuE, const T* __restrict__ raw,
+                                                         const T* __restrict__ mu, int64_t M, int64_t Mp,
+                                                         double* __restrict__ muE, double* __restrict__ part) {
+  const int l = blockIdx.y, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= Mp) return;
+  const double* Li = Linv + (int64_t)l * Mp * Mp + i * Mp;
+  const double* Le = LuE + (int64_t)l * Mp * Mp + i * Mp;
+  double me = 0.0, fro = 0.0;
+  if (i < M)
+    for (int64_t k = lane; k <= i; k += 64) {
+      me = fma(Li[k], (double)mu[(int64_t)l * M + k], me);
+      const double v = Le[k];
+      fro = fma(v, v, fro);
+    }
+  for (int o = 32; o > 0; o >>= 1) { me += __shfl_down(me, o); fro += __shfl_down(fro, o); }
+  if (lane == 0) {
+    muE[(int64_t)l * Mp + i] = me;
+    part[(int64_t)l * Mp + i] = (i < M) ? 0.5 * me * me + 0.5 * fro + log(Lc[(int64_t)l * Mp * Mp + i * Mp + i]) -
+                                              (double)raw[(int64_t)l * M * M + i * M + i]
+                                        : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void vnn_kl_sum_kernel(const double* __restrict__ part, int64_t M, int64_t Mp,
+                                                        double* __restrict__ kl) {
   __shared__ double sh[256];
   const int l = blockIdx.x, tid = threadIdx.x;
-  const double* Lb = Lc + (int64_t)l * Mp * Mp;
-  const double* Li = Linv + (int64_t)l * Mp * Mp;
-  const double* Le = LuE + (int64_t)l * Mp * Mp;
   double acc = 0.0;
-  for (int64_t i = tid; i < Mp; i += 256) {
-    double me = 0.0;
-    if (i < M) {
-      for (int64_t k = 0; k <= i; ++k) me += Li[i * Mp + k] * (double)mu[(int64_t)l * M + k];
-      acc += 0.5 * me * me + log(Lb[i * Mp + i]) - (double)raw[(int64_t)l * M * M + i * M + i];
-    }
-    muE[(int64_t)l * Mp + i] = me;
-  }
-  for (int64_t e = tid; e < M * M; e += 256) {
-    const int64_t i = e / M, j = e - i * M;
-    if (j <= i) { const double v = Le[i * Mp + j]; acc += 0.5 * v * v; }
-  }
+  for (int64_t i = tid; i < Mp; i += 256) acc += part[(int64_t)l * Mp + i];
   sh[tid] = acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) sh[tid] += sh[tid + o];
     __syncthreads();
   }
-  if (tid == 0 && kl) kl[l] = sh[0] - 0.5 * (double)M;
+  if (tid == 0) kl[l] = sh[0] - 0.5 * (double)M;
 }
 
 // Linv, LuE = Linv Lu (lower), muE and the per-latent KL (kl may be null: backward only needs the operands)
@@ -447,9 +459,14 @@ static int vnn_kl_prepare(const gpz_svgp_problem* p, VnnPlan& pl, double* kl, hi
   g.A = pl.Linv; g.lda = Mp; g.sA0 = mm; g.B = pl.LuD; g.ldb = Mp; g.sB0 = mm; g.C = pl.LuE; g.ldc = Mp; g.sC0 = mm;
   g.nb0 = (int)L; g.mt = g.nt = (int)(Mp / 128); g.K = (int)Mp; g.flags = GF_A_LOWER | GF_B_LOWER | GF_TILES_LOWER;
   if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
-  hipLaunchKernelGGL((vnn_kl_kernel<T>), dim3((unsigned)L), dim3(256), 0, s, pl.Kfac, pl.Linv, pl.LuE,
-                     static_cast<const T*>(p->Lu_raw), static_cast<const T*>(p->mu), pl.M, Mp, pl.muE, kl);
+  double* part = pl.Tmp;     // the triangular inverse is done with its scratch (L * Mp * Mp / 2 doubles >= L * Mp)
+  hipLaunchKernelGGL((vnn_kl_rows_kernel<T>), dim3((unsigned)(Mp / 4), (unsigned)L), dim3(256), 0, s, pl.Kfac, pl.Linv,
+                     pl.LuE, static_cast<const T*>(p->Lu_raw), static_cast<const T*>(p->mu), pl.M, Mp, pl.muE, part);
   GPZ_LAUNCH_OK();
+  if (kl) {
+    hipLaunchKernelGGL(vnn_kl_sum_kernel, dim3((unsigned)L), dim3(256), 0, s, part, pl.M, Mp, kl);
+    GPZ_LAUNCH_OK();
+  }
   return 0;
 }
 
@@ -587,15 +604,25 @@ __global__ void vnn_kl_addG_kernel(double* __restrict__ G, const double* __restr
 }
 
 // gmu[l][a] += gk[l] * sum_{i >= a} Linv[l][i][a] * muE[l][i]        (dKL/dmu = Linv^T Linv mu)
-__global__ void vnn_kl_mu_kernel(double* __restrict__ gmu, const double* __restrict__ Linv,
-                                 const double* __restrict__ muE, int64_t Mp, int64_t M, const double* __restrict__ g_kl) {
-  const int l = blockIdx.y;
-  const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (a >= M) return;
+// 32 columns x 8 row segments per block (a thread per column alone left 40 blocks walking up to M rows each).
+__global__ __launch_bounds__(256) void vnn_kl_mu_kernel(double* __restrict__ gmu, const double* __restrict__ Linv,
+                                                       const double* __restrict__ muE, int64_t Mp, int64_t M,
+                                                       const double* __restrict__ g_kl) {
+  __shared__ double sh[8][33];
+  const int l = blockIdx.y, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t a = (int64_t)blockIdx.x * 32 + tx;
   const double* Li = Linv + (int64_t)l * Mp * Mp;
   double t = 0.0;
-  for (int64_t i = a; i < M; ++i) t += Li[i * Mp + a] * muE[(int64_t)l * Mp + i];
-  gmu[(int64_t)l * Mp + a] += g_kl[l] * t;
+  if (a < M)
+    for (int64_t i = a + ty; i < M; i += 8) t = fma(Li[i * Mp + a], muE[(int64_t)l * Mp + i], t);
+  sh[ty][tx] = t;
+  __syncthreads();
+  if (ty == 0 && a < M) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += sh[q][tx];
+    gmu[(int64_t)l * Mp + a] += g_kl[l] * v;
+  }
 }
 
 // Q[l][i][j] += muE[l][i] * muE[l][j]
@@ -666,7 +693,7 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
     if (int rc = dgemm(LinvT, pl.LuE, Tm, GF_A_UPPER | GF_B_LOWER | GF_TILES_LOWER, 1.0)) return rc;   // Linv^T LuE
     hipLaunchKernelGGL(vnn_kl_addG_kernel, gm, dim3(256), 0, s, pl.G, Tm, Mp, g_kl);
     GPZ_LAUNCH_OK();
-    hipLaunchKernelGGL(vnn_kl_mu_kernel, dim3((unsigned)((M + 255) / 256), L32), dim3(256), 0, s, pl.gmu, pl.Linv, pl.muE,
+    hipLaunchKernelGGL(vnn_kl_mu_kernel, dim3((unsigned)((M + 31) / 32), L32), dim3(256), 0, s, pl.gmu, pl.Linv, pl.muE,
                        Mp, M, g_kl);
     GPZ_LAUNCH_OK();
   }
