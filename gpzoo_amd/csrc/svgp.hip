@@ -46,12 +46,21 @@ constexpr int NB = 128;
 // computing `tpw` tiles of its row tile back to back (fp32 statistics epilogues only).  Config 3, stage 1 / stage 2:
 // 16 x 1 134.5 / 137.0 TF, 32 x 2 135.0 / 138.9, 16 x 2 133.7 / 137.7, 48 x 3 133.9 / 138.8, 64 x 4 96 / 101.
 struct ProductSchedule { int cols, tpw; };
+// nt = column tiles of the launch.  The strips of a launch get (nearly) equal widths: an XCD takes every 8th unit, so
+// with a ragged last strip and a strip count that divides 8 (N_b = 7000: 55 column tiles = 32 + 23) the odd XCDs would
+// get all the short units and idle a quarter of the launch (minibatch step 52.4 -> 48.9 ms with 28 + 27).
 template <typename T>
-static ProductSchedule product_schedule(bool stats_epilogue) {
+static ProductSchedule product_schedule(bool stats_epilogue, int nt) {
   static const int env_tpw = [] { const char* e = getenv("GPZ_TPW"); return e ? atoi(e) : 2; }();
   static const int env_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 0; }();
   const int tpw = (sizeof(T) == 4 && stats_epilogue && env_tpw >= 1) ? env_tpw : 1;
-  return ProductSchedule{env_cols > 0 ? env_cols : 16 * tpw, tpw};
+  if (env_cols > 0) return ProductSchedule{env_cols, tpw};
+  const int full = 16 * tpw;
+  const int strips = (nt + full - 1) / full;
+  int w = (nt + strips * tpw - 1) / (strips * tpw);     // workgroups per row tile and strip
+  w += w & 1;                                           // even (gemm_launch: alternating wave halves)
+  if (w > 16) w = 16;
+  return ProductSchedule{w * tpw, tpw};
 }
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -477,7 +486,6 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
   if (int rc = prepare_t<T>(p, pl, b, s)) return rc;
 
   // 3. chunks of columns
-  const ProductSchedule sched = product_schedule<T>(true);
   const int64_t esz = sizeof(T);
   const WtCache<T> wtc = wt_cache_of<T>(pl, p->wt_cache);
   for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
@@ -485,6 +493,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
     const int64_t ncp = pad_up(nreal);  // columns computed this chunk
     const int nt = (int)(ncp / NB);
+    const ProductSchedule sched = product_schedule<T>(true, nt);
     T* const Wc = p->wt_cache ? wtc.wt(ci) : b.Wc;      // retained for the backward pass when asked for
     T* const ps1 = p->wt_cache ? wtc.ps1(ci) : b.ps1;
     prof_begin(PROF_KFILL, s);
@@ -628,7 +637,7 @@ static int precomputed_t(const void* W, const void* sigma, const void* mu, const
     g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
     g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
     g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = (int)(ncp / NB); g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-    const ProductSchedule sched = product_schedule<T>(true);
+    const ProductSchedule sched = product_schedule<T>(true, g2.nt);
     g2.super_cols = sched.cols; g2.tiles_per_wg = sched.tpw; g2.ps_sq = b.ps2; g2.ncols = ncp;
     if (int rc = gemm_launch(g2, EPI_STATS, s)) return rc;
     FinalizeArgs<T> f;
@@ -961,7 +970,6 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     hipLaunchKernelGGL((transpose_cast_kernel<T>), g32, dim3(256), 0, s, b.Linv, Mp, w.LinvT, (double*)w.D1);
     GPZ_LAUNCH_OK();
   }
-  const ProductSchedule sched = product_schedule<T>(true), sched_plain = product_schedule<T>(false);
   const int64_t esz = sizeof(T);
   const bool have_wt = p->wt_cache != nullptr && p->wt_cache_valid != 0;
   const WtCache<T> wtc = wt_cache_of<T>(pl, p->wt_cache);
@@ -970,6 +978,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
     const int64_t ncp = pad_up(nreal);
     const int nt = (int)(ncp / NB);
+    const ProductSchedule sched = product_schedule<T>(true, nt), sched_plain = product_schedule<T>(false, nt);
     const void* Xc = static_cast<const char*>(p->X) + n0 * p->d * esz;
     T* Wc = b.Wc;
     T* ps1 = b.ps1;
@@ -1190,7 +1199,7 @@ static int precomputed_backward_t(const void* W, const void* sigma, const void* 
     g2.B = b.Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
     g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
     g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = (int)(ncp / NB); g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-    g2.super_cols = 16; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
+    g2.super_cols = product_schedule<T>(false, g2.nt).cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
     if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
     GemmParams<T> g3;  // G += Wt Pbar^T  (lower tiles)
     g3.A = b.Wc; g3.lda = ncp; g3.sA0 = Mp * ncp;
