@@ -585,8 +585,7 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
     GPZ_REQUIRE(sc >= 1, "gemm: super_cols must be >= 1");
     GPZ_REQUIRE(tpw >= 1 && sc % tpw == 0, "gemm: tiles_per_wg=%d must divide super_cols=%d", tpw, sc);
     if (tpw > 1) {
-      GPZ_REQUIRE((sc / tpw) % 2 == 0 && !(p.flags & (GF_B_LOWER | GF_B_UPPER)),
-                  "gemm: tiles_per_wg > 1 needs an even number of workgroups per row tile and a dense B");
+      GPZ_REQUIRE(!(p.flags & (GF_B_LOWER | GF_B_UPPER)), "gemm: tiles_per_wg > 1 needs a dense B");
       GPZ_REQUIRE(sizeof(T) == 4 && (epilogue == EPI_STORE_STATS || epilogue == EPI_STATS),
                   "gemm: tiles_per_wg > 1 is built for the fp32 statistics epilogues only");
     }

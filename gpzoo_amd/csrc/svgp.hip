@@ -58,7 +58,6 @@ static ProductSchedule product_schedule(bool stats_epilogue, int nt) {
   const int full = 16 * tpw;
   const int strips = (nt + full - 1) / full;
   int w = (nt + strips * tpw - 1) / (strips * tpw);     // workgroups per row tile and strip
-  w += w & 1;                                           // even (gemm_launch: alternating wave halves)
   if (w > 16) w = 16;
   return ProductSchedule{w * tpw, tpw};
 }
