@@ -16,7 +16,7 @@ def draw(seed):
     g = torch.Generator().manual_seed(10_000 + seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))   # noqa: E731
     kind = KINDS[seed % len(KINDS)]
-    N = [1, 5, 127, 128, 129, 300, 517, 700][ri(0, 7)]
+    N = [1, 5, 127, 128, 129, 300, 517, 700, 2100, 4200][ri(0, 9)]   # 4200: 33 column tiles = two strips of 9 x 2 and 8 x 2 - 1
     M = [1, 2, 31, 64, 128, 129, 200, 257][ri(0, 7)]
     L = 1 if kind == "rbf_scalar" else ri(1, 5)
     d = ri(1, 3)
@@ -56,7 +56,7 @@ def oracle_parts(c, leaf):
     return mean, scale, kl, O.gaussian_elbo(c["y"], mean, scale, c["noise_sd"], kl)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("GPZ_FUZZ_SEEDS", "40"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPZ_FUZZ_SEEDS", "64"))))
 def test_random_case(seed):
     from gpzoo_amd import _lib, ops
     from gpzoo_amd.ops import KernelSpec
