@@ -37,3 +37,5 @@ GPZ_DIST_BACKEND=gloo python3 bench.py --gpus 2 --N 40000 --steps 3 --warmup 1 -
 import json,sys
 r=[json.loads(l) for l in sys.stdin if l.startswith('{')][-1]
 print('  n_gpus %d ranks %d backend %s devices %d | value %.3f %s | %.2f ms/step' % (r['n_gpus'], r['ranks'], r['backend'], r['devices'], r['value'], r['unit'], r['ms_per_step']))"
+echo "== all-parameter training step at the minibatch shape (Z, sigma, lengthscale, mu, Lu trainable): tools/svgp_allparam_step.py"
+python3 tools/svgp_allparam_step.py 2>/dev/null | grep step
