@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Training-step latency at the small notebooks' sizes (mggp_test.ipynb: N=400, M=100, 1-D, 2 groups; SVGP.ipynb:
+N=10000, M=500): forward + loss.backward() + Adam, every parameter trainable."""
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpzoo.gp import SVGP, WSVGP  # noqa: E402
+from gpzoo.kernels import NSF_RBF  # noqa: E402
+from gpzoo.likelihoods import GaussianLikelihood  # noqa: E402
+from gpzoo.utilities import _elbo_terms  # noqa: E402
+
+dev = torch.device("cuda")
+for (N, M, L, d) in ((400, 100, 1, 1), (10000, 500, 1, 1), (2000, 300, 8, 2)):
+    torch.manual_seed(0)
+    X = (torch.rand(N, d) * 20 - 10).to(dev)
+    y = torch.randn(L, N).to(dev)
+    for cls in (WSVGP, SVGP):
+        gp = cls(NSF_RBF(sigma=1.0, lengthscale=2.0, L=L), dim=d, M=M, jitter=1e-2)
+        gp.Z = nn.Parameter(X[torch.randperm(N)[:M]].clone().cpu())
+        gp.mu = nn.Parameter(torch.zeros(L, M))
+        gp.Lu = nn.Parameter(0.01 * torch.randn(L, M, M))
+        model = GaussianLikelihood(gp, noise=0.5).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        times = []
+        for it in range(30):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            loss = _elbo_terms(model, X, y, 1)
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        times = sorted(times[5:])
+        print(f"N={N:6d} M={M:4d} L={L} {cls.__name__:6s}: step median {1e3 * times[len(times) // 2]:6.2f} ms, min {1e3 * times[0]:6.2f} ms")
