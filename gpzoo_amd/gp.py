@@ -182,10 +182,13 @@ class _FusedGP(nn.Module):
         spec = kernel_spec(self.kernel, X, self._latents())
         gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
         args = (spec, X, self.Z)
-        cargs = self._cache_args(spec, X)
+        factor_deps = [self.Z, self.kernel.sigma, self.kernel.lengthscale] + ([gparam] if gparam is not None else [])
+        cargs = {} if any(t.requires_grad for t in factor_deps) else self._cache_args(spec, X)
         if not cargs:
-            # cache_factor = False: nothing is kept ACROSS calls, but the backward pass of this very call needs the same
-            # chol(Kzz) / inverse its forward just produced -- hand it over instead of factoring twice per step
+            # cache_factor = False, or Z / kernel hyper-parameters are being trained (the optimiser changes them every
+            # step: a cross-call cache could never hit and its content check costs a host sync per call): nothing is
+            # kept ACROSS calls, but the backward pass of this very call needs the same chol(Kzz) / inverse its forward
+            # just produced -- hand it over instead of factoring twice per step
             cargs = dict(cache=ops.FactorCache())
         common = dict(clamp_min=self._clamp_min, **cargs, **gk)
 
@@ -201,7 +204,7 @@ class _FusedGP(nn.Module):
         def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel, g_chol, g_kl):
             return ops.svgp_backward(*args, mu, Lu_raw, float(self.jitter), self._whitened, g_mean, g_scale, scale,
                                      kernel_grads=need_kernel, g_chol=g_chol, wt_cache=kept.pop("wt", None),
-                                     g_kl=g_kl, **common)
+                                     g_kl=g_kl, trust_cache=True, **common)
 
         call = dict(forward=fwd, backward=bwd)
         if gparam is not None:
