@@ -10,13 +10,14 @@ nccl (= RCCL over xGMI); when fewer than N GPUs are visible the ranks share the 
 rendezvous / scalar all-reduce fall back to gloo (a rehearsal -- the JSON says so in `backend` and
 `devices`, and its `value` is not a scaling number).
 
-One "step" = one closed-form Gaussian ELBO evaluation on the
-Slide-seq-shaped synthetic workload of BASELINE.json configs[2]: N=200k spots,
-M=2048 inducing points, L=32 latent GPs per GPU, Matern-3/2, fp32.  With N GPUs
-each rank owns 32 latents of a 32*N-latent model (configs[3] at N=8): weak
-scaling, no data-path collective, one RCCL all-reduce of the fp64 ELBO scalar.
-`value` counts L=32-latent ELBO evaluations per second over all ranks, inputs
-resident in HBM before the timed region.
+One "step" = one closed-form Gaussian ELBO evaluation.  N = 1: the Slide-seq-shaped synthetic
+workload of BASELINE.json configs[2] -- N=200k spots, M=2048 inducing points, L=32 latent GPs, Matern-3/2,
+fp32; `value` = L=32-latent ELBO evaluations per second.  N > 1 (default `--scaling strong`): BASELINE
+configs[3] as stated -- the same workload with L=256 latent GPs, block-sharded 128 / 64 / 32 per GPU on 2 / 4 / 8
+GPUs (SURVEY §8d "cfg4", §8e) -- total work fixed, no data-path collective, one RCCL all-reduce of the fp64 ELBO
+scalar per step; `value` = L=256-latent ELBO evaluations per second of the whole job (`value_per_32_latents`
+restates it in the N = 1 line's unit).  `--scaling weak` keeps 32 latents per GPU (a 32*N-latent model) instead.
+Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0).
 """
@@ -43,7 +44,7 @@ def gemm_source_hash() -> str:
     N-chunking): a PMC traffic file is only quoted for the code it measured."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "gemm.h", "common.h", "svgp.hip"):
+    for f in ("fused1.hip", "fused1.h", "cov.h", "gemm.hip", "gemm.h", "common.h", "svgp.hip"):
         h.update(open(os.path.join(ROOT, "gpzoo_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -74,7 +75,11 @@ def parse():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config index (1-based): 2, 3 or 5")
     ap.add_argument("--N", type=int, default=None)
     ap.add_argument("--M", type=int, default=None)
-    ap.add_argument("--L", type=int, default=None, help="latents per GPU")
+    ap.add_argument("--L", type=int, default=None, help="latents per GPU (weak scaling / one GPU)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None,
+                    help="N > 1: strong (default for config 3) = BASELINE configs[3], --Ltotal latents block-sharded over "
+                         "the GPUs; weak = --L latents on every GPU")
+    ap.add_argument("--Ltotal", type=int, default=256, help="strong scaling: latents of the whole model (configs[3]: 256)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="spots in the CPU-baseline sample")
@@ -206,6 +211,26 @@ def pmc_traffic(cfg_id, N, M, L, chunk):
         return None, "no committed PMC traffic file"
 
 
+def plan_latents(cfg_id: int, world: int, rank: int, L, Ltotal: int, scaling):
+    """Which latents of which model a rank evaluates: (model config id, scaling, latents of the whole model, this rank's
+    contiguous block, latents per rank for every rank).  One GPU: configs[cfg_id - 1] as given.  Several GPUs, config 3:
+    strong scaling by default -- BASELINE configs[3], `Ltotal` (256) latents block-sharded (SURVEY §8d "cfg4", §8e);
+    `weak`: every rank owns `L` (default: the config's) latents of an L * world-latent model."""
+    from gpzoo_amd.synthetic import CONFIGS, shard_latents
+    if scaling is None:
+        scaling = "strong" if (world > 1 and cfg_id == 3 and L is None) else "weak"
+    model = 4 if (cfg_id == 3 and world > 1) else cfg_id
+    if world > 1 and scaling == "strong":
+        if L is not None:
+            raise SystemExit("--L is latents per GPU (weak scaling); with --scaling strong give --Ltotal")
+        if Ltotal < world:
+            raise SystemExit(f"--Ltotal {Ltotal} < {world} ranks: nothing to shard")
+        blocks = [shard_latents(Ltotal, world, r) for r in range(world)]
+        return model, "strong", Ltotal, blocks[rank], [len(b) for b in blocks]
+    Lper = L if L is not None else CONFIGS[cfg_id]["L"]
+    return model, "weak", Lper * world, range(rank * Lper, (rank + 1) * Lper), [Lper] * world
+
+
 def self_launch(a) -> int:
     """`python bench.py --gpus N` typed without a launcher: start the N ranks as a child torch.distributed.run
     job (this process has not touched the GPU: device_count() does not initialise it) and return its exit
@@ -252,10 +277,9 @@ def main():
     from gpzoo_amd.synthetic import CONFIGS, make_config
 
     cfg_id = a.config
-    Lper = a.L if a.L is not None else CONFIGS[cfg_id]["L"]
-    Ltot = Lper * world
-    lat = range(rank * Lper, (rank + 1) * Lper)
-    c = make_config(4 if (cfg_id == 3 and world > 1) else cfg_id, N=a.N, M=a.M, L=Ltot, latents=lat)
+    model, scaling, Ltot, lat, per_rank = plan_latents(cfg_id, world, rank, a.L, a.Ltotal, a.scaling)
+    Lper = len(lat)
+    c = make_config(model, N=a.N, M=a.M, L=Ltot, latents=lat)
     dt = c["dtype"]
     dname = "f32" if dt == torch.float32 else "f64"
     g = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
@@ -318,13 +342,17 @@ def main():
         Mp = (M + 127) // 128 * 128
         ms1, n1 = prof["stage1"]
         ms2, n2 = prof["stage2"]
-        # dominant kernel: Wt = Linv * Kzx (gemm128_kernel<T,false,EPI_STORE_STATS>), one launch per N-chunk.
-        # algorithmic flops = L * M^2 * N per evaluation (SURVEY §8d TRSM count), spread over its launches.
+        # dominant kernel: Wt = Linv * Kzx, one launch per N-chunk -- fused_stage1_kernel (the covariance operand is
+        # generated in registers, csrc/fused1.hip) for fp32 RBF / Matern-3/2 on <= 2-D inputs, else kfill_kernel +
+        # gemm128_kernel<T,NN,store+colstats>.  algorithmic flops = L * M^2 * N per evaluation (SURVEY §8d TRSM count).
         flops1 = Lper * float(M) * M * N * a.steps
         ach1 = flops1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
         mp = measured_peaks()
         traffic, traffic_src = pmc_traffic(cfg_id, N, M, Lper, a.chunk)
-        roof = {"bound": "mfma", "kernel": "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx)" % dname,
+        fused = dname == "f32" and c["kind"] in ("rbf", "nsf_rbf", "matern32") and c["X"].shape[1] <= 2
+        roof = {"bound": "mfma",
+                "kernel": ("fused_stage1_kernel (Wt = Linv*k(Z,X), Kzx generated in registers)" if fused else
+                           "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx)" % dname),
                 "achieved": ach1, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach1 / PEAK[dname],
                 "traffic": traffic, "traffic_source": traffic_src, "launches": n1,
                 "avg_launch_ms": ms1 / max(n1, 1)}
@@ -363,17 +391,27 @@ def main():
                 sub["kuf_fill"]["frac_of_measured_write_rate"] = kgbs / mp["hbm_write_GBps"]
             if mp.get("mfma_f64_TFLOPs"):
                 sub["potrf_trailing"]["frac_of_measured_peak"] = tr_tf / mp["mfma_f64_TFLOPs"]
+        # one step = one ELBO evaluation of the WHOLE model (all ranks together): strong scaling counts evaluations of the
+        # Ltot-latent model, weak scaling evaluations of the per-GPU block (Lper latents) summed over ranks
+        strong = world > 1 and scaling == "strong"
+        value = a.steps / t if strong else a.steps * world / t
+        unit_L = Ltot if strong else Lper
+        shard = ("L=%d latents block-sharded as %s per GPU on %d GPUs" % (Ltot, "/".join(map(str, per_rank)), world)
+                 if strong else "L=%d latents/GPU x %d GPU(s)" % (Lper, world))
         res = {
-            "metric": "ELBO evals/sec (L=%d-latent evaluations, all GPUs) at M=%d inducing, N=%d, L=%d per GPU"
-                      % (Lper, M, N, Lper),
-            "value": a.steps * world / t, "unit": "ELBO evals/s", "n_gpus": world, "ranks": ranks,
+            "metric": "ELBO evals/sec (L=%d-latent evaluations, all GPUs) at M=%d inducing, N=%d, %s"
+                      % (unit_L, M, N, shard),
+            "value": value, "unit": "ELBO evals/s", "n_gpus": world, "ranks": ranks,
             "backend": backend if world > 1 else None, "devices": ndev, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": dname, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: %s, N=%d spots, M=%d, L=%d latents/GPU x %d GPU(s), %s, %s"
-                                   % (cfg_id - 1, {2: "2-D synthetic spatial", 5: "MGGP multi-group synthetic (4 groups)"}.get(
-                                       cfg_id, "Slide-seq-shaped synthetic"), N, M, Lper, world, c["kind"], dname),
+            "config": {"workload": "BASELINE configs[%d]: %s, N=%d spots, M=%d, %s, %s, %s"
+                                   % (model - 1, {2: "2-D synthetic spatial", 5: "MGGP multi-group synthetic (4 groups)"}.get(
+                                       cfg_id, "Slide-seq-shaped synthetic"), N, M, shard, c["kind"], dname),
+                       "latents_total": Ltot, "latents_per_rank": per_rank,
                        "whitened": bool(c["whitened"]), "chunk": a.chunk, "factor_dtype": "f64"},
+            # the same throughput in the one-GPU line's unit (L=32-latent evaluations per second)
+            "value_per_32_latents": value * unit_L / 32.0,
             "elbo": elbo, "roofline": roof, "kernels": sub, "clocks": clocks,
         }
         if train_ms is not None:

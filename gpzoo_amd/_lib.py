@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("GPZ_HIP_LIB") or os.path.join(HERE, "libgpzoo_hip.so"
 
 GPZ_F32, GPZ_F64 = 0, 1
 KERNEL_RBF, KERNEL_MATERN32, KERNEL_MGGP_RBF, KERNEL_DISTANCE = 0, 1, 2, 3
+SVGP_MATERIALIZE_KZX = 1      # gpz_svgp_problem.flags (include/gpzoo_hip.h)
 PROF_SLOTS = ("kfill", "stage1", "stage2", "potrf_trailing", "potrf_all", "trtri", "finalize", "_unused")
 
 
@@ -27,7 +28,7 @@ class KernelDesc(C.Structure):
 class SvgpProblem(C.Structure):
     _fields_ = [
         ("k", KernelDesc),
-        ("dtype", C.c_int32), ("whitened", C.c_int32), ("d", C.c_int32), ("reserved", C.c_int32),
+        ("dtype", C.c_int32), ("whitened", C.c_int32), ("d", C.c_int32), ("flags", C.c_int32),
         ("N", C.c_int64), ("M", C.c_int64),
         ("X", C.c_void_p), ("Z", C.c_void_p), ("gX", C.c_void_p), ("gZ", C.c_void_p),
         ("mu", C.c_void_p), ("Lu_raw", C.c_void_p),

@@ -11,6 +11,9 @@
 // LDS.  Squared distances are formed by direct differencing in the output
 // precision (50x more accurate in fp32 than the matmul expansion).
 #include "common.h"
+#include "cov.h"
+
+#include <type_traits>
 
 namespace gpz {
 
@@ -57,8 +60,11 @@ __device__ __forceinline__ int checked_group(const int64_t* g, int64_t i, int G,
 template <typename Tin, typename To, int KIND, bool VECST>
 __global__ __launch_bounds__(KF_TX* KF_TY) void kfill_kernel(KfillArgs a) {
   constexpr int VEC = VecOf<To>::N;
+  // fp32 RBF / Matern values come from cov.h, the definition the fused stage-1 product shares (bitwise equal)
+  constexpr bool F32COV = std::is_same<To, float>::value && (KIND == 0 || KIND == 1);
   __shared__ To s_amp[KF_MAXL];     // sigma^2
-  __shared__ To s_coef[KF_MAXL];    // RBF: -0.5/ell^2 ; Matern: sqrt(3)/ell
+  __shared__ To s_coef[KF_MAXL];    // RBF: -0.5/ell^2 ; Matern: sqrt(3)/ell   (F32COV: cov_const's c0)
+  __shared__ To s_c1[F32COV ? KF_MAXL : 1];
   __shared__ To s_tab[KIND == 2 ? 2 * KF_MAXTAB : 2];  // MGGP: [l][ga][gb] -> {exp coef, amplitude}
 
   const int tid = threadIdx.y * KF_TX + threadIdx.x;
@@ -66,8 +72,13 @@ __global__ __launch_bounds__(KF_TX* KF_TY) void kfill_kernel(KfillArgs a) {
   for (int l = tid; l < L; l += KF_TX * KF_TY) {
     const To s = (To) static_cast<const Tin*>(a.sigma)[l];
     const To e = (To) static_cast<const Tin*>(a.ell)[l];
-    s_amp[l] = s * s;
-    s_coef[l] = (KIND == 1) ? (To)1.7320508075688772935 / e : (To)-0.5 / (e * e);
+    if constexpr (F32COV) {
+      const CovConst cc = cov_const<KIND>((float)s, (float)e);
+      s_amp[l] = cc.amp; s_coef[l] = cc.c0; s_c1[l] = cc.c1;
+    } else {
+      s_amp[l] = s * s;
+      s_coef[l] = (KIND == 1) ? (To)1.7320508075688772935 / e : (To)-0.5 / (e * e);
+    }
   }
   if (KIND == 2) {
     __syncthreads();
@@ -118,7 +129,8 @@ __global__ __launch_bounds__(KF_TX* KF_TY) void kfill_kernel(KfillArgs a) {
     for (int v = 0; v < VEC; ++v) {
       To acc = 0;
       for (int k = 0; k < d; ++k) { const To df = ax[k] - bx[v][k]; acc = fma(df, df, acc); }
-      d2[v] = (KIND == 1 || KIND == 3) ? fast_sqrt(acc) : acc;
+      if constexpr (F32COV) d2[v] = cov_radial<KIND>(acc);
+      else d2[v] = (KIND == 1 || KIND == 3) ? fast_sqrt(acc) : acc;
     }
     To* Krow = static_cast<To*>(a.K) + i * a.ldk + j0;
     for (int l = 0; l < L; ++l) {
@@ -128,7 +140,9 @@ __global__ __launch_bounds__(KF_TX* KF_TY) void kfill_kernel(KfillArgs a) {
       for (int v = 0; v < VEC; ++v) {
         const int64_t j = j0 + v;
         To val;
-        if (KIND == 0) {
+        if constexpr (F32COV) {
+          val = cov_value<KIND>(d2[v], amp, cf, s_c1[l]);
+        } else if (KIND == 0) {
           val = amp * fast_exp(cf * d2[v]);
         } else if (KIND == 1) {
           const To t = cf * d2[v];

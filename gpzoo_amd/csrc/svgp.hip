@@ -16,6 +16,7 @@
 // N is processed in chunks so Kzx / Wt only ever exist one chunk at a time; P is
 // never stored.  All reductions are slab-based (no atomics): bitwise reproducible.
 #include "common.h"
+#include "fused1.h"
 #include "gemm.h"
 
 #include <algorithm>
@@ -487,6 +488,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
   // 3. chunks of columns
   const int64_t esz = sizeof(T);
   const WtCache<T> wtc = wt_cache_of<T>(pl, p->wt_cache);
+  const bool fused = !(p->flags & GPZ_SVGP_MATERIALIZE_KZX) && fused1_supported(p->dtype, p->k.kind, p->d);
   for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
     const int64_t n0 = ci * pl.nc;
     const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
@@ -495,6 +497,19 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     const ProductSchedule sched = product_schedule<T>(true, nt);
     T* const Wc = p->wt_cache ? wtc.wt(ci) : b.Wc;      // retained for the backward pass when asked for
     T* const ps1 = p->wt_cache ? wtc.ps1(ci) : b.ps1;
+    if (fused) {
+      // Wt = Linv * k(Z, X) with the covariance generated inside the product: Kzx is never written (fused1.hip)
+      if constexpr (sizeof(T) == 4) {
+        Fused1Args fa;
+        fa.Linv = b.LinvG; fa.Mp = Mp; fa.Z = static_cast<const float*>(p->Z); fa.M = M;
+        fa.X = static_cast<const float*>(p->X) + n0 * p->d; fa.nreal = nreal; fa.d = p->d; fa.kind = p->k.kind; fa.L = L32;
+        fa.sigma = static_cast<const float*>(p->k.sigma); fa.ell = static_cast<const float*>(p->k.lengthscale);
+        fa.Wt = Wc; fa.ncp = ncp; fa.muE = b.muE; fa.ps_sq = ps1; fa.ps_mu = b.pm1;
+        prof_begin(PROF_STAGE1, s);
+        if (int rc = fused1_launch(fa, s)) return rc;
+        prof_end(PROF_STAGE1, s);
+      }
+    } else {
     prof_begin(PROF_KFILL, s);
     if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
                               p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
@@ -510,6 +525,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     prof_begin(PROF_STAGE1, s);
     if (int rc = gemm_launch(g1, EPI_STORE_STATS, s)) return rc;
     prof_end(PROF_STAGE1, s);
+    }
     GemmParams<T> g2;  // colsum((LuE^T Wt)^2)
     g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
     g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;

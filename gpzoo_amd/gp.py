@@ -179,9 +179,13 @@ class _FusedGP(nn.Module):
         if not (torch.is_grad_enabled() and any(t.requires_grad for t in trainable)):
             _, out = self._evaluate(X, groupsX, want_chol=not self._whitened)
             return self._distributions(out)
-        spec = kernel_spec(self.kernel, X, self._latents())
-        gk = dict(gX=groupsX, gZ=self.groupsZ) if self._mggp else {}
-        args = (spec, X, self.Z)
+        # The closures below serve this call's backward pass too: they hold PRIVATE copies of everything small the
+        # problem is made of (Z, the kernel's tensors, groupsZ -- a few KB), so that whatever happens to the live
+        # parameters between this forward and its backward (`.data` edits, another forward / optimiser step) the
+        # gradients are those of the problem this forward evaluated.
+        spec = ops.freeze_spec(kernel_spec(self.kernel, X, self._latents()))
+        gk = dict(gX=groupsX, gZ=self.groupsZ.detach().clone()) if self._mggp else {}
+        args = (spec, X, self.Z.detach().clone())
         factor_deps = [self.Z, self.kernel.sigma, self.kernel.lengthscale] + ([gparam] if gparam is not None else [])
         cargs = {} if any(t.requires_grad for t in factor_deps) else self._cache_args(spec, X)
         if not cargs:
@@ -199,12 +203,17 @@ class _FusedGP(nn.Module):
             out = ops.svgp_forward(*args, mu, Lu_raw, float(self.jitter), self._whitened,
                                    want_chol=not self._whitened, retain_wt=getattr(self, "retain_wt", 1.0 / 3), **common)
             kept["wt"] = out.pop("wt_cache", None)
+            kept["gen"] = out.get("factor_generation")     # which factorisation the shared buffer holds now
             return out
 
         def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel, g_chol, g_kl):
+            # the content check (a host sync) is skipped only while the buffer still holds THIS call's factor: a
+            # forward of other inputs in between refactors into the shared buffer and bumps its generation -- the
+            # check then fails on content and the backward refactors from its own copies
+            trust = kept.get("gen") is not None and common["cache"].generation == kept["gen"]
             return ops.svgp_backward(*args, mu, Lu_raw, float(self.jitter), self._whitened, g_mean, g_scale, scale,
                                      kernel_grads=need_kernel, g_chol=g_chol, wt_cache=kept.pop("wt", None),
-                                     g_kl=g_kl, trust_cache=True, **common)
+                                     g_kl=g_kl, trust_cache=trust, **common)
 
         call = dict(forward=fwd, backward=bwd)
         if gparam is not None:

@@ -223,6 +223,15 @@ def _raise_not_pd(info: torch.Tensor, what: str):
         f"positive-definite (the leading minor of order {k} is not positive-definite).")
 
 
+def freeze_spec(spec: KernelSpec) -> KernelSpec:
+    """The same kernel with private copies of its (tiny) tensors: what a backward pass must hold so that edits of the
+    live parameters between forward and backward (``.data`` writes, optimiser steps of another closure) cannot change
+    the problem it differentiates."""
+    cp = lambda t: None if t is None else t.detach().contiguous().clone()
+    return KernelSpec(spec.kind, cp(spec.sigma), cp(spec.lengthscale), spec.batched, cp(spec.group_a), cp(spec.group_r2),
+                      spec.group_pow)
+
+
 @_on_device
 def cholesky(A: torch.Tensor) -> torch.Tensor:
     """Lower Cholesky factor of (M,M) or (L,M,M), fp32 or fp64 storage (fp64 arithmetic); raises
@@ -277,23 +286,31 @@ class FactorCache:
         self.key = None
         self.snap = None
         self._pending = None
+        # Counts the factorisations written into ``buf`` (and its invalidations).  A forward pass notes the value it
+        # committed; its backward pass may skip the content check only while the counter still has that value, i.e.
+        # while no other call has refactored into the shared buffer in between.
+        self.generation = 0
+        self._rebuilds = False
 
     @staticmethod
     def fingerprint(tensors) -> torch.Tensor:
         return torch.cat([t.reshape(-1).view(torch.uint8) for t in tensors if t is not None])
 
     def attach(self, lib, p: "SvgpProblem", key, device, deps, trust: bool = False):
-        """``trust``: the caller vouches that ``deps`` are what the committed factor was built from (the backward pass
-        of the autograd call whose forward committed it: autograd's saved-tensor version check guards the inputs), so the
-        content comparison -- a device reduction and a host sync -- is skipped."""
+        """``trust``: the caller vouches that the buffer still holds the factor of exactly these ``deps`` -- the
+        backward pass of the call whose forward committed it, holding private copies of the inputs and having checked
+        that ``generation`` is still the value that forward saw -- so the content comparison (a device reduction and a
+        host sync) is skipped."""
         nbytes = lib.gpz_svgp_factor_cache_bytes(C.byref(p))
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self.key = self.snap = None
+            self.generation += 1
         if trust and self.key == key and self.snap is not None:
             p.factor_cache = self.buf.data_ptr()
             p.factor_cache_valid = 1
             self._pending = (key, self.snap)
+            self._rebuilds = False
             return True
         fp = self.fingerprint(deps)
         valid = (self.key == key and self.snap is not None and self.snap.shape == fp.shape
@@ -301,13 +318,18 @@ class FactorCache:
         p.factor_cache = self.buf.data_ptr()
         p.factor_cache_valid = int(valid)
         self._pending = (key, fp)
+        self._rebuilds = not valid
         return valid
 
     def invalidate(self):
         self.key = self.snap = None
+        self.generation += 1
 
     def commit(self):
         self.key, self.snap = self._pending
+        if self._rebuilds:                 # the launch just wrote a new factor into the buffer
+            self.generation += 1
+            self._rebuilds = False
 
 
 def factor_key(spec: "KernelSpec", Z, jitter, dtype) -> tuple:
@@ -355,11 +377,13 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
                  y=None, noise_sd: Optional[float] = None, clamp_min: float = 1e-6, chunk: int = 0,
                  want_moments: bool = True, want_Lu: bool = True, want_chol: bool = False,
                  check_info: bool = True, cache: Optional[FactorCache] = None,
-                 retain_wt: float = 0.0) -> dict:
+                 retain_wt: float = 0.0, materialize_kzx: bool = False) -> dict:
     """One fused forward pass (gpz_svgp_forward).  Returns a dict with mean, scale
     (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars.
     ``retain_wt`` > 0: keep Wt of every chunk for ``svgp_backward(wt_cache=out["wt_cache"])`` when it fits
-    in that fraction of the free device memory (288 GB HBM: 52 GB at N=200k, M=2048, L=32, fp32)."""
+    in that fraction of the free device memory (288 GB HBM: 52 GB at N=200k, M=2048, L=32, fp32).
+    ``materialize_kzx``: write every Kzx chunk to HBM and run the plain triangular product on it (the reference's
+    structure) instead of the product that generates its covariance operand in registers; same bits either way."""
     _need_cuda(X, Z, mu, Lu_raw)
     if X.dim() == 2 and X.shape[0] == 0 and Z.dim() == 2 and Z.shape[0] > 0:
         # No data points: q(F) is empty and the ELBO is -sum(KL), as the reference's torch code gives for an (0,d) X.
@@ -377,6 +401,8 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     keep: list = []
     p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
     out = {}
+    if materialize_kzx:
+        p.flags |= _lib.SVGP_MATERIALIZE_KZX
     if y is not None:
         y = y.detach().to(dt).reshape(L, N).contiguous()
         p.y, p.noise_sd = y.data_ptr(), float(noise_sd)
@@ -407,13 +433,15 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     ws = _workspace(dev, nbytes)
     rc = lib.gpz_svgp_forward(C.byref(p), int(chunk), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_svgp_forward")
+    bad = check_info and bool(info.any())       # one device-to-host sync, shared by the cache decision and the raise
     if cache is not None:
         # a factor that failed must not be reused; without the host check the cache stays uncommitted
-        if not check_info or bool(info.any()):
+        if not check_info or bad:
             cache.invalidate()
         else:
             cache.commit()
-    if check_info and bool(info.any()):
+        out["factor_generation"] = cache.generation
+    if bad:
         _raise_info(info, "linalg.cholesky")
     out["kl"], out["loglik"], out["elbo"] = scal[:L], scal[L:2 * L], scal[2 * L]
     out["info"] = info

@@ -117,12 +117,18 @@ int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_l, void* B,
  * dtype = storage/GEMM type of X, Z, mu, Lu_raw, y, mean, scale (k.dtype must
  * match).  Kzz, its Cholesky factor and inverse are carried in fp64 in both modes.
  */
+/* gpz_svgp_problem.flags */
+#define GPZ_SVGP_MATERIALIZE_KZX 1  /* forward: write every Kzx chunk to HBM with the stand-alone fill and run the plain
+                                     * triangular product on it (what the reference does, gp.py:255 + :276) instead of
+                                     * generating the covariance operand inside the product (fp32 RBF / Matern-3/2, d <= 2
+                                     * take the fused kernel by default; the two paths agree bit for bit) */
+
 typedef struct gpz_svgp_problem {
   gpz_kernel_desc k;
   int32_t dtype;
   int32_t whitened;      /* 1: WSVGP (gp.py:260), 0: SVGP (gp.py:183) */
   int32_t d;             /* input dimension */
-  int32_t reserved;
+  int32_t flags;         /* GPZ_SVGP_* bits; 0 = defaults */
   int64_t N, M;
   const void* X;         /* (N,d) */
   const void* Z;         /* (M,d) */

@@ -30,6 +30,27 @@ def test_self_launch_builds_the_driver_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_latent_plan_is_baseline_configs3_for_several_gpus():
+    """N > 1 defaults to BASELINE configs[3] as stated (SURVEY §8d "cfg4"): 256 latents block-sharded 128 / 64 / 32 per
+    GPU, strong scaling; one GPU stays configs[2]; `--scaling weak` keeps 32 latents on every GPU."""
+    import pytest
+    import bench
+    assert bench.plan_latents(3, 1, 0, None, 256, None) == (3, "weak", 32, range(0, 32), [32])
+    for world, per in ((2, 128), (4, 64), (8, 32)):
+        seen = []
+        for rank in range(world):
+            model, scaling, total, lat, per_rank = bench.plan_latents(3, world, rank, None, 256, None)
+            assert (model, scaling, total, per_rank) == (4, "strong", 256, [per] * world)
+            seen += list(lat)
+        assert seen == list(range(256))                    # contiguous blocks, every latent exactly once
+    assert bench.plan_latents(3, 3, 0, None, 256, None)[4] == [86, 85, 85]
+    assert bench.plan_latents(3, 4, 1, None, 256, "weak") == (4, "weak", 128, range(32, 64), [32] * 4)
+    assert bench.plan_latents(3, 2, 1, 4, 256, None) == (4, "weak", 8, range(4, 8), [4, 4])   # --L: latents per GPU
+    assert bench.plan_latents(5, 8, 2, None, 256, None)[:3] == (5, "weak", 256)
+    with pytest.raises(SystemExit):
+        bench.plan_latents(3, 2, 0, 4, 256, "strong")
+
+
 def test_traffic_file_is_only_quoted_for_the_kernel_it_measured(tmp_path, monkeypatch):
     import bench
     d = tmp_path / "profiles" / "r09"

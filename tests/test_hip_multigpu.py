@@ -139,13 +139,38 @@ def test_config5_mggp_fp64_as_eight_shards_full_size():
     assert a["mean"].dtype == torch.float64 and a["mean"].shape == (32, 200_000)
 
 
+def test_bench_two_ranks_is_baseline_configs3_strong_scaled():
+    """`python bench.py --gpus 2` defaults to BASELINE configs[3]: the L=256 model, 128 latents per rank, strong scaling
+    (a gloo rehearsal on this one-GPU box); the all-reduced ELBO is the single-process L=256 ELBO on the same spots."""
+    from gpzoo_amd import ops
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import make_config
+    env = dict(os.environ, GPZ_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--N", "8192", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["scaling"] == "strong"
+    assert res["config"]["latents_total"] == 256 and res["config"]["latents_per_rank"] == [128, 128]
+    assert "configs[3]" in res["config"]["workload"] and "L=256" in res["config"]["workload"]
+    assert res["value"] == pytest.approx(1e3 / res["ms_per_step"], rel=1e-9)      # L=256-latent evaluations per second
+    assert res["value_per_32_latents"] == pytest.approx(8 * res["value"], rel=1e-12)
+    g = _to_dev(make_config(4, N=8192))
+    assert g["mu"].shape[0] == 256
+    spec, extra = spec_for_config(g, torch.device("cuda", 0))
+    o = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], g["jitter"], g["whitened"], y=g["y"],
+                         noise_sd=g["noise_sd"], want_Lu=False, want_moments=False, **extra)
+    assert res["elbo"] == pytest.approx(float(o["elbo"]), rel=1e-12)
+
+
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` as typed (no launcher): it starts its own two ranks -- on this one-GPU box they
     share the device and rendezvous over gloo -- and prints one JSON line with n_gpus = ranks = 2."""
     env = dict(os.environ, GPZ_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--N", "20000", "--M", "1024",
-                        "--L", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                        "--L", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],      # --L: latents per GPU = weak
                        capture_output=True, text=True, timeout=540, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
