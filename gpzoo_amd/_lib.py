@@ -51,6 +51,7 @@ class SvgpGrads(C.Structure):
 _SIGNATURES = {
     "gpz_version": (C.c_int, []),
     "gpz_last_error": (C.c_char_p, []),
+    "gpz_source_hash": (C.c_char_p, []),
     "gpz_kfill": (C.c_int, [C.POINTER(KernelDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_int32,
                             C.c_void_p]),
@@ -120,8 +121,22 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    check_source_hash(lib)
     _lib = lib
     return lib
+
+
+def check_source_hash(lib) -> None:
+    """Refuse a binary that was not built from the sources lying next to it: file times do not survive a copy, so the
+    library carries the sha256 of its sources (gpz_source_hash) and it is compared by content.  No sources on disk (a
+    binary-only deployment) -> nothing to compare."""
+    from . import build
+    want = build.source_hash()
+    have = lib.gpz_source_hash().decode("ascii", "replace")
+    if want is not None and have != want:
+        raise RuntimeError(
+            f"{LIB_PATH} was built from other sources (binary {have}, gpzoo_amd/csrc {want}): "
+            "rebuild it with `python -m gpzoo_amd.build`")
 
 
 def check(rc: int, what: str) -> None:

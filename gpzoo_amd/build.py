@@ -19,12 +19,42 @@ HEADERS = ["common.h", "gemm.h", "cov.h", "fused1.h", os.path.join("..", "..", "
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 
 
+HASH_MARK = b"GPZ_SRC_HASH:"
+
+
+def source_hash():
+    """sha256 (32 hex digits) over the names and contents of every file the library is built from, or None when the
+    sources are not there (a binary-only deployment).  The library carries the value it was built from
+    (gpz_source_hash): a binary older than its sources is recognised by content, whatever the file times say."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        path = os.path.join(CSRC, f)
+        if not os.path.exists(path):
+            return None
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(path, "rb").read())
+        h.update(b"\0")
+    return h.hexdigest()[:32]
+
+
+def embedded_hash(lib_path: str = LIB):
+    """The source hash a built library carries, read from the file (no dlopen); None if absent."""
+    try:
+        blob = open(lib_path, "rb").read()
+    except OSError:
+        return None
+    i = blob.find(HASH_MARK)
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i + len(HASH_MARK):j].decode("ascii", "replace")
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return embedded_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -36,7 +66,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = [f'-DGPZ_SOURCE_HASH="{source_hash()}"'] if src == "runtime.hip" else []
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

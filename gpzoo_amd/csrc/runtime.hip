@@ -53,6 +53,16 @@ void prof_end(int slot, hipStream_t s) {
 
 extern "C" int gpz_version(void) { return GPZ_VERSION; }
 
+// sha256 of the sources this binary was built from (gpzoo_amd/build.py passes it in); the marker prefix lets the
+// build script find the value in the file without loading it.
+#ifndef GPZ_SOURCE_HASH
+#define GPZ_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* gpz_source_hash(void) {
+  static const char marked[] = "GPZ_SRC_HASH:" GPZ_SOURCE_HASH;
+  return marked + 13;
+}
+
 extern "C" const char* gpz_last_error(void) { return gpz::g_err; }
 
 extern "C" int gpz_profile_enable(int32_t on) {

@@ -61,6 +61,9 @@ typedef struct gpz_kernel_desc {
 
 int gpz_version(void);
 const char* gpz_last_error(void);
+/* sha256 (32 hex digits) of the source files this binary was built from ("unknown" for a hand-made build): the Python
+ * loader refuses a library whose value differs from the sources lying next to it (a stale binary). */
+const char* gpz_source_hash(void);
 
 /* K[l][i][j] = k_l(A_i, B_j) (+ jitter where i == j if jitter != 0).
  * Replaces kernel.forward(X, Z) -- kernels.py:29-30, 57-58, 98-104, 118-130,

@@ -69,3 +69,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libgpzoo_hip.so"))
     with pytest.raises(RuntimeError, match="no CPU/torch fallback"):
         _lib.load()
+
+
+def test_library_carries_the_hash_of_its_sources(monkeypatch):
+    """A stale binary is recognised by CONTENT: the library embeds the sha256 of the sources it was built from, the
+    build script compares it (not file times) to decide what is stale, and the loader refuses a mismatch."""
+    import pytest
+    from gpzoo_amd import _lib, build
+    build.build(force=False, verbose=False)
+    want = build.source_hash()
+    assert want is not None and len(want) == 32
+    assert build.embedded_hash() == want                      # read from the file, no dlopen
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.gpz_source_hash.restype = ctypes.c_char_p
+    assert lib.gpz_source_hash().decode() == want             # the exported entry says the same
+    assert not build._stale()
+    # sources that differ from what the binary was built from: stale for the build script, refused by the loader --
+    # file times play no part (nothing on disk changes here)
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 32)
+    assert build._stale()
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib.load()
+    # a binary-only deployment (no sources next to the library) has nothing to compare
+    monkeypatch.setattr(build, "source_hash", lambda: None)
+    assert _lib.load() is not None
+    monkeypatch.setattr(_lib, "_lib", None)

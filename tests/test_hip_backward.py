@@ -36,6 +36,61 @@ def test_backward_matches_reference_autograd(name):
     assert float(loss.detach()) == pytest.approx(-c["elbo"], rel=rt)
 
 
+@pytest.mark.parametrize("edit", ["inplace", "rebind", "sigma"])
+@pytest.mark.parametrize("name", ["svgp_nsf_rbf_f64", "wsvgp_matern32_f64", "mggp_svgp_mggp_nsf_rbf_f64", "svgp_matern32_f32"])
+def test_backward_of_an_earlier_forward_after_data_edit_and_second_forward(name, edit):
+    """forward A -> `.data` edit of a frozen input (invisible to autograd's version counters) -> forward B (refactors
+    into the SHARED factor cache) -> backward(A): the gradients must be those of problem A -- the reference's autograd
+    goldens -- not a mix of B's factor with A's saved tensors (the backward used to trust the
+    cache on the host key alone).  The backward holds private copies of A's inputs and trusts the buffer only while its
+    generation counter is the one forward A committed."""
+    from gpzoo.utilities import whitened_KL_batched
+    c = load_case(name)
+    model = build(name, c)
+    gp = model.gp
+    for t in [gp.Z, *gp.kernel.parameters()]:
+        t.requires_grad_(False)                      # frozen: the persistent cross-call cache is in play
+    X, y = c["X"].cuda(), c["y"].cuda()
+    kw = {"groupsX": c["gX"].cuda()} if "gX" in c else {}
+
+    def loss_of():
+        pY, qF, qU, pU = model(X=X, E=1, **kw)
+        s = torch.nn.functional.softplus(model.noise)
+        kl = whitened_KL_batched(qU.mean, qU.scale_tril).sum() if c["whitened"] else \
+            torch.distributions.kl_divergence(qU, pU).sum()
+        return -(pY.log_prob(y).sum() - (qF.scale ** 2).sum() / (2 * s ** 2) - kl)
+
+    loss_a = loss_of()
+    gen_a = gp._factor_cache.generation
+    if edit == "inplace":
+        v0 = gp.Z._version
+        gp.Z.data.add_(0.37)
+        assert gp.Z._version == v0
+    elif edit == "rebind":
+        gp.Z.data = gp.Z.data * 1.1 + 0.2
+    else:
+        gp.kernel.sigma.data.mul_(1.3)
+    loss_b = loss_of()                               # another forward, other inputs, same cache buffer
+    assert gp._factor_cache.generation != gen_a      # it refactored
+    assert float(loss_b.detach()) != float(loss_a.detach())
+    loss_a.backward()
+    rt = rtol_for(X.dtype)
+    sc_mu, sc_Lu = float(c["grad_mu"].abs().max()), float(c["grad_Lu"].abs().max())
+    torch.testing.assert_close(gp.mu.grad.cpu(), c["grad_mu"], rtol=rt, atol=rt * sc_mu)
+    torch.testing.assert_close(gp.Lu.grad.cpu(), c["grad_Lu"], rtol=rt, atol=rt * sc_Lu)
+    # and B's own backward still differentiates B: same numbers as a cache-less evaluation of the edited model
+    gp.mu.grad = gp.Lu.grad = None
+    loss_b.backward()
+    g_mu, g_Lu = gp.mu.grad.clone(), gp.Lu.grad.clone()
+    gp.mu.grad = gp.Lu.grad = None
+    gp.cache_factor = False
+    loss_of().backward()
+    torch.testing.assert_close(g_mu, gp.mu.grad, rtol=1e-9 if X.dtype == torch.float64 else 1e-4, atol=1e-9 * max(sc_mu, 1.0)
+                               if X.dtype == torch.float64 else 1e-4 * max(sc_mu, 1.0))
+    torch.testing.assert_close(g_Lu, gp.Lu.grad, rtol=1e-9 if X.dtype == torch.float64 else 1e-4, atol=1e-9 * max(sc_Lu, 1.0)
+                               if X.dtype == torch.float64 else 1e-4 * max(sc_Lu, 1.0))
+
+
 def test_backward_multi_chunk_matches_single_chunk():
     """Chunked accumulation of the (M x n)(n x M) gradient product: 3 chunks == 1 chunk."""
     from gpzoo_amd import ops
