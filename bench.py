@@ -44,7 +44,7 @@ def gemm_source_hash() -> str:
     N-chunking): a PMC traffic file is only quoted for the code it measured."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("fused1.hip", "fused1.h", "cov.h", "gemm.hip", "gemm.h", "common.h", "svgp.hip"):
+    for f in ("gemmw.hip", "gemmw.h", "cov.h", "gemm.hip", "gemm.h", "common.h", "svgp.hip"):
         h.update(open(os.path.join(ROOT, "gpzoo_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -342,17 +342,15 @@ def main():
         Mp = (M + 127) // 128 * 128
         ms1, n1 = prof["stage1"]
         ms2, n2 = prof["stage2"]
-        # dominant kernel: Wt = Linv * Kzx, one launch per N-chunk -- fused_stage1_kernel (the covariance operand is
-        # generated in registers, csrc/fused1.hip) for fp32 RBF / Matern-3/2 on <= 2-D inputs, else kfill_kernel +
-        # gemm128_kernel<T,NN,store+colstats>.  algorithmic flops = L * M^2 * N per evaluation (SURVEY §8d TRSM count).
+        # dominant kernel: Wt = Linv * Kzx, one launch per N-chunk -- fp32: gemmw_kernel (256 x 128 tiles, csrc/gemmw.hip),
+        # fp64: gemm128_kernel<T,NN,store+colstats>.  algorithmic flops = L * M^2 * N per evaluation (SURVEY §8d TRSM count).
         flops1 = Lper * float(M) * M * N * a.steps
         ach1 = flops1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
         mp = measured_peaks()
         traffic, traffic_src = pmc_traffic(cfg_id, N, M, Lper, a.chunk)
-        fused = dname == "f32" and c["kind"] in ("rbf", "nsf_rbf", "matern32") and c["X"].shape[1] <= 2
         roof = {"bound": "mfma",
-                "kernel": ("fused_stage1_kernel (Wt = Linv*k(Z,X), Kzx generated in registers)" if fused else
-                           "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx)" % dname),
+                "kernel": ("gemmw_kernel<256,128,mem,lower,store+colstats> (Wt = Linv*Kzx, csrc/gemmw.hip)" if dname == "f32"
+                           else "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx)" % dname),
                 "achieved": ach1, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach1 / PEAK[dname],
                 "traffic": traffic, "traffic_source": traffic_src, "launches": n1,
                 "avg_launch_ms": ms1 / max(n1, 1)}

@@ -8,8 +8,8 @@
 
 namespace gpz {
 
-// Per-latent constants: amp = sigma^2; RBF: c0 = -0.5 / ell^2 * log2(e); Matern-3/2: c0 = sqrt(3) / ell,
-// c1 = c0 * log2(e) (the exponent goes through v_exp_f32 = 2^x).
+// Per-latent constants: amp = sigma^2; RBF: c0 = -0.5 / ell^2 * log2(e); Matern-3/2: c0 = sigma^2 sqrt(3) / ell,
+// c1 = sqrt(3) / ell * log2(e) (the exponent goes through v_exp_f32 = 2^x).
 struct CovConst { float amp, c0, c1; };
 
 template <int KIND>
@@ -18,8 +18,9 @@ __device__ __forceinline__ CovConst cov_const(float sigma, float ell) {
   CovConst c;
   c.amp = sigma * sigma;
   if (KIND == 1) {
-    c.c0 = 1.7320508075688772935f / ell;
-    c.c1 = c.c0 * 1.44269504088896341f;
+    const float a = 1.7320508075688772935f / ell;
+    c.c0 = c.amp * a;
+    c.c1 = a * 1.44269504088896341f;
   } else {
     c.c0 = (-0.5f / (ell * ell)) * 1.44269504088896341f;
     c.c1 = 0.f;
@@ -48,7 +49,7 @@ template <int KIND>
 __device__ __forceinline__ float cov_value(float s, float amp, float c0, float c1) {
 #pragma clang fp contract(off)
   if (KIND == 1) {
-    const float lin = amp * __builtin_fmaf(c0, s, 1.0f);          // sigma^2 (1 + sqrt(3) r / ell)
+    const float lin = __builtin_fmaf(c0, s, amp);                // sigma^2 (1 + sqrt(3) r / ell)
     return lin * __builtin_amdgcn_exp2f(-(c1 * s));              // exp(-sqrt(3) r / ell)
   }
   return amp * __builtin_amdgcn_exp2f(c0 * s);                   // sigma^2 exp(-d^2 / (2 ell^2))

@@ -1,0 +1,496 @@
+// gemmw.hip -- the two big fp32 products of the forward pass on wide workgroup tiles.
+//
+//   stage 1  Wt = Linv * Kzx      (gp.py:255 + :276: Kzx = kernel(Z, X); solve_triangular(L, Kzx))  A lower triangular
+//   stage 2  colsum((LuE^T Wt)^2) (gp.py:280-296 / utilities.py:382-397)                            A upper triangular
+//
+// One kernel template, two instantiations of its tile:
+//   * B from memory (stage 2; stage 1 of kernels the generator below does not cover): 256 x 128 tile;
+//   * B GENERATED (stage 1, fp32 RBF / Matern-3/2 on 1-D / 2-D inputs): 512 x 64 tile whose 16 x 64 slice of Kzx is
+//     computed by the workgroup itself, ONCE, from the Z block in LDS and each lane's own column -- Kzx is never
+//     written to HBM (the reference and the two-kernel path move 52 GB of it per evaluation at N=200k, M=2048, L=32).
+//     On gfx950 the f32 MFMA runs at the vector rate and vector instructions do NOT issue in its shadow (measured:
+//     every VALU instruction added to the loop costs its own ~4-8 issue cycles of MFMA time, pinned interleaving or
+//     not), so the covariance arithmetic is a tax proportional to (values per workgroup step) / (MFMAs per step)
+//     = 16 / rows of the tile: generated per wave in registers for a 128-row wave tile it cost 19 %, shared through
+//     LDS by 512 rows it costs 4 %.
+//
+// Common structure: 8 waves, wave tile 128 x 32 (16 accumulator tiles of v_mfma_f32_16x16x4_f32), k staged 16 deep.
+// Both operand tiles reach LDS by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write, no vector address
+// arithmetic: descriptor + constant per-lane offset + scalar offset); A sits [row][16 k] with its four 16-byte chunks
+// permuted per row so that the ds_read_b128 fragment reads are conflict-free, B sits [k][n] in 1-KB pieces 32 / 64
+// bytes apart so that the k and k + 4 rows a half-wave reads fall on disjoint banks.  Double buffered, one barrier per
+// 16-deep step, <= 128 VGPRs and <= 74 KB of LDS: two workgroups per CU.  Triangular A: a wave skips the steps in
+// which its 128 rows are zero and, inside its diagonal 128-block, the 16-row sub-tiles that are -- as straight-line
+// phases with compile-time ranges (hipcc copies accumulators around MFMAs that sit under run-time branches).  (Dealing
+// the rows to the row-waves in interleaved 16-row sub-tiles, so that every wave sees the same k range, was built and
+// measured: bitwise the same results, stage 1 unchanged, stage 2 1 % slower -- the contiguous blocks stay.)
+//
+// Values, k order and MFMA order equal those of kfill.hip + gemm128_kernel (cov.h is shared; lane group q owns
+// k = 4q .. 4q+3 of a 16-deep chunk in both), so Wt is bitwise the same on either path.
+#include "gemmw.h"
+
+#include "cov.h"
+
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+
+// Timing-only diagnostics (WRONG results by construction; tools/ablate_fused.sh builds them next to the real library):
+// -DGPZ_W_ABL=<bits>  1: no covariance arithmetic (the generated B tile holds a coordinate), 2: no tile loads after the
+// first, 4: no epilogue (statistics, Wt store), 8: no per-step barrier.
+#ifndef GPZ_W_ABL
+#define GPZ_W_ABL 0
+#endif
+
+namespace gpz {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { WB_MEM = 0, WB_GEN = 1 };
+enum { WA_LOWER = 1, WA_UPPER = 2 };
+enum { WE_STORE_STATS = 0, WE_STATS = 1 };
+
+struct WParams {
+  const float* A; int64_t lda, sA0;         // (L, Mp, Mp)
+  const float* B; int64_t ldb, sB0;         // WB_MEM: (L, Mp, ncols) row-major
+  const float* Z; int64_t MD;               // WB_GEN: (M, D), MD = M * D
+  const float* X; int64_t nreal;            //         (nreal, D)
+  const float* sigma; const float* ell;     //         (L,)
+  float* C; int64_t ldc, sC0;               // WE_STORE_STATS: (L, Mp, ncols)
+  const float* mu; int64_t sMu;             // WE_STORE_STATS: (L, Mp)
+  float* ps_sq; float* ps_mu; int64_t ncols;  // [L][nblk][ncols]
+  int64_t M;                                // real rows (the rest is padding)
+  int L, nblk, mtw, nt, W, strips;          // latents, 128-blocks, row tiles, column tiles, strip width, strips
+};
+
+constexpr int W_BK = 16;
+
+template <int TM, int TN, int BSRC, int D>
+struct WLds {
+  static constexpr int A_ELEMS = TM * W_BK;
+  static constexpr int RPP = 256 / TN;                        // k rows per 1-KB piece of the B tile
+  static constexpr int PITCH = 256 + (RPP == 2 ? 8 : 16);     // floats between pieces: rows k and k + 4 shift by 16 banks
+  static constexpr int B_ELEMS = (W_BK / RPP) * PITCH;
+  static constexpr int STAGE = A_ELEMS + B_ELEMS;
+  static constexpr int ZB = 128 * D;                          // WB_GEN: one 128-point block of Z per buffer
+  static constexpr size_t bytes = sizeof(float) * (2 * STAGE + (BSRC == WB_GEN ? 2 * ZB : 0));
+};
+
+template <int TM, int TN, int BSRC, int ATRI, int EPI, int KIND, int D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_kernel(const WParams p) {
+  constexpr int BK = W_BK;
+  constexpr int WMW = TM / 128, WNW = TN / 32;          // waves along rows / columns
+  static_assert(WMW * WNW == 8, "eight waves of 128 x 32");
+  using G = WLds<TM, TN, BSRC, D>;
+  constexpr int RPP = G::RPP, PITCH = G::PITCH;
+  extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+  auto sA = [&](int buf) -> float* { return smem + buf * G::STAGE; };
+  auto sB = [&](int buf) -> float* { return smem + buf * G::STAGE + G::A_ELEMS; };
+  float* const sZ = smem + 2 * G::STAGE;       // WB_GEN: [2][ZB], inducing points of the 128-blocks (parity of the block)
+  auto addrB = [](int k, int n) { return (k / RPP) * PITCH + (k % RPP) * TN + n; };
+
+  // ---------------- tile decode ----------------
+  // Blocks b, b + 8, ... run on one XCD (round-robin dispatch) and share its L2.
+  // WB_GEN: the only operand in memory is A.  A unit = (row tile, latent, strip of W column tiles): its W workgroups
+  //   stream one Linv row panel together; units go longest k range first, each level spread evenly over the XCDs.
+  // WB_MEM: a unit = (latent, strip of W column tiles): inside it row tiles go longest k range first and the W workgroups
+  //   of a row tile are dispatched together, so they walk the same A panel in lock-step over the strip's B panels.
+  int ti, tj, b0;
+  {
+    const int bid = blockIdx.x;
+    const int x = bid & 7, s = bid >> 3;
+    if (BSRC == WB_GEN) {
+      const int ug = s / p.W, within = s - ug * p.W;
+      const int u = ug * 8 + x;
+      const int per_level = p.L * p.strips;
+      if (u >= p.mtw * per_level) return;
+      const int level = u / per_level, rem = u - level * per_level;
+      ti = (ATRI == WA_LOWER) ? p.mtw - 1 - level : level;
+      b0 = rem / p.strips;
+      tj = (rem - b0 * p.strips) * p.W + within;
+    } else {
+      const int per_unit = p.mtw * p.W;
+      const int u = (s / per_unit) * 8 + x, within = s % per_unit;
+      if (u >= p.L * p.strips) return;
+      b0 = u / p.strips;
+      const int ii = within / p.W;
+      tj = (u - b0 * p.strips) * p.W + within % p.W;
+      ti = (ATRI == WA_LOWER) ? p.mtw - 1 - ii : ii;
+    }
+    if (tj >= p.nt) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // which 128-row block of the tile a wave takes alternates from tile to tile (blocks carry different amounts of work)
+  const int wm = (wave / WNW) ^ ((ti ^ tj) & 1), wn = wave % WNW;
+  const int r = lane & 15, q = lane >> 4;
+  const int Mp = p.nblk * 128;
+  const int k_begin = (ATRI == WA_UPPER) ? TM * ti : 0;
+  const int k_end = (ATRI == WA_LOWER) ? min(TM * (ti + 1), Mp) : Mp;
+  const int nk = (k_end - k_begin) / BK;
+  const int db = WMW * ti + wm;                 // this wave's 128-row block
+  const bool active = db < p.nblk;              // a block count that is no multiple of WMW leaves the last tile partly empty
+  // steps of this wave: LOWER  [0, n_a) full, [n_a, n_a + 8) diagonal block, rest idle;
+  //                     UPPER  [0, n_a) idle, [n_a, n_a + 8) diagonal block, rest full;   an inactive wave idles throughout
+  const int n_a = 8 * (ATRI == WA_LOWER ? db : wm);
+
+  // ---------------- staging: LDS-DMA ----------------
+  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr int NPA = TM / 128;                 // 1-KB pieces (16 rows x 64 B) of the A tile per wave
+#if defined(__HIP_DEVICE_COMPILE__)   // gfx950 builtins: the host pass of this single-source file only needs the kernel's stub
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.A + b0 * p.sA0), 0, (int)(p.lda * Mp * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(BSRC == WB_MEM ? p.B + b0 * p.sB0 : p.Z), 0,
+      (int)((BSRC == WB_MEM ? p.ldb * Mp : p.MD) * sizeof(float)), 0x00020000);   // reads past the end return zero
+#endif
+  int a_soff[NPA];
+#pragma unroll
+  for (int h = 0; h < NPA; ++h) {
+    int row = ti * TM + (NPA * wave + h) * 16;
+    while (row >= Mp) row -= 128;               // rows past the matrix: re-read valid ones (their waves are inactive)
+    a_soff[h] = (row * (int)p.lda + k_begin) * (int)sizeof(float);
+  }
+  // chunk c of row w sits at slot c ^ g(w), g = [0, 2, 3, 1][(w >> 2) & 3]: the 16 lanes of a ds_read_b128 group
+  // (rows r, chunk q) then cover sixteen distinct 16-byte slots of the 256-byte bank row
+  auto gperm = [](int w) { const int t = (w >> 2) & 3; return (((t >> 1) ^ t) & 1) << 1 | (t >> 1); };
+  const int a_voff = ((lane >> 2) * (int)p.lda + (((lane & 3) ^ gperm(lane >> 2)) * 4)) * (int)sizeof(float);
+  // B from memory: wave w fetches the 1-KB piece w = k rows 2w, 2w + 1 of the step (TN = 128)
+  int b_soff = ((k_begin + RPP * wave) * (int)p.ldb + tj * TN) * (int)sizeof(float);
+  const int b_voff = ((lane / (TN / 4)) * (int)p.ldb + (lane % (TN / 4)) * 4) * (int)sizeof(float);
+  bool abl_first = true;
+  auto stage_load = [&](int buf) __attribute__((always_inline)) {
+    if ((GPZ_W_ABL & 2) && !abl_first) return;
+    abl_first = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int h = 0; h < NPA; ++h) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(sA(buf) + (NPA * wave + h) * 256), 16, a_voff, a_soff[h], 0, 0);
+      a_soff[h] += BK * (int)sizeof(float);
+    }
+    if constexpr (BSRC == WB_MEM) {
+      static_assert(BSRC != WB_MEM || W_BK / RPP == 8, "one B piece per wave");
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sB(buf) + wave * PITCH), 16, b_voff, b_soff, 0, 0);
+      b_soff += BK * (int)p.ldb * (int)sizeof(float);
+    }
+#endif
+  };
+
+  // ---------------- WB_GEN: the B tile is this workgroup's own slice of Kzx ----------------
+  // Inducing points: one 128-point block per LDS buffer (waves 0 .. 2D-1, one coordinate per lane), fetched one block
+  // ahead.  Thread (wave w, lane l) computes rows w and w + 8 of the 16-deep step at columns l, l + 64, ...: its z is a
+  // wave-uniform LDS broadcast, its x sits in registers for the whole tile.
+  constexpr int NXC = TN / 64;                  // columns per lane
+  float xc[NXC][D], ampn[NXC], c0n[NXC];
+  CovConst cc = {0.f, 0.f, 0.f};
+  if constexpr (BSRC == WB_GEN) {
+    cc = cov_const<KIND>(p.sigma[b0], p.ell[b0]);
+#pragma unroll
+    for (int h = 0; h < NXC; ++h) {
+      const int64_t n = (int64_t)tj * TN + h * 64 + lane;
+      const bool real = n < p.nreal;
+#pragma unroll
+      for (int k = 0; k < D; ++k) xc[h][k] = real ? p.X[n * D + k] : 0.f;
+      ampn[h] = real ? cc.amp : 0.f;            // padded columns: exactly zero, as the stand-alone fill writes them
+      c0n[h] = (KIND == 1 && !real) ? 0.f : cc.c0;   // (Matern: c0 carries the amplitude too)
+    }
+  }
+  auto z_load = [&](int blk) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (wave < 2 * D)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sZ + (blk & 1) * G::ZB + wave * 64), 4, lane * 4,
+                                               (blk * G::ZB + wave * 64) * 4, 0, 0);
+#endif
+  };
+  auto b_generate = [&](int buf, int step) __attribute__((always_inline)) {   // step: index of the 16-deep step from k = 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kk = wave + 8 * i, kg = step * BK + kk;
+      const float* zp = sZ + ((kg >> 7) & 1) * G::ZB + (kg & 127) * D;
+      float z[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) z[k] = zp[k];
+#pragma unroll
+      for (int h = 0; h < NXC; ++h) {
+        const float v = (GPZ_W_ABL & 1) ? z[0] + xc[h][0]
+                                        : cov_value<KIND>(cov_radial<KIND>(cov_d2<D>(z, xc[h])), ampn[h], c0n[h], cc.c1);
+        sB(buf)[addrB(kk, h * 64 + lane)] = v;
+      }
+    }
+  };
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
+
+  // fragment addresses (floats): lane (r, q) owns k = 4q .. 4q+3 of the 16-deep step
+  const int fr_a = (wm * 128 + r) * BK + ((q ^ gperm(r)) * 4);
+  int fr_b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fr_b[j] = addrB(4 * q + j, wn * 32 + r);
+
+  // One step of MFMAs over the 16-row sub-tiles LO .. HI (compile-time); the A fragments come in two halves of four
+  // sub-tiles (16 registers live instead of 32).
+  auto mma_step = [&](int buf, auto lo_c, auto hi_c) __attribute__((always_inline)) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+    float bf[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bf[j][ni] = sB(buf)[fr_b[j] + ni * 16];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 fa[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (half * 4 + m >= LO && half * 4 + m <= HI)
+          fa[m] = *reinterpret_cast<const f32x4*>(sA(buf) + fr_a + (half * 4 + m) * 16 * BK);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            if (half * 4 + m >= LO && half * 4 + m <= HI)
+              acc[half * 4 + m][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][j], bf[j][ni], acc[half * 4 + m][ni], 0, 0, 0);
+    }
+  };
+
+  // ---------------- k loop ----------------
+  // Step t: start the DMA of step t + 1 into the other buffer (and, WB_GEN, compute its B tile there), run step t, wait
+  // for the DMA, barrier.  Every region below starts at an even t and has an even length (8 steps per 128-block), so the
+  // buffer is a compile-time constant per step; no MFMA sits under a run-time branch.
+  using std::integral_constant;
+  const int step0 = k_begin / BK;
+  stage_load(0);
+  if constexpr (BSRC == WB_GEN) {
+    z_load(step0 >> 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    b_generate(0, step0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int t = 0;
+  auto step = [&](auto par_c, auto run_c, auto lo_c, auto hi_c) __attribute__((always_inline)) {
+    constexpr int P = decltype(par_c)::value;
+    if (t + 1 < nk) {
+      stage_load(P ^ 1);
+      if constexpr (BSRC == WB_GEN) {
+        const int st = step0 + t;
+        if ((st & 7) == 0 && (st >> 3) + 1 < p.nblk) z_load((st >> 3) + 1);   // first step of a 128-block: fetch the next block
+        b_generate(P ^ 1, st + 1);
+      }
+    }
+    if constexpr (decltype(run_c)::value) mma_step(P, lo_c, hi_c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(GPZ_W_ABL & 8)) __syncthreads();
+    ++t;
+  };
+  using no_run = integral_constant<bool, false>;
+  using run = integral_constant<bool, true>;
+  using i0 = integral_constant<int, 0>;
+  using i1 = integral_constant<int, 1>;
+  using i7 = integral_constant<int, 7>;
+  auto idle_until = [&](int end) __attribute__((always_inline)) {
+    while (t < end) { step(i0{}, no_run{}, i0{}, i7{}); step(i1{}, no_run{}, i0{}, i7{}); }
+  };
+  auto full_until = [&](int end) __attribute__((always_inline)) {
+    while (t < end) { step(i0{}, run{}, i0{}, i7{}); step(i1{}, run{}, i0{}, i7{}); }
+  };
+  // diagonal 128-block: step u covers k = 16u .. 16u+15 of it.  A lower triangular: the rows above sub-tile u are zero
+  // there (mi >= u); A upper triangular: the rows below it are (mi <= u).
+  auto diagonal = [&](auto self, auto u_c) __attribute__((always_inline)) -> void {
+    constexpr int U = decltype(u_c)::value;
+    if constexpr (ATRI == WA_LOWER) step(integral_constant<int, U & 1>{}, run{}, integral_constant<int, U>{}, i7{});
+    else step(integral_constant<int, U & 1>{}, run{}, i0{}, integral_constant<int, U>{});
+    if constexpr (U + 1 < 8) self(self, integral_constant<int, U + 1>{});
+  };
+  if (!active) {
+    idle_until(nk);
+  } else if constexpr (ATRI == WA_LOWER) {
+    full_until(n_a);
+    diagonal(diagonal, i0{});
+    idle_until(nk);
+  } else {
+    idle_until(n_a);
+    diagonal(diagonal, i0{});
+    full_until(nk);
+  }
+
+  // ---------------- epilogue ----------------
+  if (!active) return;
+  if (GPZ_W_ABL & 4) {         // keep the accumulators alive, store (practically) nothing
+    float sum = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sum += acc[mi][ni][g];
+    if (sum == 12345.678f) p.ps_sq[0] = sum;
+    return;
+  }
+  const int64_t row0 = (int64_t)db * 128;
+  const int64_t ccol0 = (int64_t)tj * TN + wn * 32;
+  // WB_GEN: rows >= M are padding -- Linv is the identity there, so they picked up k(0, x); the stand-alone path has zeros
+  if (BSRC == WB_GEN && row0 + 128 > p.M) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (row0 + mi * 16 + 4 * q + g >= p.M) {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni][g] = 0.f;
+        }
+  }
+  // column statistics over this wave's 128 rows = one 128-row block: registers -> lane groups, no workgroup step
+  {
+    float ssq[2] = {0.f, 0.f}, smu[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      f32x4 m4 = {0, 0, 0, 0};
+      if constexpr (EPI == WE_STORE_STATS) m4 = *reinterpret_cast<const f32x4*>(p.mu + b0 * p.sMu + row0 + 4 * q + mi * 16);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const float v = acc[mi][ni][g];
+          ssq[ni] = __builtin_fmaf(v, v, ssq[ni]);
+          if constexpr (EPI == WE_STORE_STATS) smu[ni] = __builtin_fmaf(m4[g], v, smu[ni]);
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      ssq[ni] += __shfl_xor(ssq[ni], 16); ssq[ni] += __shfl_xor(ssq[ni], 32);
+      if constexpr (EPI == WE_STORE_STATS) { smu[ni] += __shfl_xor(smu[ni], 16); smu[ni] += __shfl_xor(smu[ni], 32); }
+      if (q == 0) {
+        const int64_t o = ((int64_t)b0 * p.nblk + db) * p.ncols + ccol0 + ni * 16 + r;
+        p.ps_sq[o] = ssq[ni];
+        if constexpr (EPI == WE_STORE_STATS) p.ps_mu[o] = smu[ni];
+      }
+    }
+  }
+  // output tile: through a wave-private LDS strip (it aliases the tile buffers: every read of them is behind the loop's
+  // last barrier) so each store instruction writes eight whole 128-byte row segments
+  if constexpr (EPI == WE_STORE_STATS) {
+    constexpr int LDE = 36;
+    float* strip = smem + wave * (32 * LDE);
+    float* Cg = p.C + b0 * p.sC0 + row0 * p.ldc + ccol0;
+    const int srow = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) strip[(mm * 16 + 4 * q + g) * LDE + ni * 16 + r] = acc[pass * 2 + mm][ni][g];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + srow;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * LDE + c4);
+        *reinterpret_cast<f32x4*>(Cg + (int64_t)(pass * 32 + row) * p.ldc + c4) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ---------------- host side ----------------
+template <typename K>
+static int launch_wide(K kernel, size_t lds, const WParams& p, int64_t nblocks, hipStream_t s) {
+  // dynamic LDS above 64 KB is an opt-in per kernel function and device (a handful of instantiations: linear search)
+  struct Seen { const void* fn; int dev; };
+  static Seen seen[64];
+  static int n_seen = 0;
+  static std::mutex mu;
+  int dev = 0;
+  GPZ_HIP_OK(hipGetDevice(&dev));
+  if (lds > 64 * 1024) {
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    bool have = false;
+    for (int i = 0; i < n_seen; ++i) have = have || (seen[i].fn == fn && seen[i].dev == dev);
+    if (!have) {
+      GPZ_HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (n_seen < 64) seen[n_seen++] = Seen{fn, dev};
+    }
+  }
+  GPZ_REQUIRE(nblocks > 0 && nblocks < (1ll << 31), "wide product: bad grid");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(512), lds, s, p);
+  GPZ_LAUNCH_OK();
+  return 0;
+}
+
+bool fused1_supported(int dtype, int kind, int d) {
+  return dtype == GPZ_F32 && (kind == GPZ_KERNEL_RBF || kind == GPZ_KERNEL_MATERN32) && (d == 1 || d == 2);
+}
+
+int fused1_launch(const Fused1Args& a, hipStream_t s) {
+  GPZ_REQUIRE(fused1_supported(GPZ_F32, a.kind, a.d), "fused stage 1: kind=%d d=%d unsupported", a.kind, a.d);
+  GPZ_REQUIRE(a.Mp % 128 == 0 && a.ncp % 128 == 0 && a.Mp > 0 && a.ncp > 0 && a.L > 0, "fused stage 1: bad extents");
+  GPZ_REQUIRE(a.Mp * a.Mp * 4 < (1ll << 31) && a.M * a.d * 4 < (1ll << 31), "fused stage 1: M too large");
+  constexpr int TM = 512, TN = 64;
+  WParams p = {};
+  p.A = a.Linv; p.lda = a.Mp; p.sA0 = a.Mp * a.Mp;
+  p.Z = a.Z; p.MD = a.M * a.d; p.M = a.M;
+  p.X = a.X; p.nreal = a.nreal;
+  p.sigma = a.sigma; p.ell = a.ell;
+  p.C = a.Wt; p.ldc = a.ncp; p.sC0 = a.Mp * a.ncp;
+  p.mu = a.muE; p.sMu = a.Mp;
+  p.ps_sq = a.ps_sq; p.ps_mu = a.ps_mu; p.ncols = a.ncp;
+  p.L = a.L; p.nblk = (int)(a.Mp / 128); p.mtw = (int)((a.Mp + TM - 1) / TM); p.nt = (int)(a.ncp / TN);
+  // strips of W column tiles: wide enough to share a row panel in L2 (one XCD holds 64 workgroups), numerous enough that
+  // every level of row tiles gives each XCD work
+  int strips = (p.nt + 63) / 64;
+  const int want = (32 + p.mtw * p.L - 1) / (p.mtw * p.L);
+  if (strips < want) strips = want < p.nt ? want : p.nt;
+  p.W = (p.nt + strips - 1) / strips;
+  if (const char* e = getenv("GPZ_W_W")) { const int w = atoi(e); if (w >= 1) p.W = w < p.nt ? w : p.nt; }   // diagnostics
+  p.strips = (p.nt + p.W - 1) / p.W;
+  const int64_t units = (int64_t)p.mtw * p.L * p.strips;
+  const int64_t nblocks = (units + 7) / 8 * 8 * p.W;
+#define GPZ_W1(KIND, D) return launch_wide(gemmw_kernel<TM, TN, WB_GEN, WA_LOWER, WE_STORE_STATS, KIND, D>, \
+                                           WLds<TM, TN, WB_GEN, D>::bytes, p, nblocks, s)
+  if (a.kind == GPZ_KERNEL_MATERN32) { if (a.d == 2) GPZ_W1(1, 2); GPZ_W1(1, 1); }
+  if (a.d == 2) GPZ_W1(0, 2);
+  GPZ_W1(0, 1);
+#undef GPZ_W1
+}
+
+bool wide_product_supported(int64_t Mp, int64_t ncp) {
+  return Mp % 128 == 0 && ncp % 128 == 0 && Mp * Mp * 4 < (1ll << 31) && Mp * ncp * 4 < (1ll << 31);
+}
+
+int wide_product_launch(const WideArgs& a, hipStream_t s) {
+  GPZ_REQUIRE(wide_product_supported(a.Mp, a.ncp) && a.L > 0, "wide product: bad extents");
+  constexpr int TM = 256, TN = 128;
+  WParams p = {};
+  p.A = a.A; p.lda = a.Mp; p.sA0 = a.Mp * a.Mp;
+  p.B = a.B; p.ldb = a.ncp; p.sB0 = a.Mp * a.ncp;
+  p.C = a.C; p.ldc = a.ncp; p.sC0 = a.Mp * a.ncp;
+  p.mu = a.mu; p.sMu = a.Mp;
+  p.ps_sq = a.ps_sq; p.ps_mu = a.ps_mu; p.ncols = a.ncp; p.M = a.Mp;
+  p.L = a.L; p.nblk = (int)(a.Mp / 128); p.mtw = (int)((a.Mp + TM - 1) / TM); p.nt = (int)(a.ncp / TN);
+  // strips of (nearly) equal width, at most 16 column tiles: an XCD takes every 8th (latent, strip) unit
+  const int strips = (p.nt + 15) / 16;
+  p.W = (p.nt + strips - 1) / strips;
+  if (const char* e = getenv("GPZ_W_W")) { const int w = atoi(e); if (w >= 1) p.W = w < p.nt ? w : p.nt; }   // diagnostics
+  p.strips = (p.nt + p.W - 1) / p.W;
+  const int64_t units = (int64_t)p.L * p.strips;
+  const int64_t nblocks = (units + 7) / 8 * 8 * p.mtw * p.W;
+  constexpr size_t lds = WLds<TM, TN, WB_MEM, 1>::bytes;
+  if (a.upper) {
+    GPZ_REQUIRE(!a.store, "wide product: the upper-triangular product is statistics-only");
+    return launch_wide(gemmw_kernel<TM, TN, WB_MEM, WA_UPPER, WE_STATS, 0, 1>, lds, p, nblocks, s);
+  }
+  GPZ_REQUIRE(a.store && a.C && a.mu && a.ps_mu, "wide product: the lower-triangular product stores and needs mu");
+  return launch_wide(gemmw_kernel<TM, TN, WB_MEM, WA_LOWER, WE_STORE_STATS, 0, 1>, lds, p, nblocks, s);
+}
+
+}  // namespace gpz

@@ -16,6 +16,15 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Ownership rule for HIP objects (streams, events): the library creates none implicitly and keeps none in storage
+// with a destructor.  Streams always come from the caller.  The only HIP objects the library ever creates are the
+// profiling events below, created between gpz_profile_enable(1) and gpz_profile_enable(0) and destroyed by the
+// latter -- so a process that has switched profiling off holds nothing of ours when the HIP runtime and any
+// profiler tool layered on it tear down at exit.  (Round 2's experimental look-ahead Cholesky kept two extra
+// streams, one of them CU-masked, alive until process exit; under rocprofv3 that build died with SIGSEGV inside
+// __cxa_finalize after the tool's own finalisation -- the runtime destroying streams through an interception layer
+// that was already gone.  Any future multi-stream schedule gets an explicit create / destroy pair on a handle.)
+//
 // Profiling: per slot, a growing list of (start, stop) event pairs recorded on
 // the caller's stream; read back (and reset) by gpz_profile_read.
 struct ProfState {
@@ -66,8 +75,18 @@ extern "C" const char* gpz_source_hash(void) {
 extern "C" const char* gpz_last_error(void) { return gpz::g_err; }
 
 extern "C" int gpz_profile_enable(int32_t on) {
-  gpz::g_prof.on = on != 0;
-  for (int s = 0; s < gpz::PROF_NSLOTS; ++s) gpz::g_prof.used[s] = 0;
+  using namespace gpz;
+  g_prof.on = on != 0;
+  for (int s = 0; s < PROF_NSLOTS; ++s) {
+    g_prof.used[s] = 0;
+    if (!on) {       // switching off releases every event: nothing of ours outlives the caller's use of the profiler
+      for (int i = 0; i < g_prof.created[s]; ++i) {
+        (void)hipEventDestroy(g_prof.ev[s][i][0]);
+        (void)hipEventDestroy(g_prof.ev[s][i][1]);
+      }
+      g_prof.created[s] = 0;
+    }
+  }
   return 0;
 }
 

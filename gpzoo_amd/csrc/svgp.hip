@@ -16,7 +16,7 @@
 // N is processed in chunks so Kzx / Wt only ever exist one chunk at a time; P is
 // never stored.  All reductions are slab-based (no atomics): bitwise reproducible.
 #include "common.h"
-#include "fused1.h"
+#include "gemmw.h"
 #include "gemm.h"
 
 #include <algorithm>
@@ -488,17 +488,22 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
   // 3. chunks of columns
   const int64_t esz = sizeof(T);
   const WtCache<T> wtc = wt_cache_of<T>(pl, p->wt_cache);
-  const bool fused = !(p->flags & GPZ_SVGP_MATERIALIZE_KZX) && fused1_supported(p->dtype, p->k.kind, p->d);
+  const bool narrow = (p->flags & GPZ_SVGP_NARROW_TILES) != 0;
+  // the generated-operand stage 1 is built and selectable; the materialised fill + wide-tile product is the default
+  // because it is the faster one at the benchmark shape
+  const bool fused = !narrow && (p->flags & GPZ_SVGP_GENERATE_KZX) && !(p->flags & GPZ_SVGP_MATERIALIZE_KZX) &&
+                     fused1_supported(p->dtype, p->k.kind, p->d);
   for (int64_t ci = 0; ci < pl.nchunks; ++ci) {
     const int64_t n0 = ci * pl.nc;
     const int64_t nreal = (N - n0 < pl.nc) ? N - n0 : pl.nc;
     const int64_t ncp = pad_up(nreal);  // columns computed this chunk
     const int nt = (int)(ncp / NB);
     const ProductSchedule sched = product_schedule<T>(true, nt);
+    const bool wide = !narrow && pl.f32 && wide_product_supported(Mp, ncp);    // fp32: 256 x 128 tiles (gemmw.hip)
     T* const Wc = p->wt_cache ? wtc.wt(ci) : b.Wc;      // retained for the backward pass when asked for
     T* const ps1 = p->wt_cache ? wtc.ps1(ci) : b.ps1;
     if (fused) {
-      // Wt = Linv * k(Z, X) with the covariance generated inside the product: Kzx is never written (fused1.hip)
+      // Wt = Linv * k(Z, X) with the covariance generated inside the product: Kzx is never written (gemmw.hip)
       if constexpr (sizeof(T) == 4) {
         Fused1Args fa;
         fa.Linv = b.LinvG; fa.Mp = Mp; fa.Z = static_cast<const float*>(p->Z); fa.M = M;
@@ -510,29 +515,55 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
         prof_end(PROF_STAGE1, s);
       }
     } else {
-    prof_begin(PROF_KFILL, s);
-    if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
-                              p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
-                              pl.f32 ? GPZ_F32 : GPZ_F64, s, p->info))
-      return rc;
-    prof_end(PROF_KFILL, s);
-    GemmParams<T> g1;  // Wt = Linv * Kzx, with colsum(Wt^2) and muE^T Wt
-    g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
-    g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
-    g1.C = Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
-    g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
-    g1.super_cols = sched.cols; g1.tiles_per_wg = sched.tpw; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
-    prof_begin(PROF_STAGE1, s);
-    if (int rc = gemm_launch(g1, EPI_STORE_STATS, s)) return rc;
-    prof_end(PROF_STAGE1, s);
+      prof_begin(PROF_KFILL, s);
+      if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
+                                p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
+                                pl.f32 ? GPZ_F32 : GPZ_F64, s, p->info))
+        return rc;
+      prof_end(PROF_KFILL, s);
+      prof_begin(PROF_STAGE1, s);
+      bool done = false;
+      if constexpr (sizeof(T) == 4) {
+        if (wide) {      // Wt = Linv * Kzx on the 256 x 128 tile, with colsum(Wt^2) and muE^T Wt
+          WideArgs wa = {};
+          wa.A = b.LinvG; wa.B = b.Kc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 0; wa.store = 1;
+          wa.C = Wc; wa.mu = b.muE; wa.ps_sq = ps1; wa.ps_mu = b.pm1;
+          if (int rc = wide_product_launch(wa, s)) return rc;
+          done = true;
+        }
+      }
+      if (!done) {
+        GemmParams<T> g1;  // Wt = Linv * Kzx, with colsum(Wt^2) and muE^T Wt
+        g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
+        g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
+        g1.C = Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
+        g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
+        g1.super_cols = sched.cols; g1.tiles_per_wg = sched.tpw; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
+        if (int rc = gemm_launch(g1, EPI_STORE_STATS, s)) return rc;
+      }
+      prof_end(PROF_STAGE1, s);
     }
-    GemmParams<T> g2;  // colsum((LuE^T Wt)^2)
-    g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
-    g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
-    g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-    g2.super_cols = sched.cols; g2.tiles_per_wg = sched.tpw; g2.ps_sq = b.ps2; g2.ncols = ncp;
     prof_begin(PROF_STAGE2, s);
-    if (int rc = gemm_launch(g2, EPI_STATS, s)) return rc;
+    {
+      bool done = false;
+      if constexpr (sizeof(T) == 4) {
+        if (wide) {      // colsum((LuE^T Wt)^2) on the 256 x 128 tile
+          WideArgs wa = {};
+          wa.A = b.LuT; wa.B = Wc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 1; wa.store = 0;
+          wa.ps_sq = b.ps2;
+          if (int rc = wide_product_launch(wa, s)) return rc;
+          done = true;
+        }
+      }
+      if (!done) {
+        GemmParams<T> g2;  // colsum((LuE^T Wt)^2)
+        g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+        g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+        g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+        g2.super_cols = sched.cols; g2.tiles_per_wg = sched.tpw; g2.ps_sq = b.ps2; g2.ncols = ncp;
+        if (int rc = gemm_launch(g2, EPI_STATS, s)) return rc;
+      }
+    }
     prof_end(PROF_STAGE2, s);
     FinalizeArgs<T> f;
     f.ps1 = ps1; f.pm1 = b.pm1; f.ps2 = b.ps2; f.sigma = static_cast<const T*>(p->k.sigma);

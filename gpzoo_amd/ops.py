@@ -377,13 +377,15 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
                  y=None, noise_sd: Optional[float] = None, clamp_min: float = 1e-6, chunk: int = 0,
                  want_moments: bool = True, want_Lu: bool = True, want_chol: bool = False,
                  check_info: bool = True, cache: Optional[FactorCache] = None,
-                 retain_wt: float = 0.0, materialize_kzx: bool = False) -> dict:
+                 retain_wt: float = 0.0, materialize_kzx: Optional[bool] = None, narrow_tiles: bool = False) -> dict:
     """One fused forward pass (gpz_svgp_forward).  Returns a dict with mean, scale
     (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars.
     ``retain_wt`` > 0: keep Wt of every chunk for ``svgp_backward(wt_cache=out["wt_cache"])`` when it fits
     in that fraction of the free device memory (288 GB HBM: 52 GB at N=200k, M=2048, L=32, fp32).
-    ``materialize_kzx``: write every Kzx chunk to HBM and run the plain triangular product on it (the reference's
-    structure) instead of the product that generates its covariance operand in registers; same bits either way."""
+    ``materialize_kzx``: True = write every Kzx chunk to HBM and run the triangular product on it (the reference's
+    structure), False = the product that generates its covariance operand itself (fp32 RBF / Matern-3/2, d <= 2), None =
+    the library's choice; ``narrow_tiles``: the 128 x 128-tile kernel of the other precisions for the two big fp32
+    products.  Same Wt bits on every path."""
     _need_cuda(X, Z, mu, Lu_raw)
     if X.dim() == 2 and X.shape[0] == 0 and Z.dim() == 2 and Z.shape[0] > 0:
         # No data points: q(F) is empty and the ELBO is -sum(KL), as the reference's torch code gives for an (0,d) X.
@@ -401,8 +403,10 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     keep: list = []
     p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
     out = {}
-    if materialize_kzx:
-        p.flags |= _lib.SVGP_MATERIALIZE_KZX
+    if materialize_kzx is not None:
+        p.flags |= _lib.SVGP_MATERIALIZE_KZX if materialize_kzx else _lib.SVGP_GENERATE_KZX
+    if narrow_tiles:
+        p.flags |= _lib.SVGP_NARROW_TILES
     if y is not None:
         y = y.detach().to(dt).reshape(L, N).contiguous()
         p.y, p.noise_sd = y.data_ptr(), float(noise_sd)

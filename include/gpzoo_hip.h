@@ -120,11 +120,14 @@ int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_l, void* B,
  * dtype = storage/GEMM type of X, Z, mu, Lu_raw, y, mean, scale (k.dtype must
  * match).  Kzz, its Cholesky factor and inverse are carried in fp64 in both modes.
  */
-/* gpz_svgp_problem.flags */
-#define GPZ_SVGP_MATERIALIZE_KZX 1  /* forward: write every Kzx chunk to HBM with the stand-alone fill and run the plain
-                                     * triangular product on it (what the reference does, gp.py:255 + :276) instead of
-                                     * generating the covariance operand inside the product (fp32 RBF / Matern-3/2, d <= 2
-                                     * take the fused kernel by default; the two paths agree bit for bit) */
+/* gpz_svgp_problem.flags: which kernels the forward pass takes for its two big fp32 products (results agree bit for
+ * bit in Wt on every path; 0 = the library's choice, currently the faster of the first two at the benchmark shape) */
+#define GPZ_SVGP_MATERIALIZE_KZX 1  /* write every Kzx chunk to HBM with the stand-alone fill and run the triangular
+                                     * product on it -- the reference's structure, gp.py:255 + :276 */
+#define GPZ_SVGP_NARROW_TILES 2     /* the 128 x 128-tile kernel every other precision uses (csrc/gemm.hip) instead of
+                                     * the wide-tile one (csrc/gemmw.hip); implies a materialised Kzx */
+#define GPZ_SVGP_GENERATE_KZX 4     /* fp32 RBF / Matern-3/2, d <= 2: stage 1 generates its covariance operand inside the
+                                     * product (csrc/gemmw.hip) and Kzx is never written */
 
 typedef struct gpz_svgp_problem {
   gpz_kernel_desc k;
@@ -275,7 +278,9 @@ int gpz_allreduce_sum_f64(void* comm, double* buf, int64_t n, void* stream);
 int gpz_comm_destroy(void* comm);
 
 /* Timing hooks used by bench.py: HIP events recorded on `stream` around the
- * dominant kernels of the last gpz_svgp_forward call (roofline.achieved). */
+ * dominant kernels of the last gpz_svgp_forward call (roofline.achieved).  These events are the only HIP objects
+ * the library ever creates (streams always come from the caller): gpz_profile_enable(1) starts recording,
+ * gpz_profile_enable(0) stops and DESTROYS every event, so nothing of the library's outlives it at process exit. */
 int gpz_profile_enable(int32_t on);
 int gpz_profile_read(double* ms_out, int32_t* counts_out, int32_t n_slots); /* host arrays */
 

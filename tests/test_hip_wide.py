@@ -1,0 +1,91 @@
+"""GPU: the three ways the forward pass can run its two big fp32 products give the same numbers.
+
+  narrow + kfill   kfill_kernel, then gemm128_kernel for both products (the path of round 2 and of every other precision)
+  wide + kfill     kfill_kernel, then gemmw_kernel<256,128,mem> for both products (the default)
+  generated        gemmw_kernel<512,64,gen>: stage 1 computes its covariance operand itself, Kzx is never written
+
+cov.h is shared by the fill and the generator and all three kernels give lane group q the k = 4q..4q+3 slots of a
+16-deep chunk, so Wt must agree BIT FOR BIT; the column statistics are summed in different orders, so mean / scale /
+ELBO agree to fp32 rounding.  Against the oracle: the usual north_star tolerances (helpers.rtol_for)."""
+import pytest
+import torch
+
+from helpers import rtol_for
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # cfg, N, M, L, d
+    (3, 12288, 2048, 2, 2),      # one config-3 chunk: 16 blocks, 8 / 4 row tiles
+    (3, 5000, 2048, 1, 2),       # ragged last column tile
+    (3, 3000, 3000, 2, 2),       # Mp = 3072, padded rows
+    (3, 2000, 384, 3, 2),        # 3 blocks: partial last row tile of both tile heights
+    (3, 1500, 640, 2, 2),        # 5 blocks
+    (3, 777, 100, 2, 2),         # a single block
+    (2, 20000, 512, 8, 2),       # config 2's kernel (RBF), one 512-row tile
+    (2, 4000, 640, 3, 1),        # 1-D inputs
+    (3, 4000, 640, 3, 1),
+]
+
+
+def _problem(cfg, N, M, L, d):
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(cfg, N=N, M=M, L=L)
+    if d == 1:
+        c["X"], c["Z"] = c["X"][:, :1].contiguous(), c["Z"][:, :1].contiguous()
+    g = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
+    spec, extra = spec_for_config(g, torch.device("cuda", 0))
+    return c, g, spec, extra
+
+
+def _run(c, g, spec, extra, **kw):
+    from gpzoo_amd import ops
+    return ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
+                            noise_sd=c["noise_sd"], want_Lu=False, retain_wt=0.9, **extra, **kw)
+
+
+@pytest.mark.parametrize("cfg,N,M,L,d", SHAPES)
+def test_three_paths_agree_bitwise_in_wt(cfg, N, M, L, d):
+    c, g, spec, extra = _problem(cfg, N, M, L, d)
+    Mp, ncp = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    nwt = L * Mp * ncp
+    ref = _run(c, g, spec, extra, materialize_kzx=True, narrow_tiles=True)
+    wref = ref["wt_cache"].view(torch.int32)[:nwt]
+    assert int(wref.count_nonzero()) > nwt // 4            # the comparison below is not between two empty buffers
+    for kw in (dict(), dict(materialize_kzx=True), dict(materialize_kzx=False)):
+        out = _run(c, g, spec, extra, **kw)
+        assert torch.equal(out["wt_cache"].view(torch.int32)[:nwt], wref), kw
+        torch.testing.assert_close(out["mean"], ref["mean"], rtol=1e-5, atol=1e-5 * float(ref["mean"].abs().max()))
+        torch.testing.assert_close(out["scale"], ref["scale"], rtol=1e-5, atol=0)      # strictly positive: pure rtol
+        assert float(out["elbo"]) == pytest.approx(float(ref["elbo"]), rel=1e-7)
+        assert torch.equal(out["kl"], ref["kl"])
+
+
+@pytest.mark.parametrize("materialize", [None, True, False])
+def test_each_path_against_the_oracle(materialize):
+    """N=3000, M=300, L=3 Matern-3/2 fp32 (a partial 512-row tile, padded rows and columns) against the CPU oracle."""
+    from oracle import svgp_oracle as O
+    c, g, spec, extra = _problem(3, 3000, 300, 3, 2)
+    out = _run(c, g, spec, extra, materialize_kzx=materialize)
+    e, mean, scale = O.elbo_eval(c["kind"], c["whitened"], c["X"], c["y"], c["Z"], c["sigma"], c["lengthscale"], c["mu"],
+                                 c["Lu_raw"], c["jitter"], c["noise_sd"])
+    rt = rtol_for(torch.float32)
+    torch.testing.assert_close(out["mean"].cpu(), mean, rtol=rt, atol=rt * float(mean.abs().max()))
+    torch.testing.assert_close(out["scale"].cpu(), scale, rtol=rt, atol=0)
+    assert float(out["elbo"]) == pytest.approx(float(e), rel=rt)
+
+
+def test_generated_operand_does_not_read_the_kzx_buffer():
+    """The generated path must not depend on what the workspace (where the materialised paths keep their Kzx chunk)
+    holds: poison it with NaN bit patterns, evaluate, and compare with the materialised path bit for bit."""
+    from gpzoo_amd import ops
+    c, g, spec, extra = _problem(3, 6000, 1024, 2, 2)
+    a = _run(c, g, spec, extra, materialize_kzx=True)
+    assert ops._workspaces
+    for t in ops._workspaces.values():
+        t.fill_(0xFF)
+    b = _run(c, g, spec, extra, materialize_kzx=False)
+    nwt = 2 * 1024 * 6016
+    assert torch.equal(a["wt_cache"].view(torch.int32)[:nwt], b["wt_cache"].view(torch.int32)[:nwt])
+    assert torch.isfinite(b["mean"]).all() and torch.isfinite(b["scale"]).all()

@@ -1,15 +1,15 @@
 #!/bin/bash
-# Build timing variants of the fused stage-1 kernel (csrc/fused1.hip) as gpzoo_amd/libgpzoo_hip_<tag>.so; select one with
-# GPZ_HIP_LIB=<path>.   Usage: tools/ablate_fused.sh tag1:"-DGPZ_F1_ABL=1" tag2:"-DGPZ_F1_WPE=2" ...
-# -DGPZ_F1_ABL builds give WRONG results by construction: they only tell what the MFMA pipes wait for.
+# Build timing variants of the fused stage-1 kernel (csrc/gemmw.hip) as gpzoo_amd/libgpzoo_hip_<tag>.so; select one with
+# GPZ_HIP_LIB=<path>.   Usage: tools/ablate_fused.sh tag1:"-DGPZ_W_ABL=1" tag2:"-DGPZ_F1_WPE=2" ...
+# -DGPZ_W_ABL builds give WRONG results by construction: they only tell what the MFMA pipes wait for.
 set -e
 cd "$(dirname "$0")/.."
 python3 -m gpzoo_amd.build > /dev/null
 C=gpzoo_amd/csrc
 for spec in "$@"; do
   tag=${spec%%:*}; flags=${spec#*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast $flags -c $C/fused1.hip -o /tmp/fused1_$tag.o
-  objs=$(ls $C/*.o | grep -v "/fused1.o")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpzoo_amd/libgpzoo_hip_$tag.so $objs /tmp/fused1_$tag.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast $flags -c $C/gemmw.hip -o /tmp/gemmw_$tag.o
+  objs=$(ls $C/*.o | grep -v "/gemmw.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpzoo_amd/libgpzoo_hip_$tag.so $objs /tmp/gemmw_$tag.o -ldl
   echo built gpzoo_amd/libgpzoo_hip_$tag.so
 done

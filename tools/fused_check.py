@@ -22,10 +22,10 @@ from gpzoo_amd.synthetic import make_config  # noqa: E402
 dev = torch.device("cuda", 0)
 
 
-def run(c, g, spec, extra, materialize, retain=True, chunk=0):
+def run(c, g, spec, extra, materialize, retain=True, chunk=0, narrow=False):
     return ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
                             noise_sd=c["noise_sd"], chunk=chunk, want_Lu=False, retain_wt=0.9 if retain else 0.0,
-                            materialize_kzx=materialize, **extra)
+                            materialize_kzx=materialize, narrow_tiles=narrow, **extra)
 
 
 def case(cfg, N, M, L, d=None, tag=""):
@@ -35,21 +35,25 @@ def case(cfg, N, M, L, d=None, tag=""):
         c["Z"] = c["Z"][:, :1].contiguous()
     g = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
     spec, extra = spec_for_config(g, dev)
-    a = run(c, g, spec, extra, True)
-    b = run(c, g, spec, extra, False)
+    a = run(c, g, spec, extra, True, narrow=True)      # kfill + 128 x 128-tile GEMMs: the round-2 path
     Mp = (M + 127) // 128 * 128
     ncp = (N + 127) // 128 * 128
     nwt = L * Mp * ncp
     wa = a["wt_cache"].view(torch.float32)[:nwt]
-    wb = b["wt_cache"].view(torch.float32)[:nwt]
-    same = bool(torch.equal(wa.view(torch.int32), wb.view(torch.int32)))
-    nbad = int((wa.view(torch.int32) != wb.view(torch.int32)).sum())
-    dm = float((a["mean"] - b["mean"]).abs().max())
-    ds = float(((a["scale"] - b["scale"]).abs() / a["scale"]).max())
-    de = abs(float(a["elbo"]) - float(b["elbo"])) / abs(float(a["elbo"]))
-    ok = same and dm < 1e-4 and ds < 1e-4 and de < 1e-6
-    print("%-28s cfg %d N=%6d M=%5d L=%3d d=%s  Wt bitwise %s (%d differ)  |dmean| %.2e  rel dscale %.2e  rel dELBO %.2e  %s"
-          % (tag, cfg, N, M, L, d or 2, same, nbad, dm, ds, de, "OK" if ok else "FAIL"), flush=True)
+    ok = True
+    for name, mat in (("wide+kfill", True), ("generated", False)):
+        b = run(c, g, spec, extra, mat)
+        wb = b["wt_cache"].view(torch.float32)[:nwt]
+        same = bool(torch.equal(wa.view(torch.int32), wb.view(torch.int32)))
+        nbad = int((wa.view(torch.int32) != wb.view(torch.int32)).sum())
+        dm = float((a["mean"] - b["mean"]).abs().max())
+        ds = float(((a["scale"] - b["scale"]).abs() / a["scale"]).max())
+        de = abs(float(a["elbo"]) - float(b["elbo"])) / abs(float(a["elbo"]))
+        good = same and dm < 1e-4 and ds < 1e-4 and de < 1e-6
+        ok = ok and good
+        print("%-26s %-10s cfg %d N=%6d M=%5d L=%3d d=%s  Wt bitwise %s (%d differ)  |dmean| %.2e  rel dscale %.2e  rel dELBO %.2e  %s"
+              % (tag, name, cfg, N, M, L, d or 2, same, nbad, dm, ds, de, "OK" if good else "FAIL"), flush=True)
+        del b, wb
     return ok
 
 
@@ -57,13 +61,15 @@ def timing(steps=3):
     c = make_config(3)
     g = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
     spec, extra = spec_for_config(g, dev)
-    for mat in ((False,) if "--time-only" in sys.argv else (True, False)):
-        run(c, g, spec, extra, mat, retain=False)
+    modes = (("generated", False, False),) if "--time-only" in sys.argv else \
+        (("narrow+kfill", True, True), ("wide+kfill", True, False), ("generated", False, False))
+    for name, mat, narrow in modes:
+        run(c, g, spec, extra, mat, retain=False, narrow=narrow)
         torch.cuda.synchronize()
         ops.profile_enable(True)
         t0 = time.perf_counter()
         for _ in range(steps):
-            o = run(c, g, spec, extra, mat, retain=False)
+            o = run(c, g, spec, extra, mat, retain=False, narrow=narrow)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         prof = ops.profile_read()
@@ -71,7 +77,7 @@ def timing(steps=3):
         fl = 32 * 2048.0 * 2048 * 200000
         ms1, ms2, msk = prof["stage1"][0] / steps, prof["stage2"][0] / steps, prof["kfill"][0] / steps
         print("config 3 %-12s %.1f ms/eval | stage1 %.2f ms = %.1f TF (%.3f of 157.3) | stage2 %.2f ms = %.1f TF | kfill %.2f ms | elbo %.10g"
-              % ("materialized" if mat else "fused", dt * 1e3, ms1, fl / ms1 / 1e9, fl / ms1 / 1e9 / 157.3, ms2,
+              % (name, dt * 1e3, ms1, fl / ms1 / 1e9, fl / ms1 / 1e9 / 157.3, ms2,
                  fl / ms2 / 1e9, msk, float(o["elbo"])), flush=True)
 
 
@@ -82,6 +88,8 @@ if __name__ == "__main__":
         ok &= case(3, 5000, 2048, 2, tag="ragged columns")
         ok &= case(3, 3000, 3000, 2, tag="M=3000 (Mp=3072)")
         ok &= case(3, 2000, 384, 3, tag="odd block count (Mp=384)")
+        ok &= case(3, 1500, 640, 2, tag="Mp=640 (5 blocks)")
+        ok &= case(3, 1500, 900, 2, tag="Mp=1024, padded rows")
         ok &= case(3, 777, 100, 2, tag="one block (Mp=128)")
         ok &= case(3, 1000, 250, 2, tag="Mp=256, padded rows")
         ok &= case(2, 50000, 512, 8, tag="config 2 (RBF)")

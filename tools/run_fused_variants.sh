@@ -6,5 +6,5 @@ for spec in base "$@"; do
   if [ "$spec" != "$tag" ]; then envs=${spec#*:}; fi
   if [ $tag = base ]; then lib=""; else lib="$PWD/gpzoo_amd/libgpzoo_hip_$tag.so"; fi
   echo "== $spec"
-  env GPZ_HIP_LIB=$lib $envs python3 tools/fused_check.py --time-only 2>/dev/null | grep fused
+  env GPZ_HIP_LIB=$lib $envs python3 tools/fused_check.py --time-only 2>/dev/null | grep "config 3"
 done
