@@ -82,10 +82,49 @@ def parse():
     ap.add_argument("--Ltotal", type=int, default=256, help="strong scaling: latents of the whole model (configs[3]: 256)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="spots in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="spots in the CPU-baseline sample (SURVEY §8d: 8192)")
     ap.add_argument("--with-backward", action="store_true",
                     help="also time one forward + backward (mu, Lu gradients) pass, outside the timed region")
     return ap.parse_args()
+
+
+def usable_cpus() -> tuple:
+    """(threads to use, CPU model string): the cores this process may run on -- its affinity mask, cut down to the
+    cgroup's CPU quota (cpu.max) and to the PHYSICAL cores among them (one thread per core: torch's CPU kernels gain
+    nothing from SMT siblings and lose to oversubscription)."""
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = list(range(os.cpu_count() or 1))
+    n = len(aff)
+    model, phys, cur = "unknown CPU", set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur.get("processor") in aff:
+                    phys.add((cur.get("physical id", 0), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = (t.strip() for t in line.split(":", 1))
+            if k == "model name":
+                model = v
+            if k in ("processor", "physical id", "core id"):
+                cur[k] = int(v)
+        if phys:
+            n = min(n, len(phys))
+    except OSError:
+        pass
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(f).read().split()
+            quota = float(t[0]) if t[0] != "max" else -1.0
+            period = float(t[1]) if len(t) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = max(1, min(n, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n), model
 
 
 def cpu_baseline(cfg_id: int, c: dict, sample: int) -> dict:
@@ -94,10 +133,7 @@ def cpu_baseline(cfg_id: int, c: dict, sample: int) -> dict:
     the reference's own minibatch usage (utilities.py:605-609)."""
     from oracle import svgp_oracle as O
     n = min(sample, c["X"].shape[0])
-    try:
-        threads = len(os.sched_getaffinity(0))          # the cores this process may actually run on
-    except AttributeError:
-        threads = os.cpu_count() or 1
+    threads, cpu_model = usable_cpus()
     torch.set_num_threads(threads)
     kw = {}
     if "gX" in c:
@@ -110,6 +146,19 @@ def cpu_baseline(cfg_id: int, c: dict, sample: int) -> dict:
     O.add_jitter_(Kzz, c["jitter"])
     torch.linalg.cholesky(Kzz)
     t_chol = time.perf_counter() - t0
+    # a short pilot decides whether the planned sample (8192 spots) fits the bench's time budget on this
+    # host; if not, the sample is halved until it does and the JSON says which size ran
+    pilot_n = min(512, n)
+    pk = dict(kw, gX=kw["gX"][:pilot_n]) if "gX" in kw else kw
+    t0 = time.perf_counter()
+    O.elbo_eval(c["kind"], c["whitened"], c["X"][:pilot_n], c["y"][..., :pilot_n], c["Z"], c["sigma"], c["lengthscale"],
+                c["mu"], c["Lu_raw"], c["jitter"], c["noise_sd"], **pk)
+    per_spot = max(time.perf_counter() - t0 - t_chol, 1e-9) / pilot_n
+    planned = n
+    while n > 1024 and t_chol + per_spot * n > 60.0:
+        n //= 2
+    if "gX" in kw:
+        kw["gX"] = kw["gX"][:n]
     t0 = time.perf_counter()
     e, _, _ = O.elbo_eval(c["kind"], c["whitened"], c["X"][:n], c["y"][..., :n], c["Z"], c["sigma"], c["lengthscale"],
                           c["mu"], c["Lu_raw"], c["jitter"], c["noise_sd"], **kw)
@@ -117,12 +166,13 @@ def cpu_baseline(cfg_id: int, c: dict, sample: int) -> dict:
     N = c["X"].shape[0]
     t_chunk = max(t_eval - t_chol, 1e-9)
     full = t_chol + math.ceil(N / n) * t_chunk
-    return {"value": 1.0 / full, "unit": "ELBO evals/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/svgp_oracle.py (torch CPU, {threads} threads) on the first {n} of {N} spots, all "
+    return {"value": 1.0 / full, "unit": "ELBO evals/s", "cores": threads, "cpu_model": cpu_model, "kind": "port",
+            "sample": f"oracle/svgp_oracle.py (torch CPU, {threads} threads on {cpu_model}) on the first {n} of {N} spots, all "
                       f"{c['mu'].shape[0] if c['mu'].dim() > 1 else 1} latents, M={c['Z'].shape[0]}: {t_eval:.2f} s per "
                       f"chunk-eval incl. {t_chol:.2f} s Kzz+Cholesky; extrapolated to full N as "
-                      f"1/(t_chol + ceil(N/n) * t_chunk)",
-            "sample_elbo": float(e)}
+                      f"1/(t_chol + ceil(N/n) * t_chunk)" +
+                      (f"; {planned} spots were planned, a {pilot_n}-spot pilot predicted more than 60 s for them" if n != planned else ""),
+            "sample_spots": n, "sample_elbo": float(e)}
 
 
 class ClockSampler:
@@ -418,7 +468,7 @@ def main():
             cb = cpu_baseline(cfg_id, c, a.cpu_sample)
             # parity on the driver-run line: the HIP path on the very slice the CPU port just evaluated
             # (outside the timed region), same dtype, all latents and inducing points
-            n = min(a.cpu_sample, N)
+            n = cb["sample_spots"]
             ex = {k: (v[:n] if k == "gX" else v) for k, v in extra.items()}
             o = ops.svgp_forward(spec, g["X"][:n], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
                                  y=g["y"][..., :n].contiguous(), noise_sd=c["noise_sd"], want_Lu=False, **ex)

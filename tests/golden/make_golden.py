@@ -38,29 +38,8 @@ def inv_softplus(v):
     return float(np.log(np.expm1(v)))
 
 
-def gen(seed, *shape, dist="randn"):
-    g = torch.Generator().manual_seed(seed)
-    f = torch.randn if dist == "randn" else torch.rand
-    return f(*shape, generator=g, dtype=torch.float64)
-
-
-def make_inputs(seed, N, M, d, L, n_groups=0, span=10.0):
-    X = (gen(seed, N, d, dist="rand") - 0.5) * 2 * span
-    perm = torch.randperm(N, generator=torch.Generator().manual_seed(seed + 1))
-    Z = X[perm[:M]].clone() + 0.05 * gen(seed + 2, M, d)
-    shape_mu = (L, M) if L else (M,)
-    shape_Lu = (L, M, M) if L else (M, M)
-    mu = 0.5 * gen(seed + 3, *shape_mu)
-    Lu = 0.05 * gen(seed + 4, *shape_Lu)
-    Lu = Lu + torch.diag_embed(-0.3 + 0.1 * gen(seed + 5, *shape_mu)) - torch.diag_embed(torch.diagonal(Lu, dim1=-2, dim2=-1))
-    shape_y = (L, N) if L else (N,)
-    y = torch.sin(X[:, 0] / 3.0).expand(shape_y) + 0.1 * gen(seed + 6, *shape_y)
-    out = dict(X=X, Z=Z, mu=mu, Lu_raw=Lu, y=y)
-    if n_groups:
-        g = torch.Generator().manual_seed(seed + 7)
-        out["gX"] = torch.randint(0, n_groups, (N,), generator=g)
-        out["gZ"] = torch.randint(0, n_groups, (M,), generator=g)
-    return out
+sys.path.insert(0, HERE)
+from inputs import gen, make_inputs  # noqa: E402  (shared with the tests, which regenerate the larger cases' inputs)
 
 
 def run_case(name, gp_cls, kern, inp, dtype, jitter, noise_sd, whitened, mggp):
@@ -654,3 +633,29 @@ if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "ker
 
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "vnngp_scale"):
     vnngp_scale_case()
+
+
+def multiblock_cases():
+    """The reference itself beyond one 128-block: M = 300 (three blocks: panel solves, a trailing update, one level of the
+    triangular inverse, partial wide tiles), N = 2000, L = 3.  The inputs are regenerated from their seed by the tests
+    (tests/golden/inputs.py); stored are (L,N) / (L,M) outputs and scalars only (~100 KB per case)."""
+    for name, gpc, kind, whitened in (("wsvgp_matern32", "WSVGP", "matern32", True), ("svgp_nsf_rbf", "SVGP", "nsf_rbf", False)):
+        for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            meta = dict(seed=4242, N=2000, M=300, d=2, L=3, span=25.0)
+            inp = make_inputs(meta["seed"], N=meta["N"], M=meta["M"], d=meta["d"], L=meta["L"], span=meta["span"])
+            kern = build_kernel(kind, meta["L"])
+            out = run_case(name, getattr(rgp, gpc), kern, inp, dtype, 1e-2, 0.5, whitened, False)
+            keep = {k: out[k] for k in ("mean", "scale", "kl", "elbo", "grad_mu", "sigma", "lengthscale", "jitter", "noise_sd")}
+            keep["chol_diag"] = np.diagonal(out["chol"], axis1=-2, axis2=-1).copy()
+            keep["chol_rowsum"] = out["chol"].sum(-1)
+            keep["grad_Lu_rowsum"] = out["grad_Lu"].sum(-1)
+            keep["grad_Lu_diag"] = np.diagonal(out["grad_Lu"], axis1=-2, axis2=-1).copy()
+            keep["grad_Lu_absmax"] = np.float64(np.abs(out["grad_Lu"]).max())
+            keep.update({k: np.float64(v) if isinstance(v, float) else np.int64(v) for k, v in meta.items()})
+            keep["kind"] = np.array(kind); keep["whitened"] = np.array(whitened)
+            np.savez_compressed(os.path.join(HERE, f"multiblock_{name}_{tag}.npz"), **keep)
+            print(f"multiblock_{name}_{tag}: elbo={float(out['elbo']):.10f}")
+
+
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "multiblock"):
+    multiblock_cases()

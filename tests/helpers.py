@@ -59,3 +59,24 @@ def spec_from_case(c, device):
     else:
         ga, pw = a.abs(), c["X"].shape[1] / 2
     return KernelSpec(_lib.KERNEL_MGGP_RBF, sig.reshape(-1), ell.reshape(-1), batched, ga, r2, pw)
+
+
+MULTIBLOCK = ("multiblock_wsvgp_matern32_f64", "multiblock_wsvgp_matern32_f32", "multiblock_svgp_nsf_rbf_f64",
+              "multiblock_svgp_nsf_rbf_f32")
+
+
+def load_multiblock(name):
+    """A reference-generated fixture beyond one 128-block (M = 300, N = 2000, L = 3): outputs and scalars come from the
+    file, the inputs are regenerated from the stored seed exactly as tests/golden/make_golden.py drew them."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from inputs import make_inputs
+    c = load_case(name)
+    meta = {k: int(c.pop(k)) for k in ("seed", "N", "M", "d", "L")}
+    span = float(c.pop("span"))
+    dt = torch.float64 if name.endswith("f64") else torch.float32
+    inp = make_inputs(meta["seed"], N=meta["N"], M=meta["M"], d=meta["d"], L=meta["L"], span=span)
+    c.update({k: (v.to(dt) if v.is_floating_point() else v) for k, v in inp.items()})
+    if c["kind"] == "nsf_rbf":     # NSF_RBF keeps (L,1,1) parameters
+        c["sigma"], c["lengthscale"] = c["sigma"].reshape(-1, 1, 1), c["lengthscale"].reshape(-1, 1, 1)
+    return c

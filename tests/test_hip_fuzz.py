@@ -96,8 +96,10 @@ def test_random_case(seed):
 
     rt = 1e-5 if c["f64"] else 1e-3
     tag = {k: c[k] for k in ("kind", "N", "M", "L", "d", "f64", "whitened", "jitter")}
+    # scale and kl are strictly positive: PURE rtol (atol = 0); everything that changes sign is norm-wise (rt * max|.|)
     close = lambda a, b, what: torch.testing.assert_close(  # noqa: E731
-        a.double().cpu().reshape(b.shape), b.detach(), rtol=rt, atol=rt * max(float(b.detach().abs().max()), 1e-30),
+        a.double().cpu().reshape(b.shape), b.detach(), rtol=rt,
+        atol=0.0 if what in ("scale", "kl") else rt * max(float(b.detach().abs().max()), 1e-30),
         msg=lambda m: f"{what} {tag}: {m}")
     close(out["mean"], mean, "mean")
     close(out["scale"], scale, "scale")

@@ -58,3 +58,39 @@ def test_forward_and_elbo(name):
     torch.testing.assert_close(out["chol"].cpu().reshape(c["chol"].shape), c["chol"], rtol=rt, atol=rt * 1e-2)
     torch.testing.assert_close(out["kl"].cpu().to(dt).reshape(c["kl"].shape), c["kl"], rtol=rt, atol=rt * 1e-2)
     assert float(out["elbo"]) == pytest.approx(c["elbo"], rel=rt)
+
+
+@pytest.mark.parametrize("name", __import__("helpers").MULTIBLOCK)
+def test_reference_beyond_one_block(name):
+    """The reference itself at M = 300 (three 128-blocks: panel solves, a trailing update, a triangular-inverse level,
+    partial wide tiles), N = 2000, L = 3 -- forward moments, KL, ELBO, the factor's diagonal (pure rtol: strictly
+    positive quantities) and the reference's autograd gradients of -ELBO w.r.t. mu and Lu."""
+    from gpzoo.utilities import whitened_KL_batched
+    from helpers import load_multiblock, rtol_for
+    from test_hip_api import build
+    c = load_multiblock(name)
+    rt = rtol_for(c["X"].dtype)
+    model = build(name[len("multiblock_"):], c)
+    gp = model.gp
+    for t in [gp.Z, *gp.kernel.parameters()]:
+        t.requires_grad_(False)
+    X, y = c["X"].cuda(), c["y"].cuda()
+    pY, qF, qU, pU = model(X=X, E=1)
+    torch.testing.assert_close(qF.mean.detach().cpu(), c["mean"], rtol=rt, atol=rt * float(c["mean"].abs().max()))
+    torch.testing.assert_close(qF.scale.detach().cpu(), c["scale"], rtol=rt, atol=0)
+    s = torch.nn.functional.softplus(model.noise)
+    if c["whitened"]:
+        kl = whitened_KL_batched(qU.mean, qU.scale_tril)
+    else:
+        kl = torch.distributions.kl_divergence(qU, pU)
+        chol = pU.scale_tril.detach().cpu()
+        torch.testing.assert_close(torch.diagonal(chol, dim1=-2, dim2=-1), c["chol_diag"], rtol=rt, atol=0)
+        torch.testing.assert_close(chol.sum(-1), c["chol_rowsum"], rtol=rt, atol=rt * float(c["chol_rowsum"].abs().max()))
+    torch.testing.assert_close(kl.detach().cpu().reshape(c["kl"].shape), c["kl"], rtol=rt, atol=0)
+    loss = -(pY.log_prob(y).sum() - (qF.scale ** 2).sum() / (2 * s ** 2) - kl.sum())
+    assert float(loss.detach()) == pytest.approx(-c["elbo"], rel=rt)
+    loss.backward()
+    torch.testing.assert_close(gp.mu.grad.cpu(), c["grad_mu"], rtol=rt, atol=rt * float(c["grad_mu"].abs().max()))
+    torch.testing.assert_close(gp.Lu.grad.cpu().sum(-1), c["grad_Lu_rowsum"], rtol=rt, atol=rt * float(c["grad_Lu_absmax"]) * 10)
+    torch.testing.assert_close(torch.diagonal(gp.Lu.grad.cpu(), dim1=-2, dim2=-1), c["grad_Lu_diag"], rtol=rt,
+                               atol=rt * float(c["grad_Lu_absmax"]))

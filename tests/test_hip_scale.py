@@ -37,8 +37,9 @@ def check(c, rt, chunk=0):
     ref, mean, scale = oracle_eval(c)
     L = 1 if c["mu"].dim() == 1 else c["mu"].shape[0]
     assert float(out["elbo"]) == pytest.approx(float(ref), rel=rt)
-    torch.testing.assert_close(out["mean"].double().cpu().reshape(mean.shape), mean, rtol=rt, atol=rt)
-    torch.testing.assert_close(out["scale"].double().cpu().reshape(scale.shape), scale, rtol=rt, atol=rt)
+    # the mean changes sign, so its tolerance is norm-wise (rt * max|mean|); scale is strictly positive: PURE rtol
+    torch.testing.assert_close(out["mean"].double().cpu().reshape(mean.shape), mean, rtol=rt, atol=rt * float(mean.abs().max()))
+    torch.testing.assert_close(out["scale"].double().cpu().reshape(scale.shape), scale, rtol=rt, atol=0)
     return out
 
 

@@ -44,6 +44,25 @@ def test_oracle_matches_reference(name):
     assert float(e2) == pytest.approx(float(elbo), rel=1e-12)
 
 
+@pytest.mark.parametrize("name", __import__("helpers").MULTIBLOCK)
+def test_oracle_matches_reference_beyond_one_block(name):
+    """M = 300, N = 2000, L = 3 run through the reference itself (make_golden.py multiblock_cases): the oracle on the
+    regenerated inputs reproduces the reference's moments, KL, ELBO and the factor's diagonal / row sums."""
+    from helpers import load_multiblock
+    c = load_multiblock(name)
+    f64 = c["X"].dtype == torch.float64
+    e, mean, scale = O.elbo_eval(c["kind"], c["whitened"], c["X"], c["y"], c["Z"], c["sigma"], c["lengthscale"], c["mu"],
+                                 c["Lu_raw"], c["jitter"], c["noise_sd"])
+    tol = dict(rtol=1e-9, atol=1e-11) if f64 else dict(rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(mean, c["mean"], **tol)
+    torch.testing.assert_close(scale, c["scale"], **tol)
+    assert float(e) == pytest.approx(c["elbo"], rel=1e-10 if f64 else 1e-5)
+    Kzz = O.add_jitter_(O.kernel_matrix(c["kind"], c["Z"], c["Z"], c["sigma"], c["lengthscale"]).contiguous(), c["jitter"])
+    chol = torch.linalg.cholesky(Kzz)
+    torch.testing.assert_close(torch.diagonal(chol, dim1=-2, dim2=-1), c["chol_diag"], **(tol if f64 else dict(rtol=1e-3, atol=0)))
+    torch.testing.assert_close(chol.sum(-1), c["chol_rowsum"], **(tol if f64 else dict(rtol=1e-3, atol=1e-3)))
+
+
 def test_oracle_vmap_kernels():
     z = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "kernels_only.npz"))
     gX, gZ = torch.from_numpy(z["gX"]), torch.from_numpy(z["gZ"])
