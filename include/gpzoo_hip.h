@@ -215,8 +215,8 @@ int gpz_svgp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int64_
  * standard-normal draws of rsample; W (D,Lt), V (N,): POSITIVE loadings / size factors (after
  * softplus); y (D,N) counts.  Outputs: loglik (2,) fp64: [0] = (1/E) sum_e sum_dn [y log(VZ) - VZ],
  * [1] = sum_dn lgamma(y+1) (0 unless with_lgamma; Poisson.log_prob = [0] - [1]); and
- * d loglik[0] / d{mean, scale, W, V}.  Lt <= 64 factors; E * ceil8(Lt) <= 64 per call (more samples:
- * one call per group of samples, as gpzoo_amd/ops.py does). */
+ * d loglik[0] / d{mean, scale, W, V}.  Lt <= 64 factors; E <= 4 samples per call (more samples:
+ * one call per group of four, as gpzoo_amd/ops.py does).  The three dense products (rate, dW, d exp F) run on MFMA. */
 size_t gpz_poisson_nsf_workspace_bytes(int64_t N, int64_t D, int32_t Lt, int32_t E);
 int gpz_poisson_nsf(const float* mean, const float* scale, const float* eps, const float* W,
                     const float* V, const float* y, int64_t N, int64_t D, int32_t Lt, int32_t E,

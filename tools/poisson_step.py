@@ -39,7 +39,8 @@ def main():
         return ll.detach(), lv
     t_t, ref = timed(torch_path, reps=3)
     flops = 8.0 * Lt * E * D * N
-    print(f"fused  : {t_f:8.2f} ms  ({flops / t_f / 1e9:.1f} TFLOP/s fp32 VALU, y read twice = {2 * D * N * 4 / t_f / 1e6:.0f} GB/s)")
+    print(f"fused  : {t_f:8.2f} ms  ({flops / t_f / 1e9:.1f} TFLOP/s fp32 MFMA incl. the rate computed in both passes, "
+          f"y read twice = {2 * D * N * 4 / t_f / 1e6:.0f} GB/s)")
     print(f"torch  : {t_t:8.2f} ms   loglik fused {float(out[0]):.3f} vs torch {float(ref[0]):.3f}")
 
 
