@@ -11,6 +11,8 @@
 // loaded, /opt/rocm's otherwise), so single-GPU users of the library do not need it at all.
 #include "common.h"
 
+#include <cstdio>
+
 #include <dlfcn.h>
 #include <cstring>
 #include <mutex>
@@ -34,6 +36,7 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_rccl_once;
+char g_rccl_why[256] = "not tried";               // why RCCL is unavailable (dlerror() is cleared by every call: kept here)
 
 void load_rccl() {
   const char* names[] = {"librccl.so.1", "librccl.so"};
@@ -41,8 +44,11 @@ void load_rccl() {
   for (const char* n : names)                       // a copy already in the process (PyTorch's) wins
     if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
   if (!h)
-    for (const char* n : names)
+    for (const char* n : names) {
       if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+      const char* e = dlerror();                    // the failing LOAD attempt's reason, read exactly once
+      snprintf(g_rccl_why, sizeof(g_rccl_why), "library missing: %s", e ? e : "dlopen failed");
+    }
   if (!h) return;
   Rccl r;
   r.handle = h;
@@ -52,11 +58,13 @@ void load_rccl() {
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   if (r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy) g_rccl = r;
+  else snprintf(g_rccl_why, sizeof(g_rccl_why), "symbol missing: librccl was loaded but lacks ncclGetUniqueId / "
+                "ncclCommInitRank / ncclAllReduce / ncclCommDestroy");
 }
 
 int need_rccl() {
   std::call_once(g_rccl_once, load_rccl);
-  GPZ_REQUIRE(g_rccl.handle, "RCCL is not available: dlopen(librccl.so.1) failed (%s)", dlerror() ? dlerror() : "symbols missing");
+  GPZ_REQUIRE(g_rccl.handle, "RCCL is not available (%s)", g_rccl_why);
   return 0;
 }
 

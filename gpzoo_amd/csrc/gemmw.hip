@@ -451,7 +451,6 @@ int fused1_launch(const Fused1Args& a, hipStream_t s) {
   const int want = (32 + p.mtw * p.L - 1) / (p.mtw * p.L);
   if (strips < want) strips = want < p.nt ? want : p.nt;
   p.W = (p.nt + strips - 1) / strips;
-  if (const char* e = getenv("GPZ_W_W")) { const int w = atoi(e); if (w >= 1) p.W = w < p.nt ? w : p.nt; }   // diagnostics
   p.strips = (p.nt + p.W - 1) / p.W;
   const int64_t units = (int64_t)p.mtw * p.L * p.strips;
   const int64_t nblocks = (units + 7) / 8 * 8 * p.W;
@@ -477,10 +476,12 @@ int wide_product_launch(const WideArgs& a, hipStream_t s) {
   p.mu = a.mu; p.sMu = a.Mp;
   p.ps_sq = a.ps_sq; p.ps_mu = a.ps_mu; p.ncols = a.ncp; p.M = a.Mp;
   p.L = a.L; p.nblk = (int)(a.Mp / 128); p.mtw = (int)((a.Mp + TM - 1) / TM); p.nt = (int)(a.ncp / TN);
-  // strips of (nearly) equal width, at most 16 column tiles: an XCD takes every 8th (latent, strip) unit
-  const int strips = (p.nt + 15) / 16;
+  // strips of (nearly) equal width, at most 32 column tiles: an XCD takes every 8th (latent, strip) unit.  Measured at
+  // config 3 (evaluation ms, stage 1 / stage 2 TF): 8 columns 391.0, 141.1 / 145.7 (L2 -> fabric 23.2 GB per stage-1
+  // launch); 16 columns 386.7, 142.8 / 147.4 (17.8 GB); 24: 386.1; 32: 384.2, 143.7 / 148.5; 48: 385.8
+  constexpr int WMAX = 32;
+  const int strips = (p.nt + WMAX - 1) / WMAX;
   p.W = (p.nt + strips - 1) / strips;
-  if (const char* e = getenv("GPZ_W_W")) { const int w = atoi(e); if (w >= 1) p.W = w < p.nt ? w : p.nt; }   // diagnostics
   p.strips = (p.nt + p.W - 1) / p.W;
   const int64_t units = (int64_t)p.L * p.strips;
   const int64_t nblocks = (units + 7) / 8 * 8 * p.mtw * p.W;

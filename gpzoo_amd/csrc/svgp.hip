@@ -52,10 +52,7 @@ struct ProductSchedule { int cols, tpw; };
 // get all the short units and idle a quarter of the launch (minibatch step 52.4 -> 48.9 ms with 28 + 27).
 template <typename T>
 static ProductSchedule product_schedule(bool stats_epilogue, int nt) {
-  static const int env_tpw = [] { const char* e = getenv("GPZ_TPW"); return e ? atoi(e) : 2; }();
-  static const int env_cols = [] { const char* e = getenv("GPZ_SUPER_COLS"); return e ? atoi(e) : 0; }();
-  const int tpw = (sizeof(T) == 4 && stats_epilogue && env_tpw >= 1) ? env_tpw : 1;
-  if (env_cols > 0) return ProductSchedule{env_cols, tpw};
+  const int tpw = (sizeof(T) == 4 && stats_epilogue) ? 2 : 1;
   const int full = 16 * tpw;
   const int strips = (nt + full - 1) / full;
   int w = (nt + strips * tpw - 1) / (strips * tpw);     // workgroups per row tile and strip

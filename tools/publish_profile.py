@@ -22,7 +22,9 @@ here = os.path.dirname(os.path.abspath(__file__))
 subprocess.run([sys.executable, here + "/pmc_summary.py", *(src + "/pmc_" + k for k in ("fetch", "write", "l2", "sq")),
                 "--json", dst + "/pmc_per_dispatch.json"], check=True, stdout=subprocess.DEVNULL)
 pmc = json.load(open(dst + "/pmc_per_dispatch.json"))
-stage1 = [k for k in pmc if "gemm128_kernel<float" in k and ", false, 1," in k][0]     # <float, NI, NN, EPI_STORE_STATS, STG>
+# stage 1 = Wt = Linv * Kzx: gemmw_kernel<256, 128, mem, lower, store+stats, ..> (fp32) or gemm128_kernel<T, NI, NN, EPI_STORE_STATS, ..>
+stage1 = ([k for k in pmc if "gemmw_kernel<256, 128, 0, 1, 0" in k] or
+          [k for k in pmc if "gemm128_kernel<float" in k and ", false, 1," in k])[0]
 v = pmc[stage1]
 cfgs = bench["config"]["workload"]
 N, M, L = (int(cfgs.split(f"{t}=")[1].split()[0].rstrip(",")) for t in ("N", "M", "L"))
@@ -43,11 +45,11 @@ json.dump(out, open(dst + "/traffic_stage1.json", "w"), indent=1)
 print("bench under rocprof: %.1f ms/step, stage-1 avg launch %.3f ms, %.1f TF" % (
     bench["ms_per_step"], bench["roofline"]["avg_launch_ms"], bench["roofline"]["achieved"]))
 for r in csv.DictReader(open(dst + "/kernel_stats.csv")):
-    if "gemm128_kernel<float" in r["Name"]:
+    if "gemm128_kernel<float" in r["Name"] or "gemmw_kernel<" in r["Name"]:
         print("rocprof:", r["Name"][:60], r["Calls"], "calls, avg %.3f ms" % (float(r["AverageNs"]) / 1e6))
 print("traffic %.2f GB / launch, algorithmic %.2f GB" % (out["hbm_bytes_per_launch"] / 1e9, algo / 1e9))
 for k in pmc:
-    if "gemm128_kernel<float" in k and "GRBM_GUI_ACTIVE" in pmc[k]:
+    if ("gemm128_kernel<float" in k or "gemmw_kernel<" in k) and "GRBM_GUI_ACTIVE" in pmc[k]:
         w = pmc[k]
         print(k, "MFMA busy %.3f, L2 hit %.3f" % (w["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * w["GRBM_GUI_ACTIVE"] / 8),
                                                  w["TCC_HIT_sum"] / (w["TCC_HIT_sum"] + w["TCC_MISS_sum"])))
