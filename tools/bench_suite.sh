@@ -6,8 +6,10 @@ one() { python3 - "$1" <<'PY'
 import json, sys
 r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 k = r["kernels"]
-print("  value %.4f %s | %.2f ms/step | stage1 %.1f TF (frac %.3f) | stage2 %.1f TF | kfill %.0f GB/s | potrf %.2f ms (trailing %.1f TF) | trtri %.2f ms%s" % (
-    r["value"], r["unit"], r["ms_per_step"], r["roofline"]["achieved"], r["roofline"]["frac"], k["stage2_LuT_Wt"]["achieved_TFLOPs"],
+clk = r.get("clocks") or {}
+print("  value %.4f %s | %.2f ms/step | stage1 %.1f TF (frac %.3f; sclk %.0f MHz: frac at that clock %.3f) | stage2 %.1f TF | kfill %.0f GB/s | potrf %.2f ms (trailing %.1f TF) | trtri %.2f ms%s" % (
+    r["value"], r["unit"], r["ms_per_step"], r["roofline"]["achieved"], r["roofline"]["frac"], clk.get("sclk_MHz_mean", 0.0),
+    r["roofline"].get("frac_at_sampled_clock", 0.0), k["stage2_LuT_Wt"]["achieved_TFLOPs"],
     k["kuf_fill"]["achieved_GBps"], k["potrf_ms_per_eval"], k["potrf_trailing"]["achieved_TFLOPs"], k["trtri_ms_per_eval"],
     (" | fwd+bwd %s ms" % {a: round(b, 1) for a, b in r["forward_backward_ms"].items()}) if "forward_backward_ms" in r else ""))
 PY
