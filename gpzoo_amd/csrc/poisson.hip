@@ -76,7 +76,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __bui
 //         accumulator tiles hold four CONSECUTIVE spots of a gene row: y arrives as one 16-byte load per row (256
 //         contiguous bytes per gene row and wave).  Emits log-lik, dV and dexpF partial slabs (no atomics).
 template <int KS>
-__global__ __launch_bounds__(256) void spot_mfma_kernel(PoissonArgs a, int GS) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void spot_mfma_kernel(PoissonArgs a, int GS) {
   constexpr int LT16 = (KS + 3) / 4;          // 16-row tiles of the factor axis
   __shared__ double sh[8];
   // lgamma(y + 1) = log(y!) for the counts a Poisson model is fed: a table for integer y < 256 (lgammaf is ~100
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void spot_mfma_kernel(PoissonArgs a, int GS) {
 //         y arrives as four 16-byte loads per lane (256 contiguous bytes per gene).  dW^T[factor][gene] stays in 4 * LT16
 //         registers for the whole sweep.
 template <int KS>
-__global__ __launch_bounds__(256) void gene_mfma_kernel(PoissonArgs a, int SN) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void gene_mfma_kernel(PoissonArgs a, int SN) {
   constexpr int LT16 = (KS + 3) / 4, LP = 16 * LT16, PF = 68;      // factor rows staged (zero padded), row pitch
   extern __shared__ float smem_p[];
   const int FB = a.E * LP * PF;                 // one buffer of exp(F): [E][LP][PF]

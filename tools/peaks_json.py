@@ -9,15 +9,16 @@ import sys
 
 txt = open(sys.argv[1]).read()
 f32 = [float(m.group(1)) for m in re.finditer(r"pure mfma\s+shape=16.*?([\d.]+) TF", txt)]
-f64 = [float(m.group(1)) for m in re.finditer(r"f64 16x16x4 \S+ distinct.*?([\d.]+) TF", txt)]
+f64 = [float(m.group(1)) for m in re.finditer(r"f64 16x16x4 nacc\S+ \S+ blocks/CU=\d+\s+[\d.]+ ms\s+([\d.]+) TF", txt)]
 wr = [float(m.group(1)) for m in re.finditer(r"write (\d+) GB/s", txt)]
 rd = [float(m.group(1)) for m in re.finditer(r"read (\d+) GB/s", txt)]
 cp = [float(m.group(1)) for m in re.finditer(r"copy (\d+) GB/s", txt)]
-out = {"mfma_f32_TFLOPs": max(f32), "mfma_f64_probe_TFLOPs": max(f64), "hbm_write_GBps": max(wr), "hbm_read_GBps": max(rd),
+out = {"mfma_f32_TFLOPs": max(f32), "mfma_f64_TFLOPs": max(f64), "hbm_write_GBps": max(wr), "hbm_read_GBps": max(rd),
        "hbm_copy_GBps": max(cp),
-       "mfma_f64_note": "the register-resident fp64 loop tops out at this rate in every shape tried (shared / distinct operands, "
-                        "4-16 accumulators, 1-8 waves per SIMD), yet the fp64 GEMM of this build sustains 69-71 TF on the "
-                        "config-5 products: the probe is NOT an upper bound, so fp64 fractions stay against the 78.6 TF datasheet figure",
+       "mfma_f64_note": "register-resident v_mfma_f64_16x16x4_f64 loop with the accumulators tied to VGPRs (inline asm): 64 shader "
+                        "cycles per MFMA per SIMD at the ~2.39 GHz the chip holds = the 78.6 TF datasheet rate.  (Round 2's 49 TF "
+                        "probe used the builtin: hipcc kept the accumulators in AGPRs and emitted 16 v_accvgpr moves per MFMA, which "
+                        "cost their issue time -- vector instructions are not free beside an MFMA.)",
        "how": "tools/peaks.sh on the MI355X box: register-resident v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 loops "
               "(tools/mfma_probe_f32.hip, _f64.hip) and 16-byte-per-lane streaming kernels over 4 GiB buffers (tools/hbm_probe.hip); "
               "best of the occupancies tried"}
