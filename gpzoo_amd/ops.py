@@ -146,9 +146,11 @@ def kfill(spec: KernelSpec, A: torch.Tensor, B: torch.Tensor, gA=None, gB=None, 
     if spec.kind == _lib.KERNEL_MGGP_RBF:
         gA, gB = _group_ids(gA, A.shape[0], A.device, "groupsX"), _group_ids(gB, B.shape[0], A.device, "groupsZ")
         G = int(spec.group_r2.shape[0])
-        for g_ in (gA, gB):     # stand-alone call: checked on the host (the fused pass flags it on the device)
-            if g_.numel() and bool(((g_ < 0) | (g_ >= G)).any()):
-                raise IndexError("index out of range in self: a group id is outside [0, n_groups)")
+        # stand-alone call: checked here with ONE device-to-host sync for both id vectors (the fused pass flags it on the
+        # device and rides on the sync it needs anyway)
+        bad = [((g_ < 0) | (g_ >= G)).any() for g_ in (gA, gB) if g_.numel()]
+        if bad and bool(torch.stack(bad).any()):
+            raise IndexError("index out of range in self: a group id is outside [0, n_groups)")
     else:
         gA = gB = None
     odt = A.dtype if out_dtype is None else out_dtype

@@ -600,31 +600,33 @@ def exact_gp_case():
     print("exact_mggp_step_f64: loss", float(loss))
 
 
-def vnngp_scale_case():
-    """VNNGP neighbour bookkeeping at Slide-seq-like coordinates in fp32 (|x| <= 100, N=4000, M=500, K=8): the
-    reference orders neighbours by torch.cdist's fp32 matmul-expansion distances (kernels.py:118, gp.py:31, 64),
-    whose error reaches 0.06 there.  Stores the reference's neighbour table and moments.
-    -> vnngp_scale_f32.npz"""
+def vnngp_scale_case(tag="f32", N=4000, M=500):
+    """VNNGP neighbour bookkeeping at Slide-seq-like coordinates (|x| <= 100, K=8): the reference orders neighbours by
+    torch.cdist's matmul-expansion distances (kernels.py:118, gp.py:31, 64; either side > 25 rows), whose fp32 error
+    reaches 0.06 there.  Stores the reference's neighbour table and moments.
+    -> vnngp_scale_f32.npz (N=4000, M=500) and vnngp_scale_f64.npz (N=1500, M=120: the fp64 instantiation of the
+    matmul-expansion ranking)"""
     import contextlib
     import io
-    L, N, M, K = 2, 4000, 500, 8
+    L, K = 2, 8
+    dt = torch.float32 if tag == "f32" else torch.float64
     inp = make_inputs(811, N=N, M=M, d=2, L=L, span=100.0)
     kern = rk.NSF_RBF(L=L)
     kern.sigma = nn.Parameter(per_latent([1.0, 0.8], True)); kern.lengthscale = nn.Parameter(per_latent([6.0, 9.0], True))
     gp = rgp.VNNGP(kern, dim=2, M=M, K=K, jitter=1e-2)
     gp.Z = nn.Parameter(inp["Z"].clone()); gp.mu = nn.Parameter(inp["mu"].clone()); gp.Lu = nn.Parameter(inp["Lu_raw"].clone())
-    gp = gp.float()
-    X = inp["X"].float()
+    gp = gp.to(dt)
+    X = inp["X"].to(dt)
     with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
         qF, qU, pU = gp(X)
         _, dist = kern(X, gp.Z, return_distance=True)
     idx = torch.argsort(dist, dim=1)[:, :K]
-    np.savez_compressed(os.path.join(HERE, "vnngp_scale_f32.npz"), X=X.numpy(), Z=gp.Z.detach().numpy(),
+    np.savez_compressed(os.path.join(HERE, f"vnngp_scale_{tag}.npz"), X=X.numpy(), Z=gp.Z.detach().numpy(),
                         mu=gp.mu.detach().numpy(), Lu_raw=gp.Lu.detach().numpy(), sigma=kern.sigma.detach().numpy(),
                         lengthscale=kern.lengthscale.detach().numpy(), idx=idx.numpy().astype(np.int16),
                         dist_k=torch.gather(dist, 1, idx).numpy(), mean=qF.mean.numpy(), scale=qF.scale.numpy(),
                         jitter=np.float64(1e-2), K=np.int64(K))
-    print("vnngp_scale_f32: idx", tuple(idx.shape), "mean[0,:3]", qF.mean[0, :3].tolist())
+    print(f"vnngp_scale_{tag}: idx", tuple(idx.shape), "mean[0,:3]", qF.mean[0, :3].tolist())
 
 
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "kernel_grads"):
@@ -633,6 +635,7 @@ if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "ker
 
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "vnngp_scale"):
     vnngp_scale_case()
+    vnngp_scale_case("f64", N=1500, M=120)
 
 
 def multiblock_cases():
