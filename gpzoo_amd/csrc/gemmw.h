@@ -20,16 +20,29 @@ struct Fused1Args {
 bool fused1_supported(int dtype, int kind, int d);
 int fused1_launch(const Fused1Args& a, hipStream_t s);
 
-// Triangular A (L, Mp, Mp) times dense B (L, Mp, ncp) from memory, fp32:
-//   upper = 0: C = A * B with A lower triangular, stored, plus colsum(C^2) and mu^T C per 128-row block   (stage 1)
-//   upper = 1: colsum((A * B)^2) per 128-row block with A upper triangular, nothing stored                 (stage 2)
+// Triangular A (L, Mp, Mp) times dense B (L, Mp, ncp) from memory, fp32, on 256 x 128 tiles:
+enum WideEpilogue {
+  WIDE_STORE_STATS = 0,     // lower A: C = A B stored, plus colsum(C^2) and mu^T C per 128-row block          (forward stage 1)
+  WIDE_STATS = 1,           // upper A: colsum((A B)^2) per 128-row block, nothing stored                       (forward stage 2)
+  WIDE_STORE = 2,           // upper A: C = A B                                                                  (backward Kbar_x)
+  WIDE_STORE_COLSCALE = 3,  // upper A: C[i][j] = colscale[j] (A B)[i][j]                                        (backward Pbar)
+  WIDE_WBAR = 4,            // lower A: C[i][j] = (A B)[i][j] + rowvec[i] colvec[j] - aux[i][j] colscale[j]      (backward Wbar)
+};
 struct WideArgs {
   const float* A; const float* B; int64_t Mp, ncp; int L;
-  int upper, store;
-  float* C; const float* mu;                  // stage 1 only
-  float* ps_sq; float* ps_mu;                 // [L][Mp/128][ncp]; ps_mu stage 1 only
+  int upper, epilogue;
+  float* C; const float* mu;                  // mu: WIDE_STORE_STATS
+  float* ps_sq; float* ps_mu;                 // [L][Mp/128][ncp]; ps_mu: WIDE_STORE_STATS
+  const float* colscale; const float* colvec; // (L, ncp)
+  const float* rowvec;                        // (L, Mp)
+  const float* aux;                           // (L, Mp, ncp)
 };
 bool wide_product_supported(int64_t Mp, int64_t ncp);
 int wide_product_launch(const WideArgs& a, hipStream_t s);
+
+// C (L, Mp, Mp) += A (L, Mp, K) * B (L, Mp, K)^T, lower 128-tiles only (the tiles on the diagonal are written whole), fp32:
+// the backward pass's gradient accumulations over an N-chunk.
+bool wide_nt_supported(int64_t Mp, int64_t K);
+int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s);
 
 }  // namespace gpz

@@ -48,7 +48,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { WB_MEM = 0, WB_GEN = 1 };
 enum { WA_LOWER = 1, WA_UPPER = 2 };
-enum { WE_STORE_STATS = 0, WE_STATS = 1 };
+enum { WE_STORE_STATS = 0,      // C = A B, plus colsum(C^2) and mu^T C per 128-row block        (forward stage 1)
+       WE_STATS = 1,            // colsum((A B)^2) per 128-row block only                         (forward stage 2)
+       WE_STORE = 2,            // C = A B                                                        (backward: Kbar_x = Linv^T Wbar)
+       WE_STORE_COLSCALE = 3,   // C[i][j] = colscale[j] (A B)[i][j]                              (backward: Pbar)
+       WE_WBAR = 4 };           // C[i][j] = (A B)[i][j] + rowvec[i] colvec[j] - aux[i][j] colscale[j]   (backward: Wbar)
 
 struct WParams {
   const float* A; int64_t lda, sA0;         // (L, Mp, Mp)
@@ -59,6 +63,9 @@ struct WParams {
   float* C; int64_t ldc, sC0;               // WE_STORE_STATS: (L, Mp, ncols)
   const float* mu; int64_t sMu;             // WE_STORE_STATS: (L, Mp)
   float* ps_sq; float* ps_mu; int64_t ncols;  // [L][nblk][ncols]
+  const float* colscale; const float* colvec; int64_t sCs;   // WE_STORE_COLSCALE / WE_WBAR: (L, ncols) vectors
+  const float* rowvec; int64_t sRv;           // WE_WBAR: (L, Mp)
+  const float* aux;                           // WE_WBAR: laid out like C
   int64_t M;                                // real rows (the rest is padding)
   int L, nblk, mtw, nt, W, strips;          // latents, 128-blocks, row tiles, column tiles, strip width, strips
 };
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
   }
   // column statistics over this wave's 128 rows = one 128-row block: registers -> lane groups, no workgroup step
-  {
+  if constexpr (EPI == WE_STORE_STATS || EPI == WE_STATS) {
     float ssq[2] = {0.f, 0.f}, smu[2] = {0.f, 0.f};
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
@@ -376,11 +383,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   // output tile: through a wave-private LDS strip (it aliases the tile buffers: every read of them is behind the loop's
   // last barrier) so each store instruction writes eight whole 128-byte row segments
-  if constexpr (EPI == WE_STORE_STATS) {
+  if constexpr (EPI != WE_STATS) {
     constexpr int LDE = 36;
     float* strip = smem + wave * (32 * LDE);
     float* Cg = p.C + b0 * p.sC0 + row0 * p.ldc + ccol0;
     const int srow = lane >> 3, c4 = (lane & 7) * 4;
+    float cs[2] = {1.f, 1.f};
+    if constexpr (EPI == WE_STORE_COLSCALE) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) cs[ni] = p.colscale[b0 * p.sCs + ccol0 + ni * 16 + r];
+    }
+    f32x4 sc = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
+    if constexpr (EPI == WE_WBAR) {
+      sc = *reinterpret_cast<const f32x4*>(p.colscale + b0 * p.sCs + ccol0 + c4);
+      cv = *reinterpret_cast<const f32x4*>(p.colvec + b0 * p.sCs + ccol0 + c4);
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
 #pragma unroll
@@ -388,16 +405,176 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) strip[(mm * 16 + 4 * q + g) * LDE + ni * 16 + r] = acc[pass * 2 + mm][ni][g];
+          for (int g = 0; g < 4; ++g) strip[(mm * 16 + 4 * q + g) * LDE + ni * 16 + r] = cs[ni] * acc[pass * 2 + mm][ni][g];
       __builtin_amdgcn_wave_barrier();
+      f32x4 w[4];
+      float rv[4];
+      if constexpr (EPI == WE_WBAR) {       // every operand of the pass is loaded before its first store (stores may alias)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int64_t row = pass * 32 + it * 8 + srow;
+          w[it] = *reinterpret_cast<const f32x4*>(p.aux + b0 * p.sC0 + (row0 + row) * p.ldc + ccol0 + c4);
+          rv[it] = p.rowvec[b0 * p.sRv + row0 + row];
+        }
+      }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + srow;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * LDE + c4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * LDE + c4);
+        if constexpr (EPI == WE_WBAR) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] + rv[it] * cv[e] - w[it][e] * sc[e];
+        }
         *reinterpret_cast<f32x4*>(Cg + (int64_t)(pass * 32 + row) * p.ldc + c4) = v;
       }
       __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+// ---------------- C += A B^T over a long k (the backward pass's M x M gradient accumulations) ----------------
+// G += W Pbar^T and GL += Kbar_x W^T (gp.py:276-296 under autograd): A, B (L, Mp, K) row-major with K = the N-chunk,
+// C (L, Mp, Mp), lower tiles only.  Same wave tiling and LDS-DMA staging as above; both operands are [row][16 k] images
+// (B's fragments are ds_read_b128 too), every step runs all sub-tiles, and the epilogue is a read-modify-write of the
+// 256 x 128 tile through the wave-private strips.  Tiles of one matrix take a contiguous range of blocks on ONE XCD
+// (blocks b, b + 8, ... share an XCD): its workgroups walk k together and share the operand panels in that L2.
+struct NTParams {
+  const float* A; const float* B; float* C;
+  int64_t ld, sAB, ldc, sC;                 // operand leading dimension (= K) / batch stride, C's
+  int K, nblk, mt, L, T;                    // k extent, 128-blocks, 256-row tiles, matrices, tiles per matrix
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_nt_kernel(const NTParams p) {
+  constexpr int BK = W_BK, TM = 256, TN = 128;
+  constexpr int A_ELEMS = TM * BK, B_ELEMS = TN * BK, STAGE = A_ELEMS + B_ELEMS;
+  extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+  auto sA = [&](int buf) -> float* { return smem + buf * STAGE; };
+  auto sB = [&](int buf) -> float* { return smem + buf * STAGE + A_ELEMS; };
+  // block -> (matrix, tile): XCD x takes the contiguous range [x n / 8, (x + 1) n / 8) of the (matrix-major) tile order
+  int b0, ti, tj;
+  {
+    const int nb = (int)gridDim.x, qn = nb >> 3, rem = nb & 7, x = blockIdx.x & 7;
+    const int lid = x * qn + min(x, rem) + (int)(blockIdx.x >> 3);
+    b0 = lid / p.T;
+    const int t = lid - b0 * p.T;
+    // row tile ti holds column tiles 0 .. 2 ti + 1 (the last row of an odd block count one fewer): ti (ti + 1) tiles precede it
+    int i = (int)((sqrtf(4.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((i + 1) * (i + 2) <= t) ++i;
+    while (i * (i + 1) > t) --i;
+    ti = i; tj = t - i * (i + 1);
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+  const int Mp = p.nblk * 128;
+  const int db = 2 * ti + wm;                        // this wave's 128-row block
+  const bool active = db < p.nblk && tj <= db;       // blocks above the diagonal (and past the matrix) are not computed
+  typedef __attribute__((address_space(3))) void lds_void;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.A + b0 * p.sAB), 0, (int)(p.ld * Mp * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.B + b0 * p.sAB), 0, (int)(p.ld * Mp * sizeof(float)), 0x00020000);
+#endif
+  auto gperm = [](int w) { const int t = (w >> 2) & 3; return (((t >> 1) ^ t) & 1) << 1 | (t >> 1); };
+  const int voff = ((lane >> 2) * (int)p.ld + (((lane & 3) ^ gperm(lane >> 2)) * 4)) * (int)sizeof(float);
+  int a_soff[2], b_soff;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int row = ti * TM + (2 * wave + h) * 16;
+    while (row >= Mp) row -= 128;
+    a_soff[h] = row * (int)p.ld * (int)sizeof(float);
+  }
+  b_soff = (tj * TN + wave * 16) * (int)p.ld * (int)sizeof(float);
+  auto stage_load = [&](int buf) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(sA(buf) + (2 * wave + h) * 256), 16, voff, a_soff[h], 0, 0);
+      a_soff[h] += BK * (int)sizeof(float);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sB(buf) + wave * 256), 16, voff, b_soff, 0, 0);
+    b_soff += BK * (int)sizeof(float);
+#endif
+  };
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
+  const int fr_a = (wm * 128 + r) * BK + ((q ^ gperm(r)) * 4);
+  const int fr_b = (wn * 32 + r) * BK + ((q ^ gperm(r)) * 4);
+  auto mma_step = [&](int buf) __attribute__((always_inline)) {
+    f32x4 fb[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) fb[ni] = *reinterpret_cast<const f32x4*>(sB(buf) + fr_b + ni * 16 * BK);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 fa[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const f32x4*>(sA(buf) + fr_a + (half * 4 + m) * 16 * BK);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[half * 4 + m][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][j], fb[ni][j], acc[half * 4 + m][ni], 0, 0, 0);
+    }
+  };
+  const int nk = p.K / BK;                           // even: K is a multiple of 128
+  stage_load(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // (the wave-uniform `active` test sits outside the loops: no MFMA under a run-time branch)
+  if (active) {
+    for (int t = 0; t < nk; t += 2) {
+      if (t + 1 < nk) stage_load(1);
+      mma_step(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 2 < nk) stage_load(0);
+      mma_step(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    for (int t = 0; t < nk; t += 2) {
+      if (t + 1 < nk) stage_load(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 2 < nk) stage_load(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    return;
+  }
+  // read-modify-write of the tile: all loads of a pass are issued before its first store
+  constexpr int LDE = 36;
+  float* strip = smem + wave * (32 * LDE);
+  float* Cg = p.C + b0 * p.sC + (int64_t)db * 128 * p.ldc + (int64_t)tj * TN + wn * 32;
+  const int srow = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) strip[(mm * 16 + 4 * q + g) * LDE + ni * 16 + r] = acc[pass * 2 + mm][ni][g];
+    __builtin_amdgcn_wave_barrier();
+    f32x4 cin[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) cin[it] = *reinterpret_cast<const f32x4*>(Cg + (int64_t)(pass * 32 + it * 8 + srow) * p.ldc + c4);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + srow;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * LDE + c4);
+      *reinterpret_cast<f32x4*>(Cg + (int64_t)(pass * 32 + row) * p.ldc + c4) = cin[it] + v;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -475,6 +652,7 @@ int wide_product_launch(const WideArgs& a, hipStream_t s) {
   p.C = a.C; p.ldc = a.ncp; p.sC0 = a.Mp * a.ncp;
   p.mu = a.mu; p.sMu = a.Mp;
   p.ps_sq = a.ps_sq; p.ps_mu = a.ps_mu; p.ncols = a.ncp; p.M = a.Mp;
+  p.colscale = a.colscale; p.colvec = a.colvec; p.sCs = a.ncp; p.rowvec = a.rowvec; p.sRv = a.Mp; p.aux = a.aux;
   p.L = a.L; p.nblk = (int)(a.Mp / 128); p.mtw = (int)((a.Mp + TM - 1) / TM); p.nt = (int)(a.ncp / TN);
   // strips of (nearly) equal width, at most 32 column tiles: an XCD takes every 8th (latent, strip) unit.  Measured at
   // config 3 (evaluation ms, stage 1 / stage 2 TF): 8 columns 391.0, 141.1 / 145.7 (L2 -> fabric 23.2 GB per stage-1
@@ -486,12 +664,45 @@ int wide_product_launch(const WideArgs& a, hipStream_t s) {
   const int64_t units = (int64_t)p.L * p.strips;
   const int64_t nblocks = (units + 7) / 8 * 8 * p.mtw * p.W;
   constexpr size_t lds = WLds<TM, TN, WB_MEM, 1>::bytes;
-  if (a.upper) {
-    GPZ_REQUIRE(!a.store, "wide product: the upper-triangular product is statistics-only");
-    return launch_wide(gemmw_kernel<TM, TN, WB_MEM, WA_UPPER, WE_STATS, 0, 1>, lds, p, nblocks, s);
+#define GPZ_WM(ATRI, EPI) return launch_wide(gemmw_kernel<TM, TN, WB_MEM, ATRI, EPI, 0, 1>, lds, p, nblocks, s)
+  switch (a.epilogue) {
+    case WIDE_STORE_STATS:
+      GPZ_REQUIRE(!a.upper && a.C && a.mu && a.ps_sq && a.ps_mu, "wide product: store + statistics is the lower-triangular product and needs C, mu and both slabs");
+      GPZ_WM(WA_LOWER, WE_STORE_STATS);
+    case WIDE_STATS:
+      GPZ_REQUIRE(a.upper && a.ps_sq, "wide product: statistics only is the upper-triangular product");
+      GPZ_WM(WA_UPPER, WE_STATS);
+    case WIDE_STORE:
+      GPZ_REQUIRE(a.upper && a.C, "wide product: the plain store is built for the upper-triangular product");
+      GPZ_WM(WA_UPPER, WE_STORE);
+    case WIDE_STORE_COLSCALE:
+      GPZ_REQUIRE(a.upper && a.C && a.colscale, "wide product: the column-scaled store is the upper-triangular product and needs the factors");
+      GPZ_WM(WA_UPPER, WE_STORE_COLSCALE);
+    case WIDE_WBAR:
+      GPZ_REQUIRE(!a.upper && a.C && a.colscale && a.colvec && a.rowvec && a.aux, "wide product: the W-bar epilogue needs its operands");
+      GPZ_WM(WA_LOWER, WE_WBAR);
+    default: break;
   }
-  GPZ_REQUIRE(a.store && a.C && a.mu && a.ps_mu, "wide product: the lower-triangular product stores and needs mu");
-  return launch_wide(gemmw_kernel<TM, TN, WB_MEM, WA_LOWER, WE_STORE_STATS, 0, 1>, lds, p, nblocks, s);
+#undef GPZ_WM
+  GPZ_REQUIRE(false, "wide product: unknown epilogue %d", a.epilogue);
+}
+
+bool wide_nt_supported(int64_t Mp, int64_t K) {
+  return Mp % 128 == 0 && K % 128 == 0 && K > 0 && Mp * K * 4 < (1ll << 31);
+}
+
+int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s) {
+  GPZ_REQUIRE(A && B && C && wide_nt_supported(Mp, K) && L > 0, "wide A B^T: bad arguments");
+  NTParams p;
+  p.A = A; p.B = B; p.C = C; p.ld = K; p.sAB = Mp * K; p.ldc = Mp; p.sC = Mp * Mp;
+  p.K = (int)K; p.nblk = (int)(Mp / 128); p.mt = (p.nblk + 1) / 2; p.L = L;
+  p.T = p.mt * (p.mt + 1) - (p.nblk & 1);            // row tile ti holds min(2 ti + 2, nblk) column tiles
+  const int64_t nblocks = (int64_t)p.T * L;
+  GPZ_REQUIRE(nblocks > 0 && nblocks < (1ll << 31), "wide A B^T: bad grid");
+  constexpr size_t lds = sizeof(float) * 2 * (256 + 128) * W_BK;
+  hipLaunchKernelGGL(gemmw_nt_kernel, dim3((unsigned)nblocks), dim3(512), lds, s, p);
+  GPZ_LAUNCH_OK();
+  return 0;
 }
 
 }  // namespace gpz

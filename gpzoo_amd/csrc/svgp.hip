@@ -523,7 +523,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
       if constexpr (sizeof(T) == 4) {
         if (wide) {      // Wt = Linv * Kzx on the 256 x 128 tile, with colsum(Wt^2) and muE^T Wt
           WideArgs wa = {};
-          wa.A = b.LinvG; wa.B = b.Kc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 0; wa.store = 1;
+          wa.A = b.LinvG; wa.B = b.Kc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 0; wa.epilogue = WIDE_STORE_STATS;
           wa.C = Wc; wa.mu = b.muE; wa.ps_sq = ps1; wa.ps_mu = b.pm1;
           if (int rc = wide_product_launch(wa, s)) return rc;
           done = true;
@@ -546,7 +546,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
       if constexpr (sizeof(T) == 4) {
         if (wide) {      // colsum((LuE^T Wt)^2) on the 256 x 128 tile
           WideArgs wa = {};
-          wa.A = b.LuT; wa.B = Wc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 1; wa.store = 0;
+          wa.A = b.LuT; wa.B = Wc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 1; wa.epilogue = WIDE_STATS;
           wa.ps_sq = b.ps2;
           if (int rc = wide_product_launch(wa, s)) return rc;
           done = true;
@@ -1058,6 +1058,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     const int64_t ncp = pad_up(nreal);
     const int nt = (int)(ncp / NB);
     const ProductSchedule sched = product_schedule<T>(true, nt), sched_plain = product_schedule<T>(false, nt);
+    const bool wide = !(p->flags & GPZ_SVGP_NARROW_TILES) && pl.f32 && wide_product_supported(Mp, ncp);   // gemmw.hip
     const void* Xc = static_cast<const char*>(p->X) + n0 * p->d * esz;
     T* Wc = b.Wc;
     T* ps1 = b.ps1;
@@ -1068,59 +1069,107 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       if (int rc = kfill_padded(&p->k, p->Z, M, Mp, Xc, nreal, ncp, p->d, p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp,
                                 Mp * ncp, 0.0, 0, pl.f32 ? GPZ_F32 : GPZ_F64, s))
         return rc;
-      GemmParams<T> g1;  // W = Linv * Kzx (column sums of W^2 only when the clamp mask is needed)
-      g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
-      g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
-      g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
-      g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
-      const ProductSchedule s1 = full ? sched : sched_plain;    // the plain-store epilogue has no multi-tile variant
-      g1.super_cols = s1.cols; g1.tiles_per_wg = s1.tpw; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
-      if (int rc = gemm_launch(g1, full ? EPI_STORE_STATS : EPI_STORE, s)) return rc;
+      bool done = false;
+      if constexpr (sizeof(T) == 4) {
+        if (wide) {      // W = Linv * Kzx on the wide tile (its column statistics come for free)
+          WideArgs wa = {};
+          wa.A = b.LinvG; wa.B = b.Kc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 0; wa.epilogue = WIDE_STORE_STATS;
+          wa.C = b.Wc; wa.mu = b.muE; wa.ps_sq = b.ps1; wa.ps_mu = b.pm1;
+          if (int rc = wide_product_launch(wa, s)) return rc;
+          done = true;
+        }
+      }
+      if (!done) {
+        GemmParams<T> g1;  // W = Linv * Kzx (column sums of W^2 only when the clamp mask is needed)
+        g1.A = b.LinvG; g1.lda = Mp; g1.sA0 = mm;
+        g1.B = b.Kc; g1.ldb = ncp; g1.sB0 = Mp * ncp;
+        g1.C = b.Wc; g1.ldc = ncp; g1.sC0 = Mp * ncp;
+        g1.nb0 = L32; g1.mt = (int)pl.nblk; g1.nt = nt; g1.K = (int)Mp; g1.flags = GF_A_LOWER | GF_GROUP_COLS;
+        const ProductSchedule s1 = full ? sched : sched_plain;    // the plain-store epilogue has no multi-tile variant
+        g1.super_cols = s1.cols; g1.tiles_per_wg = s1.tpw; g1.mu = b.muE; g1.sMu = Mp; g1.ps_sq = b.ps1; g1.ps_mu = b.pm1; g1.ncols = ncp;
+        if (int rc = gemm_launch(g1, full ? EPI_STORE_STATS : EPI_STORE, s)) return rc;
+      }
     }
     hipLaunchKernelGGL((colscale_kernel<T>), dim3((unsigned)((ncp + 255) / 256), L32), dim3(256), 0, s,
                        static_cast<const T*>(g->g_scale), static_cast<const T*>(g->scale), N, n0, ncp, (int)wh,
                        p->var_clamp_min, w.cs, static_cast<const T*>(g->g_mean), (const T*)ps1, (int)pl.nblk,
                        static_cast<const T*>(p->k.sigma), w.csc, w.gmc);
     GPZ_LAUNCH_OK();
-    GemmParams<T> g2;  // Pbar = (LuE^T W) diag(gv2)
-    g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
-    g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
-    g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
-    g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-    g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
-    if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
+    {                  // Pbar = (LuE^T W) diag(gv2)
+      bool done = false;
+      if constexpr (sizeof(T) == 4) {
+        if (wide) {
+          WideArgs wa = {};
+          wa.A = b.LuT; wa.B = Wc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 1; wa.epilogue = WIDE_STORE_COLSCALE;
+          wa.C = w.Pc; wa.colscale = w.cs;
+          if (int rc = wide_product_launch(wa, s)) return rc;
+          done = true;
+        }
+      }
+      if (!done) {
+        GemmParams<T> g2;
+        g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+        g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+        g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
+        g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+        g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
+        if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
+      }
+    }
     GemmParams<T> g3;  // G += W Pbar^T  (lower tiles)
     g3.A = Wc; g3.lda = ncp; g3.sA0 = Mp * ncp;
     g3.B = w.Pc; g3.ldb = ncp; g3.sB0 = Mp * ncp;
     g3.C = w.G; g3.ldc = Mp; g3.sC0 = mm;
     g3.nb0 = L32; g3.mt = g3.nt = (int)pl.nblk; g3.K = (int)ncp; g3.flags = GF_B_TRANS | GF_TILES_LOWER;
     g3.alpha = 1; g3.beta = 1;
-    if (int rc = gemm_launch(g3, EPI_STORE, s)) return rc;
+    const bool wide_nt = sizeof(T) == 4 && wide && wide_nt_supported(Mp, ncp);
+    if (wide_nt) {
+      if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(Wc, w.Pc, w.G, Mp, ncp, L32, s)) return rc; }
+    } else if (int rc = gemm_launch(g3, EPI_STORE, s)) return rc;
     hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, Wc, Mp, ncp,
                        static_cast<const T*>(g->g_mean), N, n0, w.mu_part, pl.nchunks, ci);
     GPZ_LAUNCH_OK();
     if (full) {
       // Wbar = Lu Pbar - W diag(gv2 c) + mu gm^T            (into the Kzx buffer, no longer needed)
-      GemmParams<T> g4;
-      g4.A = w.LuN; g4.lda = Mp; g4.sA0 = mm;
-      g4.B = w.Pc; g4.ldb = ncp; g4.sB0 = Mp * ncp;
-      g4.C = b.Kc; g4.ldc = ncp; g4.sC0 = Mp * ncp;
-      g4.nb0 = L32; g4.mt = (int)pl.nblk; g4.nt = nt; g4.K = (int)Mp; g4.flags = GF_A_LOWER | GF_GROUP_COLS;
-      g4.super_cols = sched_plain.cols; g4.colscale = w.csc; g4.colvec = w.gmc; g4.sCs = ncp; g4.rowvec = b.muE; g4.sRv = Mp;
-      g4.aux = Wc; g4.ncols = ncp;
-      if (int rc = gemm_launch(g4, EPI_WBAR, s)) return rc;
-      // Kbar_x = Linv^T Wbar                                   (into the Pbar buffer)
-      GemmParams<T> g5;
-      g5.A = w.LinvT; g5.lda = Mp; g5.sA0 = mm;
-      g5.B = b.Kc; g5.ldb = ncp; g5.sB0 = Mp * ncp;
-      g5.C = w.Pc; g5.ldc = ncp; g5.sC0 = Mp * ncp;
-      g5.nb0 = L32; g5.mt = (int)pl.nblk; g5.nt = nt; g5.K = (int)Mp; g5.flags = GF_A_UPPER | GF_GROUP_COLS;
-      g5.super_cols = sched_plain.cols;
-      if (int rc = gemm_launch(g5, EPI_STORE, s)) return rc;
+      bool done = false;
+      if constexpr (sizeof(T) == 4) {
+        if (wide) {
+          WideArgs wa = {};
+          wa.A = w.LuN; wa.B = w.Pc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 0; wa.epilogue = WIDE_WBAR;
+          wa.C = b.Kc; wa.colscale = w.csc; wa.colvec = w.gmc; wa.rowvec = b.muE; wa.aux = Wc;
+          if (int rc = wide_product_launch(wa, s)) return rc;
+          // Kbar_x = Linv^T Wbar                                 (into the Pbar buffer)
+          WideArgs wb = {};
+          wb.A = w.LinvT; wb.B = b.Kc; wb.Mp = Mp; wb.ncp = ncp; wb.L = L32; wb.upper = 1; wb.epilogue = WIDE_STORE;
+          wb.C = w.Pc;
+          if (int rc = wide_product_launch(wb, s)) return rc;
+          done = true;
+        }
+      }
+      if (!done) {
+        GemmParams<T> g4;
+        g4.A = w.LuN; g4.lda = Mp; g4.sA0 = mm;
+        g4.B = w.Pc; g4.ldb = ncp; g4.sB0 = Mp * ncp;
+        g4.C = b.Kc; g4.ldc = ncp; g4.sC0 = Mp * ncp;
+        g4.nb0 = L32; g4.mt = (int)pl.nblk; g4.nt = nt; g4.K = (int)Mp; g4.flags = GF_A_LOWER | GF_GROUP_COLS;
+        g4.super_cols = sched_plain.cols; g4.colscale = w.csc; g4.colvec = w.gmc; g4.sCs = ncp; g4.rowvec = b.muE; g4.sRv = Mp;
+        g4.aux = Wc; g4.ncols = ncp;
+        if (int rc = gemm_launch(g4, EPI_WBAR, s)) return rc;
+        // Kbar_x = Linv^T Wbar                                   (into the Pbar buffer)
+        GemmParams<T> g5;
+        g5.A = w.LinvT; g5.lda = Mp; g5.sA0 = mm;
+        g5.B = b.Kc; g5.ldb = ncp; g5.sB0 = Mp * ncp;
+        g5.C = w.Pc; g5.ldc = ncp; g5.sC0 = Mp * ncp;
+        g5.nb0 = L32; g5.mt = (int)pl.nblk; g5.nt = nt; g5.K = (int)Mp; g5.flags = GF_A_UPPER | GF_GROUP_COLS;
+        g5.super_cols = sched_plain.cols;
+        if (int rc = gemm_launch(g5, EPI_STORE, s)) return rc;
+      }
       // GL += Kbar_x W^T  (lower tiles):  dLoss/dL = -tril(GL)
       GemmParams<T> g6 = g3;
       g6.A = w.Pc; g6.B = Wc; g6.C = w.GL;
-      if (int rc = gemm_launch(g6, EPI_STORE, s)) return rc;
+      if (wide_nt) {
+        if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(w.Pc, Wc, w.GL, Mp, ncp, L32, s)) return rc; }
+      } else if (int rc = gemm_launch(g6, EPI_STORE, s)) return rc;
       // kernel hyper-parameter and Z gradients from Kbar_x
       KgradArgs ka;
       ka.Kbar = w.Pc; ka.ld = ncp; ka.stride = Mp * ncp; ka.Z = p->Z; ka.X = Xc;
@@ -1293,7 +1342,9 @@ static int precomputed_backward_t(const void* W, const void* sigma, const void* 
     g3.C = w.G; g3.ldc = Mp; g3.sC0 = mm;
     g3.nb0 = L32; g3.mt = g3.nt = (int)pl.nblk; g3.K = (int)ncp; g3.flags = GF_B_TRANS | GF_TILES_LOWER;
     g3.alpha = 1; g3.beta = 1;
-    if (int rc = gemm_launch(g3, EPI_STORE, s)) return rc;
+    if (sizeof(T) == 4 && wide_nt_supported(Mp, ncp)) {
+      if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(b.Wc, w.Pc, w.G, Mp, ncp, L32, s)) return rc; }
+    } else if (int rc = gemm_launch(g3, EPI_STORE, s)) return rc;
     hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Wc, Mp, ncp,
                        static_cast<const T*>(g_mean), N, n0, w.mu_part, pl.nchunks, ci);
     GPZ_LAUNCH_OK();

@@ -457,7 +457,8 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
 @_on_device
 def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
                   gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0, cache: Optional[FactorCache] = None,
-                  kernel_grads: bool = False, g_chol=None, wt_cache=None, g_kl=None, trust_cache: bool = False):
+                  kernel_grads: bool = False, g_chol=None, wt_cache=None, g_kl=None, trust_cache: bool = False,
+                  narrow_tiles: bool = False):
     """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) (gpz_svgp_backward); with ``kernel_grads`` also
     dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64.
     ``wt_cache``: the buffer a forward pass on the same inputs and ``chunk`` returned under "wt_cache".
@@ -475,6 +476,8 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, whitened, gX, gZ, clamp_min, keep)
     info = torch.empty(L, dtype=torch.int32, device=dev)
     p.info = info.data_ptr()
+    if narrow_tiles:                 # the 128 x 128-tile kernel for the fp32 products (csrc/gemm.hip), as in round 2
+        p.flags |= _lib.SVGP_NARROW_TILES
     g = _lib.SvgpGrads()
     gm = g_mean.detach().to(dt).reshape(L, N).contiguous()
     gs = g_scale.detach().to(dt).reshape(L, N).contiguous()
@@ -618,6 +621,8 @@ def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, id
     p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, False, None, None, clamp_min, keep)
     info = torch.empty(L, dtype=torch.int32, device=dev)
     p.info = info.data_ptr()
+    if narrow_tiles:                 # the 128 x 128-tile kernel for the fp32 products (csrc/gemm.hip), as in round 2
+        p.flags |= _lib.SVGP_NARROW_TILES
     g = _lib.SvgpGrads()
     gm = g_mean.detach().to(dt).reshape(L, N).contiguous()
     gs = g_scale.detach().to(dt).reshape(L, N).contiguous()

@@ -89,3 +89,26 @@ def test_generated_operand_does_not_read_the_kzx_buffer():
     nwt = 2 * 1024 * 6016
     assert torch.equal(a["wt_cache"].view(torch.int32)[:nwt], b["wt_cache"].view(torch.int32)[:nwt])
     assert torch.isfinite(b["mean"]).all() and torch.isfinite(b["scale"]).all()
+
+
+@pytest.mark.parametrize("whitened", [True, False])
+@pytest.mark.parametrize("N,M,L,retain", [(5000, 640, 2, True), (5000, 640, 2, False), (3000, 1024, 1, True), (2000, 384, 3, False)])
+def test_backward_wide_matches_narrow(N, M, L, retain, whitened):
+    """The backward pass's fp32 products on the wide kernels (W = Linv Kzx, Pbar with the column scale, Wbar, Kbar_x and the
+    two A B^T accumulations over the N-chunk) against the 128 x 128-tile kernel: every gradient agrees to fp32 rounding
+    (the k order is the same; only the column statistics of a recomputed W are summed in a different order)."""
+    from gpzoo_amd import ops
+    c, g, spec, extra = _problem(3, N, M, L, 2)
+    out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], whitened, want_Lu=False,
+                           retain_wt=0.9 if retain else 0.0, **extra)
+    gen = torch.Generator().manual_seed(5)
+    gm = torch.randn(out["mean"].shape, generator=gen).cuda()
+    gs = torch.randn(out["scale"].shape, generator=gen).cuda()
+    res = {}
+    for narrow in (True, False):
+        res[narrow] = ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], whitened, gm, gs, out["scale"],
+                                        kernel_grads=True, wt_cache=out.get("wt_cache"), narrow_tiles=narrow, **extra)
+    for a, b, what in zip(res[True], res[False], ("grad_mu", "grad_Lu", "grad_theta", "grad_Z")):
+        a, b = a.double(), b.double()
+        assert torch.isfinite(b).all(), what
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-5 * float(a.abs().max()), msg=lambda m: f"{what}: {m}")
