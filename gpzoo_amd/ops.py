@@ -621,8 +621,6 @@ def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, id
     p, (L, M, N, dt, dev, deps) = _problem(spec, X, Z, mu, Lu_raw, jitter, False, None, None, clamp_min, keep)
     info = torch.empty(L, dtype=torch.int32, device=dev)
     p.info = info.data_ptr()
-    if narrow_tiles:                 # the 128 x 128-tile kernel for the fp32 products (csrc/gemm.hip), as in round 2
-        p.flags |= _lib.SVGP_NARROW_TILES
     g = _lib.SvgpGrads()
     gm = g_mean.detach().to(dt).reshape(L, N).contiguous()
     gs = g_scale.detach().to(dt).reshape(L, N).contiguous()
