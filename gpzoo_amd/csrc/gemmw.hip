@@ -5,21 +5,23 @@
 //
 // One kernel template, two instantiations of its tile:
 //   * B from memory (stage 2; stage 1 of kernels the generator below does not cover): 256 x 128 tile;
-//   * B GENERATED (stage 1, fp32 RBF / Matern-3/2 on 1-D / 2-D inputs): 512 x 64 tile whose 16 x 64 slice of Kzx is
-//     computed by the workgroup itself, ONCE, from the Z block in LDS and each lane's own column -- Kzx is never
+//   * B GENERATED (stage 1, fp32 RBF / Matern-3/2 on 1-D / 2-D inputs): 512 x 128 tile, 16 waves, whose 16 x 128 slice of
+//     Kzx is computed by the workgroup itself, ONCE, from the Z block in LDS and each lane's own columns -- Kzx is never
 //     written to HBM (the reference and the two-kernel path move 52 GB of it per evaluation at N=200k, M=2048, L=32).
 //     On gfx950 the f32 MFMA runs at the vector rate and vector instructions do NOT issue in its shadow (measured:
 //     every VALU instruction added to the loop costs its own ~4-8 issue cycles of MFMA time, pinned interleaving or
 //     not), so the covariance arithmetic is a tax proportional to (values per workgroup step) / (MFMAs per step)
 //     = 16 / rows of the tile: generated per wave in registers for a 128-row wave tile it cost 19 %, shared through
-//     LDS by 512 rows it costs 4 %.
+//     LDS by 512 rows it costs 4 % -- to which a 1024-thread workgroup adds 3.5 % of barrier time (all four waves of a
+//     SIMD belong to it and meet at every step), so this path stays 3.6 % behind the fill + 256 x 128 product and is
+//     selectable, not the default.
 //
-// Common structure: 8 waves, wave tile 128 x 32 (16 accumulator tiles of v_mfma_f32_16x16x4_f32), k staged 16 deep.
+// Common structure: 8 (16) waves, wave tile 128 x 32 (16 accumulator tiles of v_mfma_f32_16x16x4_f32), k staged 16 deep.
 // Both operand tiles reach LDS by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write, no vector address
 // arithmetic: descriptor + constant per-lane offset + scalar offset); A sits [row][16 k] with its four 16-byte chunks
 // permuted per row so that the ds_read_b128 fragment reads are conflict-free, B sits [k][n] in 1-KB pieces 32 / 64
 // bytes apart so that the k and k + 4 rows a half-wave reads fall on disjoint banks.  Double buffered, one barrier per
-// 16-deep step, <= 128 VGPRs and <= 74 KB of LDS: two workgroups per CU.  Triangular A: a wave skips the steps in
+// 16-deep step, <= 128 VGPRs; 50 KB of LDS and two workgroups per CU (from memory), 84 KB and one (generated).  Triangular A: a wave skips the steps in
 // which its 128 rows are zero and, inside its diagonal 128-block, the 16-row sub-tiles that are -- as straight-line
 // phases with compile-time ranges (hipcc copies accumulators around MFMAs that sit under run-time branches).  (Dealing
 // the rows to the row-waves in interleaved 16-row sub-tiles, so that every wave sees the same k range, was built and
@@ -84,10 +86,11 @@ struct WLds {
 };
 
 template <int TM, int TN, int BSRC, int ATRI, int EPI, int KIND, int D>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_kernel(const WParams p) {
+__global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_kernel(const WParams p) {
   constexpr int BK = W_BK;
   constexpr int WMW = TM / 128, WNW = TN / 32;          // waves along rows / columns
-  static_assert(WMW * WNW == 8, "eight waves of 128 x 32");
+  constexpr int NW = WMW * WNW;                         // waves: 8 (256 x 128, from memory) or 16 (512 x 128, generated)
+  static_assert(NW == 8 || NW == 16, "8 or 16 waves of 128 x 32");
   using G = WLds<TM, TN, BSRC, D>;
   constexpr int RPP = G::RPP, PITCH = G::PITCH;
   extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   // ---------------- staging: LDS-DMA ----------------
   typedef __attribute__((address_space(3))) void lds_void;
-  constexpr int NPA = TM / 128;                 // 1-KB pieces (16 rows x 64 B) of the A tile per wave
+  constexpr int NPA = TM / (16 * NW);           // 1-KB pieces (16 rows x 64 B) of the A tile per wave
 #if defined(__HIP_DEVICE_COMPILE__)   // gfx950 builtins: the host pass of this single-source file only needs the kernel's stub
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.A + b0 * p.sA0), 0, (int)(p.lda * Mp * sizeof(float)), 0x00020000);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       a_soff[h] += BK * (int)sizeof(float);
     }
     if constexpr (BSRC == WB_MEM) {
-      static_assert(BSRC != WB_MEM || W_BK / RPP == 8, "one B piece per wave");
+      static_assert(BSRC != WB_MEM || (W_BK / RPP == 8 && NW == 8), "one B piece per wave");
       __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sB(buf) + wave * PITCH), 16, b_voff, b_soff, 0, 0);
       b_soff += BK * (int)p.ldb * (int)sizeof(float);
     }
@@ -212,8 +215,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   };
   auto b_generate = [&](int buf, int step) __attribute__((always_inline)) {   // step: index of the 16-deep step from k = 0
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kk = wave + 8 * i, kg = step * BK + kk;
+    for (int i = 0; i < BK / NW; ++i) {
+      const int kk = wave + NW * i, kg = step * BK + kk;
       const float* zp = sZ + ((kg >> 7) & 1) * G::ZB + (kg & 127) * D;
       float z[D];
 #pragma unroll
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 // ---------------- host side ----------------
 template <typename K>
-static int launch_wide(K kernel, size_t lds, const WParams& p, int64_t nblocks, hipStream_t s) {
+static int launch_wide(K kernel, size_t lds, const WParams& p, int64_t nblocks, hipStream_t s, int threads = 512) {
   // dynamic LDS above 64 KB is an opt-in per kernel function and device (a handful of instantiations: linear search)
   struct Seen { const void* fn; int dev; };
   static Seen seen[64];
@@ -599,7 +602,7 @@ static int launch_wide(K kernel, size_t lds, const WParams& p, int64_t nblocks, 
     }
   }
   GPZ_REQUIRE(nblocks > 0 && nblocks < (1ll << 31), "wide product: bad grid");
-  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(512), lds, s, p);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3((unsigned)threads), lds, s, p);
   GPZ_LAUNCH_OK();
   return 0;
 }
@@ -612,7 +615,7 @@ int fused1_launch(const Fused1Args& a, hipStream_t s) {
   GPZ_REQUIRE(fused1_supported(GPZ_F32, a.kind, a.d), "fused stage 1: kind=%d d=%d unsupported", a.kind, a.d);
   GPZ_REQUIRE(a.Mp % 128 == 0 && a.ncp % 128 == 0 && a.Mp > 0 && a.ncp > 0 && a.L > 0, "fused stage 1: bad extents");
   GPZ_REQUIRE(a.Mp * a.Mp * 4 < (1ll << 31) && a.M * a.d * 4 < (1ll << 31), "fused stage 1: M too large");
-  constexpr int TM = 512, TN = 64;
+  constexpr int TM = 512, TN = 128;           // 16 waves (1024 threads), one workgroup per CU
   WParams p = {};
   p.A = a.Linv; p.lda = a.Mp; p.sA0 = a.Mp * a.Mp;
   p.Z = a.Z; p.MD = a.M * a.d; p.M = a.M;
@@ -624,7 +627,7 @@ int fused1_launch(const Fused1Args& a, hipStream_t s) {
   p.L = a.L; p.nblk = (int)(a.Mp / 128); p.mtw = (int)((a.Mp + TM - 1) / TM); p.nt = (int)(a.ncp / TN);
   // strips of W column tiles: wide enough to share a row panel in L2 (one XCD holds 64 workgroups), numerous enough that
   // every level of row tiles gives each XCD work
-  int strips = (p.nt + 63) / 64;
+  int strips = (p.nt + 31) / 32;              // one XCD holds 32 of these workgroups
   const int want = (32 + p.mtw * p.L - 1) / (p.mtw * p.L);
   if (strips < want) strips = want < p.nt ? want : p.nt;
   p.W = (p.nt + strips - 1) / strips;
@@ -632,7 +635,7 @@ int fused1_launch(const Fused1Args& a, hipStream_t s) {
   const int64_t units = (int64_t)p.mtw * p.L * p.strips;
   const int64_t nblocks = (units + 7) / 8 * 8 * p.W;
 #define GPZ_W1(KIND, D) return launch_wide(gemmw_kernel<TM, TN, WB_GEN, WA_LOWER, WE_STORE_STATS, KIND, D>, \
-                                           WLds<TM, TN, WB_GEN, D>::bytes, p, nblocks, s)
+                                           WLds<TM, TN, WB_GEN, D>::bytes, p, nblocks, s, 1024)
   if (a.kind == GPZ_KERNEL_MATERN32) { if (a.d == 2) GPZ_W1(1, 2); GPZ_W1(1, 1); }
   if (a.d == 2) GPZ_W1(0, 2);
   GPZ_W1(0, 1);

@@ -2,7 +2,7 @@
 
   narrow + kfill   kfill_kernel, then gemm128_kernel for both products (the path of round 2 and of every other precision)
   wide + kfill     kfill_kernel, then gemmw_kernel<256,128,mem> for both products (the default)
-  generated        gemmw_kernel<512,64,gen>: stage 1 computes its covariance operand itself, Kzx is never written
+  generated        gemmw_kernel<512,128,gen> (16 waves): stage 1 computes its covariance operand itself, Kzx is never written
 
 cov.h is shared by the fill and the generator and all three kernels give lane group q the k = 4q..4q+3 slots of a
 16-deep chunk, so Wt must agree BIT FOR BIT; the column statistics are summed in different orders, so mean / scale /
