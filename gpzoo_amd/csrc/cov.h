@@ -1,5 +1,5 @@
 // cov.h -- fp32 covariance of one (point, point) pair, shared by the stand-alone fill (kfill.hip) and by the
-// stage-1 product that generates its Kzx operand in registers (fused1.hip): one definition, explicit
+// stage-1 product that generates its Kzx operand itself (gemmw.hip, WB_GEN): one definition, explicit
 // operation order, no contraction left to the compiler, so both paths produce the same bits.
 //
 // Replaces the element-wise part of kernels.py:14-30 (Matern-3/2) and :42-58 / :118-130 (RBF).

@@ -33,7 +33,7 @@
 
 #include "cov.h"
 
-#include <cstdlib>
+
 #include <mutex>
 #include <type_traits>
 

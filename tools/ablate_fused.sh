@@ -1,6 +1,6 @@
 #!/bin/bash
-# Build timing variants of the fused stage-1 kernel (csrc/gemmw.hip) as gpzoo_amd/libgpzoo_hip_<tag>.so; select one with
-# GPZ_HIP_LIB=<path>.   Usage: tools/ablate_fused.sh tag1:"-DGPZ_W_ABL=1" tag2:"-DGPZ_F1_WPE=2" ...
+# Build timing variants of the wide-tile kernels (csrc/gemmw.hip) as gpzoo_amd/libgpzoo_hip_<tag>.so; select one with
+# GPZ_HIP_LIB=<path>.   Usage: tools/ablate_fused.sh tag1:"-DGPZ_W_ABL=1" tag2:"-DGPZ_W_ABL=7" ...
 # -DGPZ_W_ABL builds give WRONG results by construction: they only tell what the MFMA pipes wait for.
 set -e
 cd "$(dirname "$0")/.."

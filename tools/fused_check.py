@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fused stage 1 (csrc/fused1.hip) against the two-kernel path (kfill + gemm128) on the GPU box.
+"""The three forward kernel paths (csrc/gemmw.hip wide tiles from memory, generated operand; csrc/gemm.hip narrow tiles) on the GPU box.
 
     python3 tools/fused_check.py            # parity over a set of shapes, then timing at config 3
 
