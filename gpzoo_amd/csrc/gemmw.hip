@@ -661,7 +661,12 @@ int wide_product_launch(const WideArgs& a, hipStream_t s) {
   // config 3 (evaluation ms, stage 1 / stage 2 TF): 8 columns 391.0, 141.1 / 145.7 (L2 -> fabric 23.2 GB per stage-1
   // launch); 16 columns 386.7, 142.8 / 147.4 (17.8 GB); 24: 386.1; 32: 384.2, 143.7 / 148.5; 48: 385.8
   constexpr int WMAX = 32;
-  const int strips = (p.nt + WMAX - 1) / WMAX;
+  int strips = (p.nt + WMAX - 1) / WMAX;
+  // ... but at least 8 units where the problem has that many column tiles: with fewer units than XCDs part of the chip
+  // sits idle (N=3000, M=3000, L=4 as one 24-column strip per latent = 4 units: 61 TF; two strips = 8 units: 122 TF;
+  // four strips = 16 units: 108 TF, narrower strips share each A panel among fewer workgroups)
+  const int want = (8 + p.L - 1) / p.L;
+  if (strips < want) strips = want < p.nt ? want : p.nt;
   p.W = (p.nt + strips - 1) / strips;
   p.strips = (p.nt + p.W - 1) / p.W;
   const int64_t units = (int64_t)p.L * p.strips;

@@ -112,3 +112,36 @@ def test_backward_wide_matches_narrow(N, M, L, retain, whitened):
         a, b = a.double(), b.double()
         assert torch.isfinite(b).all(), what
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-5 * float(a.abs().max()), msg=lambda m: f"{what}: {m}")
+
+
+def test_full_benchmark_size_paths_agree():
+    """BASELINE configs[2] at its full size (N=200 000, M=2048, L=32, 17 chunks): the retained Wt (its 16 full chunks) of the default path, of
+    the generated-operand path and of the 128 x 128-tile path (52 GB each) have the same bits -- compared through a 64-bit
+    sum and an xor-fold of their int32 views -- and q(F) / the ELBO agree to fp32 rounding."""
+    from gpzoo_amd import ops
+    c, g, spec, extra = _problem(3, 200_000, 2048, 32, 2)
+
+    def digest(**kw):
+        out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
+                               noise_sd=c["noise_sd"], want_Lu=False, retain_wt=0.6, **extra, **kw)
+        assert "wt_cache" in out
+        w = out.pop("wt_cache").view(torch.int32)
+        nfull = 200_000 // 12_288                               # the 16 full chunks (the last slot is only partly written)
+        nwt = nfull * 32 * 2048 * 12_288                        # their Wt slots; the column-sum slabs behind them differ in order
+        w = w[:nwt].view(-1, 1 << 20)
+        s = int(w.sum(dim=1, dtype=torch.int64).sum())
+        x = w[:, 0].clone()
+        for j in range(1, 64):
+            x ^= w[:, j * 1000]
+        res = (s, int(x.sum(dtype=torch.int64)), out["mean"], out["scale"], float(out["elbo"]))
+        del w, out
+        torch.cuda.empty_cache()
+        return res
+
+    ref = digest(materialize_kzx=True, narrow_tiles=True)
+    for kw in (dict(), dict(materialize_kzx=False)):
+        got = digest(**kw)
+        assert got[0] == ref[0] and got[1] == ref[1], kw
+        torch.testing.assert_close(got[2], ref[2], rtol=1e-5, atol=1e-5 * float(ref[2].abs().max()))
+        torch.testing.assert_close(got[3], ref[3], rtol=1e-5, atol=0)
+        assert got[4] == pytest.approx(ref[4], rel=1e-7)
