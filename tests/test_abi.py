@@ -95,3 +95,15 @@ def test_library_carries_the_hash_of_its_sources(monkeypatch):
     monkeypatch.setattr(build, "source_hash", lambda: None)
     assert _lib.load() is not None
     monkeypatch.setattr(_lib, "_lib", None)
+
+
+def test_flag_constants_match_the_header():
+    """The Python mirror of gpz_svgp_problem.flags carries the header's values."""
+    from gpzoo_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "gpzoo_hip.h")).read()
+    vals = {n: int(v) for n, v in re.findall(r"#define\s+(GPZ_SVGP_[A-Z_]+)\s+(\d+)", hdr)}
+    assert vals == {"GPZ_SVGP_MATERIALIZE_KZX": _lib.SVGP_MATERIALIZE_KZX, "GPZ_SVGP_NARROW_TILES": _lib.SVGP_NARROW_TILES,
+                    "GPZ_SVGP_GENERATE_KZX": _lib.SVGP_GENERATE_KZX}
+    assert len(set(vals.values())) == 3 and all(v & (v - 1) == 0 for v in vals.values())     # distinct single bits
+    fields = dict(_lib.SvgpProblem._fields_)
+    assert "flags" in fields and ctypes.sizeof(fields["flags"]) == 4
