@@ -37,6 +37,12 @@ from bench import gemm_source_hash  # noqa: E402
 out = {"kernel": stage1, "gemm_src_sha16": gemm_source_hash(), "workload": {"config": 3, "N": N, "M": M, "L": L, "chunk": 0, "launches_per_eval": launches},
        "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"],
        "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
+       # the x2 of the gfx950 note is calibrated on 16-byte-per-lane reads that form 128-byte requests; the wide kernel's A
+       # tiles are read as 64-byte row segments (three quarters of its L2 requests: TCC_HIT + TCC_MISS = A bytes / 64 +
+       # B bytes / 128 + written bytes / 128), for which the counter may already be exact -- so the figure above is an
+       # upper bound and this one the lower bound
+       "hbm_bytes_per_launch_undoubled": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
+       "l2_requests_per_launch": v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0),
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), averaged over "
                "the dispatches of `python3 bench.py --steps 2 --warmup 1`; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                "(gfx950 reports half the bytes of wide coalesced reads); counts L2->fabric requests, Infinity-Cache hits included",
