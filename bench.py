@@ -392,14 +392,14 @@ def main():
         Mp = (M + 127) // 128 * 128
         ms1, n1 = prof["stage1"]
         ms2, n2 = prof["stage2"]
-        # dominant kernel: Wt = Linv * Kzx, one launch per N-chunk -- fp32: gemmw_kernel (256 x 128 tiles, csrc/gemmw.hip),
+        # dominant kernel: Wt = Linv * Kzx, one launch per N-chunk -- fp32: gemmw_kernel (128 x 256 tiles, csrc/gemmw.hip),
         # fp64: gemm128_kernel<T,NN,store+colstats>.  algorithmic flops = L * M^2 * N per evaluation (SURVEY §8d TRSM count).
         flops1 = Lper * float(M) * M * N * a.steps
         ach1 = flops1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
         mp = measured_peaks()
         traffic, traffic_src = pmc_traffic(cfg_id, N, M, Lper, a.chunk)
         roof = {"bound": "mfma",
-                "kernel": ("gemmw_kernel<256,128,mem,lower,store+colstats> (Wt = Linv*Kzx, csrc/gemmw.hip)" if dname == "f32"
+                "kernel": ("gemmw_kernel<128,256,mem,lower,store+colstats> (Wt = Linv*Kzx, csrc/gemmw.hip)" if dname == "f32"
                            else "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx)" % dname),
                 "achieved": ach1, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach1 / PEAK[dname],
                 "traffic": traffic, "traffic_source": traffic_src, "launches": n1,

@@ -20,7 +20,7 @@ struct Fused1Args {
 bool fused1_supported(int dtype, int kind, int d);
 int fused1_launch(const Fused1Args& a, hipStream_t s);
 
-// Triangular A (L, Mp, Mp) times dense B (L, Mp, ncp) from memory, fp32, on 256 x 128 tiles:
+// Triangular A (L, Mp, Mp) times dense B (L, Mp, ncp) from memory, fp32, on 128 x 256 tiles:
 enum WideEpilogue {
   WIDE_STORE_STATS = 0,     // lower A: C = A B stored, plus colsum(C^2) and mu^T C per 128-row block          (forward stage 1)
   WIDE_STATS = 1,           // upper A: colsum((A B)^2) per 128-row block, nothing stored                       (forward stage 2)

@@ -4,7 +4,13 @@
 //   stage 2  colsum((LuE^T Wt)^2) (gp.py:280-296 / utilities.py:382-397)                            A upper triangular
 //
 // One kernel template, two instantiations of its tile:
-//   * B from memory (stage 2; stage 1 of kernels the generator below does not cover): 256 x 128 tile;
+//   * B from memory (stage 2; stage 1 of every kernel by default): 128 x 256 tile, 8 waves side by side.  Every wave of
+//     the workgroup owns the same 128 rows, so all of them see the same k range of the triangular operand: no wave idles
+//     while another finishes (a 256 x 128 tile of two row-waves, the first form of this kernel, left one of them idle for
+//     8 steps per tile -- a quarter of all wave-steps at M = 512: configs[1] stage 1 118 -> 123 TF, stage 2 128 -> 131.5;
+//     config 3 142.3 -> 142.6 / 150.4 -> 151.1, same box, both forms timed back to back).  A workgroup runs TWO row tiles
+//     of its column tile, the pi-th longest and the pi-th shortest k range, so every workgroup of a launch executes the
+//     same number of steps; the second tile's first operand tiles are fetched during the first tile's last step.
 //   * B GENERATED (stage 1, fp32 RBF / Matern-3/2 on 1-D / 2-D inputs): 512 x 128 tile, 16 waves, whose 16 x 128 slice of
 //     Kzx is computed by the workgroup itself, ONCE, from the Z block in LDS and each lane's own columns -- Kzx is never
 //     written to HBM (the reference and the two-kernel path move 52 GB of it per evaluation at N=200k, M=2048, L=32).
@@ -13,19 +19,19 @@
 //     not), so the covariance arithmetic is a tax proportional to (values per workgroup step) / (MFMAs per step)
 //     = 16 / rows of the tile: generated per wave in registers for a 128-row wave tile it cost 19 %, shared through
 //     LDS by 512 rows it costs 4 % -- to which a 1024-thread workgroup adds 3.5 % of barrier time (all four waves of a
-//     SIMD belong to it and meet at every step), so this path stays 3.6 % behind the fill + 256 x 128 product and is
+//     SIMD belong to it and meet at every step), so this path stays behind the fill + product from memory and is
 //     selectable, not the default.
 //
 // Common structure: 8 (16) waves, wave tile 128 x 32 (16 accumulator tiles of v_mfma_f32_16x16x4_f32), k staged 16 deep.
 // Both operand tiles reach LDS by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write, no vector address
 // arithmetic: descriptor + constant per-lane offset + scalar offset); A sits [row][16 k] with its four 16-byte chunks
-// permuted per row so that the ds_read_b128 fragment reads are conflict-free, B sits [k][n] in 1-KB pieces 32 / 64
-// bytes apart so that the k and k + 4 rows a half-wave reads fall on disjoint banks.  Double buffered, one barrier per
-// 16-deep step, <= 128 VGPRs; 50 KB of LDS and two workgroups per CU (from memory), 84 KB and one (generated).  Triangular A: a wave skips the steps in
+// permuted per row so that the ds_read_b128 fragment reads are conflict-free, B sits [k][n] in 1-KB pieces 16 / 32
+// bytes apart so that the four k rows one ds_read_b32 touches fall on disjoint banks.  Double buffered, one barrier per
+// 16-deep step, <= 128 VGPRs; 50 KB of LDS and two workgroups per CU (from memory), 84 KB and one (generated).  The DMA
+// is never what a step waits for (a timing build that issues the loads and never waits for them runs at the same
+// speed); what the loads cost (4-5 %: the build without them) is their traffic.  Triangular A: a wave skips the steps in
 // which its 128 rows are zero and, inside its diagonal 128-block, the 16-row sub-tiles that are -- as straight-line
-// phases with compile-time ranges (hipcc copies accumulators around MFMAs that sit under run-time branches).  (Dealing
-// the rows to the row-waves in interleaved 16-row sub-tiles, so that every wave sees the same k range, was built and
-// measured: bitwise the same results, stage 1 unchanged, stage 2 1 % slower -- the contiguous blocks stay.)
+// phases with compile-time ranges (hipcc copies accumulators around MFMAs that sit under run-time branches).
 //
 // Values, k order and MFMA order equal those of kfill.hip + gemm128_kernel (cov.h is shared; lane group q owns
 // k = 4q .. 4q+3 of a 16-deep chunk in both), so Wt is bitwise the same on either path.
@@ -39,7 +45,7 @@
 
 // Timing-only diagnostics (WRONG results by construction; tools/ablate_fused.sh builds them next to the real library):
 // -DGPZ_W_ABL=<bits>  1: no covariance arithmetic (the generated B tile holds a coordinate), 2: no tile loads after the
-// first, 4: no epilogue (statistics, Wt store), 8: no per-step barrier.
+// first, 4: no epilogue (statistics, Wt store), 8: no per-step barrier, 16: tile loads issued but never waited for.
 #ifndef GPZ_W_ABL
 #define GPZ_W_ABL 0
 #endif
@@ -78,7 +84,8 @@ template <int TM, int TN, int BSRC, int D>
 struct WLds {
   static constexpr int A_ELEMS = TM * W_BK;
   static constexpr int RPP = 256 / TN;                        // k rows per 1-KB piece of the B tile
-  static constexpr int PITCH = 256 + (RPP == 2 ? 8 : 16);     // floats between pieces: rows k and k + 4 shift by 16 banks
+  // floats between pieces: the k rows j, j + 4, j + 8, j + 12 one ds_read_b32 touches must fall 16 banks apart
+  static constexpr int PITCH = 256 + (RPP == 2 ? 8 : RPP == 1 ? 4 : 16);
   static constexpr int B_ELEMS = (W_BK / RPP) * PITCH;
   static constexpr int STAGE = A_ELEMS + B_ELEMS;
   static constexpr int ZB = 128 * D;                          // WB_GEN: one 128-point block of Z per buffer
@@ -89,7 +96,7 @@ template <int TM, int TN, int BSRC, int ATRI, int EPI, int KIND, int D>
 __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_kernel(const WParams p) {
   constexpr int BK = W_BK;
   constexpr int WMW = TM / 128, WNW = TN / 32;          // waves along rows / columns
-  constexpr int NW = WMW * WNW;                         // waves: 8 (256 x 128, from memory) or 16 (512 x 128, generated)
+  constexpr int NW = WMW * WNW;                         // waves: 8 (128 x 256, from memory) or 16 (512 x 128, generated)
   static_assert(NW == 8 || NW == 16, "8 or 16 waves of 128 x 32");
   using G = WLds<TM, TN, BSRC, D>;
   constexpr int RPP = G::RPP, PITCH = G::PITCH;
@@ -100,13 +107,16 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
   float* const sZ = smem + 2 * G::STAGE;       // WB_GEN: [2][ZB], inducing points of the 128-blocks (parity of the block)
   auto addrB = [](int k, int n) { return (k / RPP) * PITCH + (k % RPP) * TN + n; };
 
-  // ---------------- tile decode ----------------
+  // ---------------- workgroup decode ----------------
   // Blocks b, b + 8, ... run on one XCD (round-robin dispatch) and share its L2.
   // WB_GEN: the only operand in memory is A.  A unit = (row tile, latent, strip of W column tiles): its W workgroups
   //   stream one Linv row panel together; units go longest k range first, each level spread evenly over the XCDs.
-  // WB_MEM: a unit = (latent, strip of W column tiles): inside it row tiles go longest k range first and the W workgroups
-  //   of a row tile are dispatched together, so they walk the same A panel in lock-step over the strip's B panels.
-  int ti, tj, b0;
+  // WB_MEM: a unit = (latent, strip of W column tiles).  A workgroup takes TWO row tiles of one column tile, the
+  //   pi-th longest and the pi-th shortest k range (a middle tile of an odd count alone): every workgroup of the launch
+  //   then runs the same number of steps -- no tail of short tiles, no ordering to get right -- and the second tile's
+  //   first operand tiles travel while the first tile's epilogue runs.  The W workgroups of a pair are dispatched
+  //   together, so they walk the same two A panels in lock-step over the strip's B panels.
+  int tj, b0, leg_ti[2], nlegs = 1;
   {
     const int bid = blockIdx.x;
     const int x = bid & 7, s = bid >> 3;
@@ -116,34 +126,30 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
       const int per_level = p.L * p.strips;
       if (u >= p.mtw * per_level) return;
       const int level = u / per_level, rem = u - level * per_level;
-      ti = (ATRI == WA_LOWER) ? p.mtw - 1 - level : level;
+      leg_ti[0] = leg_ti[1] = (ATRI == WA_LOWER) ? p.mtw - 1 - level : level;
       b0 = rem / p.strips;
       tj = (rem - b0 * p.strips) * p.W + within;
     } else {
-      const int per_unit = p.mtw * p.W;
+      const int per_unit = ((p.mtw + 1) >> 1) * p.W;
       const int u = (s / per_unit) * 8 + x, within = s % per_unit;
       if (u >= p.L * p.strips) return;
       b0 = u / p.strips;
-      const int ii = within / p.W;
+      const int pi = within / p.W, far = p.mtw - 1 - pi;
       tj = (u - b0 * p.strips) * p.W + within % p.W;
-      ti = (ATRI == WA_LOWER) ? p.mtw - 1 - ii : ii;
+      // the longer k range first in one workgroup, last in the one that most likely shares its CU (an XCD's 32 CUs take
+      // 32 consecutive workgroups of its sequence each): their epilogues and thin diagonal steps then do not coincide
+      const bool long_first = ((s >> 5) & 1) == 0;
+      leg_ti[0] = ((ATRI == WA_LOWER) == long_first) ? far : pi;
+      leg_ti[1] = ((ATRI == WA_LOWER) == long_first) ? pi : far;
+      nlegs = far == pi ? 1 : 2;
     }
     if (tj >= p.nt) return;
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // which 128-row block of the tile a wave takes alternates from tile to tile (blocks carry different amounts of work)
-  const int wm = (wave / WNW) ^ ((ti ^ tj) & 1), wn = wave % WNW;
+  const int wn = wave % WNW;
   const int r = lane & 15, q = lane >> 4;
   const int Mp = p.nblk * 128;
-  const int k_begin = (ATRI == WA_UPPER) ? TM * ti : 0;
-  const int k_end = (ATRI == WA_LOWER) ? min(TM * (ti + 1), Mp) : Mp;
-  const int nk = (k_end - k_begin) / BK;
-  const int db = WMW * ti + wm;                 // this wave's 128-row block
-  const bool active = db < p.nblk;              // a block count that is no multiple of WMW leaves the last tile partly empty
-  // steps of this wave: LOWER  [0, n_a) full, [n_a, n_a + 8) diagonal block, rest idle;
-  //                     UPPER  [0, n_a) idle, [n_a, n_a + 8) diagonal block, rest full;   an inactive wave idles throughout
-  const int n_a = 8 * (ATRI == WA_LOWER ? db : wm);
 
   // ---------------- staging: LDS-DMA ----------------
   typedef __attribute__((address_space(3))) void lds_void;
@@ -155,19 +161,14 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
       const_cast<float*>(BSRC == WB_MEM ? p.B + b0 * p.sB0 : p.Z), 0,
       (int)((BSRC == WB_MEM ? p.ldb * Mp : p.MD) * sizeof(float)), 0x00020000);   // reads past the end return zero
 #endif
-  int a_soff[NPA];
-#pragma unroll
-  for (int h = 0; h < NPA; ++h) {
-    int row = ti * TM + (NPA * wave + h) * 16;
-    while (row >= Mp) row -= 128;               // rows past the matrix: re-read valid ones (their waves are inactive)
-    a_soff[h] = (row * (int)p.lda + k_begin) * (int)sizeof(float);
-  }
+  auto k_begin_of = [&](int ti) { return (ATRI == WA_UPPER) ? TM * ti : 0; };
+  auto k_end_of = [&](int ti) { return (ATRI == WA_LOWER) ? min(TM * (ti + 1), Mp) : Mp; };
+  int a_soff[NPA], b_soff = 0;
   // chunk c of row w sits at slot c ^ g(w), g = [0, 2, 3, 1][(w >> 2) & 3]: the 16 lanes of a ds_read_b128 group
   // (rows r, chunk q) then cover sixteen distinct 16-byte slots of the 256-byte bank row
   auto gperm = [](int w) { const int t = (w >> 2) & 3; return (((t >> 1) ^ t) & 1) << 1 | (t >> 1); };
   const int a_voff = ((lane >> 2) * (int)p.lda + (((lane & 3) ^ gperm(lane >> 2)) * 4)) * (int)sizeof(float);
   // B from memory: wave w fetches the 1-KB piece w = k rows 2w, 2w + 1 of the step (TN = 128)
-  int b_soff = ((k_begin + RPP * wave) * (int)p.ldb + tj * TN) * (int)sizeof(float);
   const int b_voff = ((lane / (TN / 4)) * (int)p.ldb + (lane % (TN / 4)) * 4) * (int)sizeof(float);
   bool abl_first = true;
   auto stage_load = [&](int buf) __attribute__((always_inline)) {
@@ -180,11 +181,27 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
       a_soff[h] += BK * (int)sizeof(float);
     }
     if constexpr (BSRC == WB_MEM) {
-      static_assert(BSRC != WB_MEM || (W_BK / RPP == 8 && NW == 8), "one B piece per wave");
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sB(buf) + wave * PITCH), 16, b_voff, b_soff, 0, 0);
+      constexpr int NPB = (W_BK / RPP) / NW;      // 1-KB pieces of the B tile per wave: 1 (TN = 128) or 2 (TN = 256)
+      static_assert(BSRC != WB_MEM || (NPB * NW * RPP == W_BK && NPB >= 1), "whole B pieces per wave");
+#pragma unroll
+      for (int h = 0; h < NPB; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sB(buf) + (wave + NW * h) * PITCH), 16, b_voff,
+                                                 b_soff + h * NW * RPP * (int)p.ldb * (int)sizeof(float), 0, 0);
       b_soff += BK * (int)p.ldb * (int)sizeof(float);
     }
 #endif
+  };
+  // point the DMA at the first step of row tile ti and start it (into buffer 0)
+  auto tile_begin = [&](int ti) __attribute__((always_inline)) {
+    const int kb = k_begin_of(ti);
+#pragma unroll
+    for (int h = 0; h < NPA; ++h) {
+      int row = ti * TM + (NPA * wave + h) * 16;
+      while (row >= Mp) row -= 128;             // rows past the matrix: re-read valid ones (their waves are inactive)
+      a_soff[h] = (row * (int)p.lda + kb) * (int)sizeof(float);
+    }
+    b_soff = ((kb + RPP * wave) * (int)p.ldb + tj * TN) * (int)sizeof(float);
+    stage_load(0);
   };
 
   // ---------------- WB_GEN: the B tile is this workgroup's own slice of Kzx ----------------
@@ -231,13 +248,11 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
   };
 
   f32x4 acc[8][2];
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
 
+  // per row tile ("leg") of this workgroup: which 128-row block the wave takes, its k range, its fragment address
+  int wm = 0, nk = 0, db = 0, n_a = 0, fr_a = 0, step0 = 0, t = 0, next_ti = -1;
+  bool active = false;
   // fragment addresses (floats): lane (r, q) owns k = 4q .. 4q+3 of the 16-deep step
-  const int fr_a = (wm * 128 + r) * BK + ((q ^ gperm(r)) * 4);
   int fr_b[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) fr_b[j] = addrB(4 * q + j, wn * 32 + r);
@@ -274,17 +289,6 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
   // for the DMA, barrier.  Every region below starts at an even t and has an even length (8 steps per 128-block), so the
   // buffer is a compile-time constant per step; no MFMA sits under a run-time branch.
   using std::integral_constant;
-  const int step0 = k_begin / BK;
-  stage_load(0);
-  if constexpr (BSRC == WB_GEN) {
-    z_load(step0 >> 3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    b_generate(0, step0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int t = 0;
   auto step = [&](auto par_c, auto run_c, auto lo_c, auto hi_c) __attribute__((always_inline)) {
     constexpr int P = decltype(par_c)::value;
     if (t + 1 < nk) {
@@ -294,10 +298,20 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
         if ((st & 7) == 0 && (st >> 3) + 1 < p.nblk) z_load((st >> 3) + 1);   // first step of a 128-block: fetch the next block
         b_generate(P ^ 1, st + 1);
       }
+    } else if (next_ti >= 0) {
+      // last step of this row tile (it reads buffer 1; buffer 0 is free since the previous step's barrier): the first
+      // operand tiles of the workgroup's next row tile start now and are waited for with this step's own DMA wait, so
+      // nothing after the epilogue has to wait on the memory counter (which would also wait for the epilogue's stores)
+      tile_begin(next_ti);
     }
     if constexpr (decltype(run_c)::value) mma_step(P, lo_c, hi_c);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(GPZ_W_ABL & 8)) __syncthreads();
+    if (GPZ_W_ABL & 16) {        // timing only: the DMA is issued but never waited for (what a deeper prefetch could hide at most)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(GPZ_W_ABL & 8)) __syncthreads();
+    }
     ++t;
   };
   using no_run = integral_constant<bool, false>;
@@ -319,118 +333,157 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
     else step(integral_constant<int, U & 1>{}, run{}, i0{}, integral_constant<int, U>{});
     if constexpr (U + 1 < 8) self(self, integral_constant<int, U + 1>{});
   };
-  if (!active) {
-    idle_until(nk);
-  } else if constexpr (ATRI == WA_LOWER) {
-    full_until(n_a);
-    diagonal(diagonal, i0{});
-    idle_until(nk);
-  } else {
-    idle_until(n_a);
-    diagonal(diagonal, i0{});
-    full_until(nk);
-  }
 
-  // ---------------- epilogue ----------------
-  if (!active) return;
-  if (GPZ_W_ABL & 4) {         // keep the accumulators alive, store (practically) nothing
-    float sum = 0.f;
+  tile_begin(leg_ti[0]);
+#pragma unroll 1
+  for (int leg = 0; leg < nlegs; ++leg) {
+    const int ti = leg_ti[leg];
+    // which 128-row block of the tile a wave takes alternates from tile to tile (blocks carry different amounts of work)
+    wm = WMW == 1 ? 0 : (wave / WNW) ^ ((ti ^ tj) & 1);
+    const int k_begin = k_begin_of(ti);
+    nk = (k_end_of(ti) - k_begin) / BK;
+    db = WMW * ti + wm;                         // this wave's 128-row block
+    // a block count that is no multiple of WMW leaves the last row tile partly empty, a column count that is no multiple
+    // of TN the last column tile (its operand reads past a row's end land in the next row or, past the matrix, return zero)
+    active = db < p.nblk && (int64_t)tj * TN + wn * 32 < p.ncols;
+    // steps of this wave: LOWER  [0, n_a) full, [n_a, n_a + 8) diagonal block, rest idle;
+    //                     UPPER  [0, n_a) idle, [n_a, n_a + 8) diagonal block, rest full;   an inactive wave idles throughout
+    n_a = 8 * (ATRI == WA_LOWER ? db : wm);
+    fr_a = (wm * 128 + r) * BK + ((q ^ gperm(r)) * 4);
+    step0 = k_begin / BK;
+    t = 0;
+    next_ti = leg + 1 < nlegs ? leg_ti[leg + 1] : -1;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) sum += acc[mi][ni][g];
-    if (sum == 12345.678f) p.ps_sq[0] = sum;
-    return;
-  }
-  const int64_t row0 = (int64_t)db * 128;
-  const int64_t ccol0 = (int64_t)tj * TN + wn * 32;
-  // WB_GEN: rows >= M are padding -- Linv is the identity there, so they picked up k(0, x); the stand-alone path has zeros
-  if (BSRC == WB_GEN && row0 + 128 > p.M) {
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        if (row0 + mi * 16 + 4 * q + g >= p.M) {
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) acc[mi][ni][g] = 0.f;
-        }
-  }
-  // column statistics over this wave's 128 rows = one 128-row block: registers -> lane groups, no workgroup step
-  if constexpr (EPI == WE_STORE_STATS || EPI == WE_STATS) {
-    float ssq[2] = {0.f, 0.f}, smu[2] = {0.f, 0.f};
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-      f32x4 m4 = {0, 0, 0, 0};
-      if constexpr (EPI == WE_STORE_STATS) m4 = *reinterpret_cast<const f32x4*>(p.mu + b0 * p.sMu + row0 + 4 * q + mi * 16);
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const float v = acc[mi][ni][g];
-          ssq[ni] = __builtin_fmaf(v, v, ssq[ni]);
-          if constexpr (EPI == WE_STORE_STATS) smu[ni] = __builtin_fmaf(m4[g], v, smu[ni]);
-        }
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
+    if constexpr (BSRC == WB_GEN) {
+      z_load(step0 >> 3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      b_generate(0, step0);
     }
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      ssq[ni] += __shfl_xor(ssq[ni], 16); ssq[ni] += __shfl_xor(ssq[ni], 32);
-      if constexpr (EPI == WE_STORE_STATS) { smu[ni] += __shfl_xor(smu[ni], 16); smu[ni] += __shfl_xor(smu[ni], 32); }
-      if (q == 0) {
-        const int64_t o = ((int64_t)b0 * p.nblk + db) * p.ncols + ccol0 + ni * 16 + r;
-        p.ps_sq[o] = ssq[ni];
-        if constexpr (EPI == WE_STORE_STATS) p.ps_mu[o] = smu[ni];
-      }
+    // The first operand tiles have landed (leg 0: wait here; later legs: they were waited for in the previous leg's last
+    // step) and every wave is through the previous leg's epilogue, whose strips lie in buffer 1.  A bare barrier behind
+    // the LDS counter: __syncthreads() would also drain the epilogue's global stores.
+    if (leg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!active) {
+      idle_until(nk);
+    } else if constexpr (ATRI == WA_LOWER) {
+      full_until(n_a);
+      diagonal(diagonal, i0{});
+      idle_until(nk);
+    } else {
+      idle_until(n_a);
+      diagonal(diagonal, i0{});
+      full_until(nk);
     }
-  }
-  // output tile: through a wave-private LDS strip (it aliases the tile buffers: every read of them is behind the loop's
-  // last barrier) so each store instruction writes eight whole 128-byte row segments
-  if constexpr (EPI != WE_STATS) {
-    constexpr int LDE = 36;
-    float* strip = smem + wave * (32 * LDE);
-    float* Cg = p.C + b0 * p.sC0 + row0 * p.ldc + ccol0;
-    const int srow = lane >> 3, c4 = (lane & 7) * 4;
-    float cs[2] = {1.f, 1.f};
-    if constexpr (EPI == WE_STORE_COLSCALE) {
+
+    // ---------------- epilogue ----------------
+    if (!active) continue;
+    if (GPZ_W_ABL & 4) {         // keep the accumulators alive, store (practically) nothing
+      float sum = 0.f;
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) cs[ni] = p.colscale[b0 * p.sCs + ccol0 + ni * 16 + r];
-    }
-    f32x4 sc = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
-    if constexpr (EPI == WE_WBAR) {
-      sc = *reinterpret_cast<const f32x4*>(p.colscale + b0 * p.sCs + ccol0 + c4);
-      cv = *reinterpret_cast<const f32x4*>(p.colvec + b0 * p.sCs + ccol0 + c4);
-    }
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-#pragma unroll
-      for (int mm = 0; mm < 2; ++mm)
+      for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) strip[(mm * 16 + 4 * q + g) * LDE + ni * 16 + r] = cs[ni] * acc[pass * 2 + mm][ni][g];
-      __builtin_amdgcn_wave_barrier();
-      f32x4 w[4];
-      float rv[4];
-      if constexpr (EPI == WE_WBAR) {       // every operand of the pass is loaded before its first store (stores may alias)
+          for (int g = 0; g < 4; ++g) sum += acc[mi][ni][g];
+      if (sum == 12345.678f) p.ps_sq[0] = sum;
+      continue;
+    }
+    const int64_t row0 = (int64_t)db * 128;
+    const int64_t ccol0 = (int64_t)tj * TN + wn * 32;
+    // WB_GEN: rows >= M are padding -- Linv is the identity there, so they picked up k(0, x); the stand-alone path has zeros
+    if (BSRC == WB_GEN && row0 + 128 > p.M) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int64_t row = pass * 32 + it * 8 + srow;
-          w[it] = *reinterpret_cast<const f32x4*>(p.aux + b0 * p.sC0 + (row0 + row) * p.ldc + ccol0 + c4);
-          rv[it] = p.rowvec[b0 * p.sRv + row0 + row];
-        }
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (row0 + mi * 16 + 4 * q + g >= p.M) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][g] = 0.f;
+          }
+    }
+    // column statistics over this wave's 128 rows = one 128-row block: registers -> lane groups, no workgroup step
+    if constexpr (EPI == WE_STORE_STATS || EPI == WE_STATS) {
+      float ssq[2] = {0.f, 0.f}, smu[2] = {0.f, 0.f};
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        f32x4 m4 = {0, 0, 0, 0};
+        if constexpr (EPI == WE_STORE_STATS) m4 = *reinterpret_cast<const f32x4*>(p.mu + b0 * p.sMu + row0 + 4 * q + mi * 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const float v = acc[mi][ni][g];
+            ssq[ni] = __builtin_fmaf(v, v, ssq[ni]);
+            if constexpr (EPI == WE_STORE_STATS) smu[ni] = __builtin_fmaf(m4[g], v, smu[ni]);
+          }
       }
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + srow;
-        f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * LDE + c4);
-        if constexpr (EPI == WE_WBAR) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] + rv[it] * cv[e] - w[it][e] * sc[e];
+      for (int ni = 0; ni < 2; ++ni) {
+        ssq[ni] += __shfl_xor(ssq[ni], 16); ssq[ni] += __shfl_xor(ssq[ni], 32);
+        if constexpr (EPI == WE_STORE_STATS) { smu[ni] += __shfl_xor(smu[ni], 16); smu[ni] += __shfl_xor(smu[ni], 32); }
+        if (q == 0) {
+          const int64_t o = ((int64_t)b0 * p.nblk + db) * p.ncols + ccol0 + ni * 16 + r;
+          p.ps_sq[o] = ssq[ni];
+          if constexpr (EPI == WE_STORE_STATS) p.ps_mu[o] = smu[ni];
         }
-        *reinterpret_cast<f32x4*>(Cg + (int64_t)(pass * 32 + row) * p.ldc + c4) = v;
       }
-      __builtin_amdgcn_wave_barrier();
+    }
+    // output tile: through a wave-private LDS strip of one 16-row sub-tile (the strips lie in tile buffer 1: every read of
+    // it is behind the loop's last barrier, and the next leg's DMA has buffer 0) so each store instruction writes eight
+    // whole 128-byte row segments
+    if constexpr (EPI != WE_STATS) {
+      constexpr int LDE = 36;
+      static_assert(NW * 16 * LDE <= G::STAGE, "the epilogue strips fit tile buffer 1");
+      float* strip = sA(1) + wave * (16 * LDE);
+      float* Cg = p.C + b0 * p.sC0 + row0 * p.ldc + ccol0;
+      int srow = lane >> 3;
+      asm volatile("" : "+v"(srow));          // per leg: keeps the sixteen row addresses from being hoisted (and spilled)
+      const int c4 = (lane & 7) * 4;
+      float cs[2] = {1.f, 1.f};
+      if constexpr (EPI == WE_STORE_COLSCALE) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) cs[ni] = p.colscale[b0 * p.sCs + ccol0 + ni * 16 + r];
+      }
+      f32x4 sc = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
+      if constexpr (EPI == WE_WBAR) {
+        sc = *reinterpret_cast<const f32x4*>(p.colscale + b0 * p.sCs + ccol0 + c4);
+        cv = *reinterpret_cast<const f32x4*>(p.colvec + b0 * p.sCs + ccol0 + c4);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) strip[(4 * q + g) * LDE + ni * 16 + r] = cs[ni] * acc[mi][ni][g];
+        __builtin_amdgcn_wave_barrier();
+        f32x4 w[2];
+        float rv[2];
+        if constexpr (EPI == WE_WBAR) {       // every operand of the pass is loaded before its first store (stores may alias)
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int64_t row = mi * 16 + it * 8 + srow;
+            w[it] = *reinterpret_cast<const f32x4*>(p.aux + b0 * p.sC0 + (row0 + row) * p.ldc + ccol0 + c4);
+            rv[it] = p.rowvec[b0 * p.sRv + row0 + row];
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + srow;
+          f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * LDE + c4);
+          if constexpr (EPI == WE_WBAR) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] + rv[it] * cv[e] - w[it][e] * sc[e];
+          }
+          *reinterpret_cast<f32x4*>(Cg + (int64_t)(mi * 16 + row) * p.ldc + c4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
 }
@@ -646,9 +699,8 @@ bool wide_product_supported(int64_t Mp, int64_t ncp) {
   return Mp % 128 == 0 && ncp % 128 == 0 && Mp * Mp * 4 < (1ll << 31) && Mp * ncp * 4 < (1ll << 31);
 }
 
-int wide_product_launch(const WideArgs& a, hipStream_t s) {
-  GPZ_REQUIRE(wide_product_supported(a.Mp, a.ncp) && a.L > 0, "wide product: bad extents");
-  constexpr int TM = 256, TN = 128;
+template <int TM, int TN>
+static int wide_product_launch_t(const WideArgs& a, hipStream_t s) {
   WParams p = {};
   p.A = a.A; p.lda = a.Mp; p.sA0 = a.Mp * a.Mp;
   p.B = a.B; p.ldb = a.ncp; p.sB0 = a.Mp * a.ncp;
@@ -656,11 +708,11 @@ int wide_product_launch(const WideArgs& a, hipStream_t s) {
   p.mu = a.mu; p.sMu = a.Mp;
   p.ps_sq = a.ps_sq; p.ps_mu = a.ps_mu; p.ncols = a.ncp; p.M = a.Mp;
   p.colscale = a.colscale; p.colvec = a.colvec; p.sCs = a.ncp; p.rowvec = a.rowvec; p.sRv = a.Mp; p.aux = a.aux;
-  p.L = a.L; p.nblk = (int)(a.Mp / 128); p.mtw = (int)((a.Mp + TM - 1) / TM); p.nt = (int)(a.ncp / TN);
-  // strips of (nearly) equal width, at most 32 column tiles: an XCD takes every 8th (latent, strip) unit.  Measured at
-  // config 3 (evaluation ms, stage 1 / stage 2 TF): 8 columns 391.0, 141.1 / 145.7 (L2 -> fabric 23.2 GB per stage-1
-  // launch); 16 columns 386.7, 142.8 / 147.4 (17.8 GB); 24: 386.1; 32: 384.2, 143.7 / 148.5; 48: 385.8
-  constexpr int WMAX = 32;
+  p.L = a.L; p.nblk = (int)(a.Mp / 128); p.mtw = (int)((a.Mp + TM - 1) / TM); p.nt = (int)((a.ncp + TN - 1) / TN);
+  // strips of (nearly) equal width, at most 4096 columns: an XCD takes every 8th (latent, strip) unit.  Measured at
+  // config 3 with 128-column tiles (evaluation ms, stage 1 / stage 2 TF): 8 tiles 391.0, 141.1 / 145.7 (L2 -> fabric
+  // 23.2 GB per stage-1 launch); 16 tiles 386.7, 142.8 / 147.4 (17.8 GB); 24: 386.1; 32: 384.2, 143.7 / 148.5; 48: 385.8
+  constexpr int WMAX = 4096 / TN;
   int strips = (p.nt + WMAX - 1) / WMAX;
   // ... but at least 8 units where the problem has that many column tiles: with fewer units than XCDs part of the chip
   // sits idle (N=3000, M=3000, L=4 as one 24-column strip per latent = 4 units: 61 TF; two strips = 8 units: 122 TF;
@@ -670,7 +722,7 @@ int wide_product_launch(const WideArgs& a, hipStream_t s) {
   p.W = (p.nt + strips - 1) / strips;
   p.strips = (p.nt + p.W - 1) / p.W;
   const int64_t units = (int64_t)p.L * p.strips;
-  const int64_t nblocks = (units + 7) / 8 * 8 * p.mtw * p.W;
+  const int64_t nblocks = (units + 7) / 8 * 8 * ((p.mtw + 1) / 2) * p.W;      // a workgroup takes a pair of row tiles
   constexpr size_t lds = WLds<TM, TN, WB_MEM, 1>::bytes;
 #define GPZ_WM(ATRI, EPI) return launch_wide(gemmw_kernel<TM, TN, WB_MEM, ATRI, EPI, 0, 1>, lds, p, nblocks, s)
   switch (a.epilogue) {
@@ -693,6 +745,11 @@ int wide_product_launch(const WideArgs& a, hipStream_t s) {
   }
 #undef GPZ_WM
   GPZ_REQUIRE(false, "wide product: unknown epilogue %d", a.epilogue);
+}
+
+int wide_product_launch(const WideArgs& a, hipStream_t s) {
+  GPZ_REQUIRE(wide_product_supported(a.Mp, a.ncp) && a.L > 0, "wide product: bad extents");
+  return wide_product_launch_t<128, 256>(a, s);
 }
 
 bool wide_nt_supported(int64_t Mp, int64_t K) {

@@ -496,7 +496,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     const int64_t ncp = pad_up(nreal);  // columns computed this chunk
     const int nt = (int)(ncp / NB);
     const ProductSchedule sched = product_schedule<T>(true, nt);
-    const bool wide = !narrow && pl.f32 && wide_product_supported(Mp, ncp);    // fp32: 256 x 128 tiles (gemmw.hip)
+    const bool wide = !narrow && pl.f32 && wide_product_supported(Mp, ncp);    // fp32: 128 x 256 tiles (gemmw.hip)
     T* const Wc = p->wt_cache ? wtc.wt(ci) : b.Wc;      // retained for the backward pass when asked for
     T* const ps1 = p->wt_cache ? wtc.ps1(ci) : b.ps1;
     if (fused) {
@@ -521,7 +521,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
       prof_begin(PROF_STAGE1, s);
       bool done = false;
       if constexpr (sizeof(T) == 4) {
-        if (wide) {      // Wt = Linv * Kzx on the 256 x 128 tile, with colsum(Wt^2) and muE^T Wt
+        if (wide) {      // Wt = Linv * Kzx on the 128 x 256 tile, with colsum(Wt^2) and muE^T Wt
           WideArgs wa = {};
           wa.A = b.LinvG; wa.B = b.Kc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 0; wa.epilogue = WIDE_STORE_STATS;
           wa.C = Wc; wa.mu = b.muE; wa.ps_sq = ps1; wa.ps_mu = b.pm1;
@@ -544,7 +544,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     {
       bool done = false;
       if constexpr (sizeof(T) == 4) {
-        if (wide) {      // colsum((LuE^T Wt)^2) on the 256 x 128 tile
+        if (wide) {      // colsum((LuE^T Wt)^2) on the 128 x 256 tile
           WideArgs wa = {};
           wa.A = b.LuT; wa.B = Wc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 1; wa.epilogue = WIDE_STATS;
           wa.ps_sq = b.ps2;

@@ -1,7 +1,7 @@
 """GPU: the three ways the forward pass can run its two big fp32 products give the same numbers.
 
   narrow + kfill   kfill_kernel, then gemm128_kernel for both products (the path of round 2 and of every other precision)
-  wide + kfill     kfill_kernel, then gemmw_kernel<256,128,mem> for both products (the default)
+  wide + kfill     kfill_kernel, then gemmw_kernel<128,256,mem> for both products (the default)
   generated        gemmw_kernel<512,128,gen> (16 waves): stage 1 computes its covariance operand itself, Kzx is never written
 
 cov.h is shared by the fill and the generator and all three kernels give lane group q the k = 4q..4q+3 slots of a

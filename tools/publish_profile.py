@@ -22,8 +22,8 @@ here = os.path.dirname(os.path.abspath(__file__))
 subprocess.run([sys.executable, here + "/pmc_summary.py", *(src + "/pmc_" + k for k in ("fetch", "write", "l2", "sq")),
                 "--json", dst + "/pmc_per_dispatch.json"], check=True, stdout=subprocess.DEVNULL)
 pmc = json.load(open(dst + "/pmc_per_dispatch.json"))
-# stage 1 = Wt = Linv * Kzx: gemmw_kernel<256, 128, mem, lower, store+stats, ..> (fp32) or gemm128_kernel<T, NI, NN, EPI_STORE_STATS, ..>
-stage1 = ([k for k in pmc if "gemmw_kernel<256, 128, 0, 1, 0" in k] or
+# stage 1 = Wt = Linv * Kzx: gemmw_kernel<128, 256, mem, lower, store+stats, ..> (fp32) or gemm128_kernel<T, NI, NN, EPI_STORE_STATS, ..>
+stage1 = ([k for k in pmc if "gemmw_kernel<128, 256, 0, 1, 0" in k] or
           [k for k in pmc if "gemm128_kernel<float" in k and ", false, 1," in k])[0]
 v = pmc[stage1]
 cfgs = bench["config"]["workload"]
