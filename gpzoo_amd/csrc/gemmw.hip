@@ -8,9 +8,10 @@
 //     the workgroup owns the same 128 rows, so all of them see the same k range of the triangular operand: no wave idles
 //     while another finishes (a 256 x 128 tile of two row-waves, the first form of this kernel, left one of them idle for
 //     8 steps per tile -- a quarter of all wave-steps at M = 512: configs[1] stage 1 118 -> 123 TF, stage 2 128 -> 131.5;
-//     config 3 142.3 -> 142.6 / 150.4 -> 151.1, same box, both forms timed back to back).  A workgroup runs TWO row tiles
-//     of its column tile, the pi-th longest and the pi-th shortest k range, so every workgroup of a launch executes the
-//     same number of steps; the second tile's first operand tiles are fetched during the first tile's last step.
+//     config 3 142.3 -> 142.6 / 150.4 -> 151.1, same box, both forms timed back to back).  In long launches without a
+//     store epilogue (stage 2 at config 3) a workgroup runs TWO row tiles of its column tile, the pi-th longest and the
+//     pi-th shortest k range, so every workgroup of the launch executes the same number of steps, and the second tile's
+//     first operand tiles are fetched during the first tile's last step; elsewhere one tile, longest k range first.
 //   * B GENERATED (stage 1, fp32 RBF / Matern-3/2 on 1-D / 2-D inputs): 512 x 128 tile, 16 waves, whose 16 x 128 slice of
 //     Kzx is computed by the workgroup itself, ONCE, from the Z block in LDS and each lane's own columns -- Kzx is never
 //     written to HBM (the reference and the two-kernel path move 52 GB of it per evaluation at N=200k, M=2048, L=32).
@@ -76,6 +77,7 @@ struct WParams {
   const float* aux;                           // WE_WBAR: laid out like C
   int64_t M;                                // real rows (the rest is padding)
   int L, nblk, mtw, nt, W, strips;          // latents, 128-blocks, row tiles, column tiles, strip width, strips
+  int pair, colmajor;                       // WB_MEM: two row tiles per workgroup; dispatch order column tile by column tile
 };
 
 constexpr int W_BK = 16;
@@ -111,11 +113,12 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
   // Blocks b, b + 8, ... run on one XCD (round-robin dispatch) and share its L2.
   // WB_GEN: the only operand in memory is A.  A unit = (row tile, latent, strip of W column tiles): its W workgroups
   //   stream one Linv row panel together; units go longest k range first, each level spread evenly over the XCDs.
-  // WB_MEM: a unit = (latent, strip of W column tiles).  A workgroup takes TWO row tiles of one column tile, the
-  //   pi-th longest and the pi-th shortest k range (a middle tile of an odd count alone): every workgroup of the launch
-  //   then runs the same number of steps -- no tail of short tiles, no ordering to get right -- and the second tile's
-  //   first operand tiles travel while the first tile's epilogue runs.  The W workgroups of a pair are dispatched
-  //   together, so they walk the same two A panels in lock-step over the strip's B panels.
+  // WB_MEM: a unit = (latent, strip of W column tiles).  Short launches: inside it row tiles go longest k range first and
+  //   the W workgroups of a row tile are dispatched together, so they walk the same A panel in lock-step over the strip's
+  //   B panels.  Long launches (p.pair, p.colmajor; the host side decides): a workgroup takes TWO row tiles of one column
+  //   tile, the pi-th longest and the pi-th shortest k range (a middle tile of an odd count alone) -- every workgroup of
+  //   the launch then runs the same number of steps and the second tile's first operand tiles travel during the first
+  //   tile's last step -- and the pairs of one column tile are dispatched together: they read the same B panel.
   int tj, b0, leg_ti[2], nlegs = 1;
   {
     const int bid = blockIdx.x;
@@ -130,18 +133,22 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
       b0 = rem / p.strips;
       tj = (rem - b0 * p.strips) * p.W + within;
     } else {
-      const int per_unit = ((p.mtw + 1) >> 1) * p.W;
+      const int per_unit = (p.pair ? (p.mtw + 1) >> 1 : p.mtw) * p.W;
       const int u = (s / per_unit) * 8 + x, within = s % per_unit;
       if (u >= p.L * p.strips) return;
       b0 = u / p.strips;
-      const int pi = within / p.W, far = p.mtw - 1 - pi;
-      tj = (u - b0 * p.strips) * p.W + within % p.W;
+      const int nrow = p.pair ? (p.mtw + 1) >> 1 : p.mtw;
+      const int pi = p.colmajor ? within % nrow : within / p.W, far = p.pair ? p.mtw - 1 - pi : pi;
+      tj = (u - b0 * p.strips) * p.W + (p.colmajor ? within / nrow : within % p.W);
       // the longer k range first in one workgroup, last in the one that most likely shares its CU (an XCD's 32 CUs take
-      // 32 consecutive workgroups of its sequence each): their epilogues and thin diagonal steps then do not coincide
+      // 32 consecutive workgroups of its sequence each): their epilogues and thin diagonal steps then do not coincide.
+      // (Measured against always-long-first, always-short-first and the order that re-reads the B rows just read:
+      // all within run-to-run noise, 140.1 - 141.4 TF on stage 1 of config 3.)
       const bool long_first = ((s >> 5) & 1) == 0;
       leg_ti[0] = ((ATRI == WA_LOWER) == long_first) ? far : pi;
       leg_ti[1] = ((ATRI == WA_LOWER) == long_first) ? pi : far;
       nlegs = far == pi ? 1 : 2;
+      if (!p.pair) leg_ti[0] = leg_ti[1] = (ATRI == WA_LOWER) ? p.mtw - 1 - pi : pi;    // single tiles, longest k range first
     }
     if (tj >= p.nt) return;
   }
@@ -722,7 +729,17 @@ static int wide_product_launch_t(const WideArgs& a, hipStream_t s) {
   p.W = (p.nt + strips - 1) / strips;
   p.strips = (p.nt + p.W - 1) / p.W;
   const int64_t units = (int64_t)p.L * p.strips;
-  const int64_t nblocks = (units + 7) / 8 * 8 * ((p.mtw + 1) / 2) * p.W;      // a workgroup takes a pair of row tiles
+  // Two schedules.  Launches of many rounds (>= 16 rounds of 512 resident workgroups, e.g. a config-3 chunk: 24): a
+  // workgroup takes TWO row tiles (equal work everywhere, the second tile's operands prefetched) and the workgroups of a
+  // unit are dispatched column tile by column tile, so the row tiles of a column walk its B panel together in L2 and
+  // no tail of long tiles is left (config 3, same box: 382.7 -> 381.9 ms, stage 1 143.1 -> 143.8 TF, L2 -> fabric reads
+  // 20.9 -> 17.5 GB per stage-1 launch; column-major WITHOUT the pairing leaves the long tiles of the last columns
+  // running alone: 121 TF).  Shorter launches lose more to the coarser granularity of pairs than they gain
+  // (N_b = 7000, M = 3000, L = 20: 13 rounds of pairs, stage 1 132.4 -> 127.5 TF): there single tiles, row tile by row
+  // tile, longest k range first, fill the tail.
+  const int64_t paired = (units + 7) / 8 * 8 * ((p.mtw + 1) / 2) * p.W;
+  p.pair = p.colmajor = paired >= 16 * 512;
+  const int64_t nblocks = p.pair ? paired : (units + 7) / 8 * 8 * p.mtw * p.W;
   constexpr size_t lds = WLds<TM, TN, WB_MEM, 1>::bytes;
 #define GPZ_WM(ATRI, EPI) return launch_wide(gemmw_kernel<TM, TN, WB_MEM, ATRI, EPI, 0, 1>, lds, p, nblocks, s)
   switch (a.epilogue) {

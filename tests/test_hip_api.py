@@ -330,6 +330,45 @@ def test_two_streams_do_not_share_scratch():
         assert torch.equal(o["mean"], r["mean"]) and torch.equal(o["scale"], r["scale"]) and float(o["elbo"]) == float(r["elbo"])
 
 
+@pytest.mark.parametrize("whitened", [True, False])
+def test_forward_is_capturable_as_a_hip_graph(whitened):
+    """gpz_svgp_forward is a pure sequence of launches on the caller's stream (no host synchronisation, no allocation, no
+    stream of its own): torch.cuda.graph() captures it, a replay reproduces the eager numbers bit for bit and follows
+    in-place edits of the captured inputs."""
+    from gpzoo_amd import ops
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(3, N=3000, M=300, L=3)
+    g = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
+    spec, extra = spec_for_config(g)
+    fwd = lambda: ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], whitened, y=g["y"],  # noqa: E731
+                                   noise_sd=c["noise_sd"], check_info=False, **extra)
+    ref = fwd()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        fwd()                                        # the capture stream's workspace exists before the capture
+        with torch.cuda.graph(graph, stream=side):
+            out = fwd()
+    torch.cuda.current_stream().wait_stream(side)
+    for k in ("mean", "scale", "kl", "elbo"):
+        out[k].zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(out["info"].abs().sum()) == 0
+    for k in ("mean", "scale", "kl", "loglik", "elbo"):
+        assert torch.equal(out[k], ref[k]), k
+    g["mu"].mul_(0.5)
+    g["Z"].add_(0.25)
+    graph.replay()
+    torch.cuda.synchronize()
+    new = fwd()
+    for k in ("mean", "scale", "kl", "loglik", "elbo"):
+        assert torch.equal(out[k], new[k]), k
+    assert not torch.equal(new["mean"], ref["mean"])
+
+
 @pytest.mark.parametrize("cls_name", ["WSVGP", "SVGP"])
 def test_scalar_kernel_shared_by_batched_posteriors(cls_name):
     """RBF with scalar sigma / lengthscale under mu (L,M), Lu (L,M,M): the reference broadcasts one kernel

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [
     # cfg, N, M, L, d
-    (3, 12288, 2048, 2, 2),      # one config-3 chunk: 16 blocks, 8 / 4 row tiles
+    (3, 12288, 2048, 2, 2),      # one config-3 chunk: 16 blocks (short launch: single row tiles per workgroup)
+    (3, 12288, 2048, 24, 2),     # ... with enough latents for the long-launch schedule (pairs of row tiles, column-major)
     (3, 5000, 2048, 1, 2),       # ragged last column tile
     (3, 3000, 3000, 2, 2),       # Mp = 3072, padded rows
     (3, 2000, 384, 3, 2),        # 3 blocks: partial last row tile of both tile heights
@@ -107,6 +108,25 @@ def test_backward_wide_matches_narrow(N, M, L, retain, whitened):
     res = {}
     for narrow in (True, False):
         res[narrow] = ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], whitened, gm, gs, out["scale"],
+                                        kernel_grads=True, wt_cache=out.get("wt_cache"), narrow_tiles=narrow, **extra)
+    for a, b, what in zip(res[True], res[False], ("grad_mu", "grad_Lu", "grad_theta", "grad_Z")):
+        a, b = a.double(), b.double()
+        assert torch.isfinite(b).all(), what
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-5 * float(a.abs().max()), msg=lambda m: f"{what}: {m}")
+
+
+def test_backward_wide_matches_narrow_on_the_paired_schedule():
+    """One config-3 chunk (N=12288, M=2048, L=32: 24 rounds of workgroups) puts every wide product of the backward pass on
+    the long-launch schedule (two row tiles per workgroup, column-major dispatch); same comparison as above."""
+    from gpzoo_amd import ops
+    c, g, spec, extra = _problem(3, 12288, 2048, 32, 2)
+    out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], True, want_Lu=False, retain_wt=0.5, **extra)
+    gen = torch.Generator().manual_seed(6)
+    gm = torch.randn(out["mean"].shape, generator=gen).cuda()
+    gs = torch.randn(out["scale"].shape, generator=gen).cuda()
+    res = {}
+    for narrow in (True, False):
+        res[narrow] = ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], True, gm, gs, out["scale"],
                                         kernel_grads=True, wt_cache=out.get("wt_cache"), narrow_tiles=narrow, **extra)
     for a, b, what in zip(res[True], res[False], ("grad_mu", "grad_Lu", "grad_theta", "grad_Z")):
         a, b = a.double(), b.double()

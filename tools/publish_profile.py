@@ -19,7 +19,8 @@ line = [l for l in open(src + "/trace.log") if l.startswith("{")][-1]
 open(dst + "/bench_under_rocprof.json", "w").write(line)
 bench = json.loads(line)
 here = os.path.dirname(os.path.abspath(__file__))
-subprocess.run([sys.executable, here + "/pmc_summary.py", *(src + "/pmc_" + k for k in ("fetch", "write", "l2", "sq")),
+passes = [k for k in ("fetch", "write", "l2", "sq", "lds") if os.path.isdir(src + "/pmc_" + k)]
+subprocess.run([sys.executable, here + "/pmc_summary.py", *(src + "/pmc_" + k for k in passes),
                 "--json", dst + "/pmc_per_dispatch.json"], check=True, stdout=subprocess.DEVNULL)
 pmc = json.load(open(dst + "/pmc_per_dispatch.json"))
 # stage 1 = Wt = Linv * Kzx: gemmw_kernel<128, 256, mem, lower, store+stats, ..> (fp32) or gemm128_kernel<T, NI, NN, EPI_STORE_STATS, ..>
