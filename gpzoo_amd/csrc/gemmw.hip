@@ -139,7 +139,10 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
       b0 = u / p.strips;
       const int nrow = p.pair ? (p.mtw + 1) >> 1 : p.mtw;
       const int pi = p.colmajor ? within % nrow : within / p.W, far = p.pair ? p.mtw - 1 - pi : pi;
-      tj = (u - b0 * p.strips) * p.W + (p.colmajor ? within / nrow : within % p.W);
+      // strips of equal width up to one column tile (an XCD's units then carry equal work): strip i is [i nt / strips, ...)
+      const int strip = u - b0 * p.strips, c0 = strip * p.nt / p.strips, c1 = (strip + 1) * p.nt / p.strips;
+      tj = c0 + (p.colmajor ? within / nrow : within % p.W);
+      if (tj >= c1) return;
       // the longer k range first in one workgroup, last in the one that most likely shares its CU (an XCD's 32 CUs take
       // 32 consecutive workgroups of its sequence each): their epilogues and thin diagonal steps then do not coincide.
       // (Measured against always-long-first, always-short-first and the order that re-reads the B rows just read:
@@ -726,19 +729,21 @@ static int wide_product_launch_t(const WideArgs& a, hipStream_t s) {
   // four strips = 16 units: 108 TF, narrower strips share each A panel among fewer workgroups)
   const int want = (8 + p.L - 1) / p.L;
   if (strips < want) strips = want < p.nt ? want : p.nt;
-  p.W = (p.nt + strips - 1) / strips;
-  p.strips = (p.nt + p.W - 1) / p.W;
+  p.strips = strips;
+  p.W = (p.nt + strips - 1) / strips;        // the widest strip (the kernel deals the column tiles out evenly)
   const int64_t units = (int64_t)p.L * p.strips;
-  // Two schedules.  Launches of many rounds (>= 16 rounds of 512 resident workgroups, e.g. a config-3 chunk: 24): a
-  // workgroup takes TWO row tiles (equal work everywhere, the second tile's operands prefetched) and the workgroups of a
-  // unit are dispatched column tile by column tile, so the row tiles of a column walk its B panel together in L2 and
-  // no tail of long tiles is left (config 3, same box: 382.7 -> 381.9 ms, stage 1 143.1 -> 143.8 TF, L2 -> fabric reads
-  // 20.9 -> 17.5 GB per stage-1 launch; column-major WITHOUT the pairing leaves the long tiles of the last columns
-  // running alone: 121 TF).  Shorter launches lose more to the coarser granularity of pairs than they gain
-  // (N_b = 7000, M = 3000, L = 20: 13 rounds of pairs, stage 1 132.4 -> 127.5 TF): there single tiles, row tile by row
-  // tile, longest k range first, fill the tail.
+  // Two schedules.  From 4 rounds of 512 resident workgroups up (a config-3 chunk: 24; configs[1]: 6): a workgroup takes TWO
+  // row tiles (equal work everywhere, the second tile's operands prefetched) and the workgroups of a unit are dispatched
+  // column tile by column tile, so the row tiles of a column walk its B panel together in L2 and no tail of long tiles is
+  // left.  Same box, paired column-major against single tiles row tile by row tile, stage 1 / stage 2 TF: config-3 chunks
+  // 139.7 / 149.6 -> 141.5 / 150.7 (L2 -> fabric reads 20.9 -> 17.5 GB per stage-1 launch); configs[1] 120.1 / 126.8 ->
+  // 122.2 / 130.3; N=5000, M=512, L=64 114.0 / 122.8 -> 124.7 / 134.8; N=13000, M=2048, L=32 136.5 / 147.6 -> 139.7 / 149.4;
+  // N_b=7000, M=3000, L=20 129.5 / 139.0 -> 130.9 / 138.7.  (Column-major WITHOUT the pairing leaves the long tiles of the
+  // last columns running alone: 121 TF at config 3.  And equal strips matter more than either: with a short last strip the
+  // XCDs carry unequal work, which had made the pairs look 4 % WORSE than single tiles at N_b=7000.)  Below that a launch
+  // has too few pairs to fill the chip (N=3000, M=3000, L=4: 576 pairs, 122 -> 98 TF): single tiles, longest k range first.
   const int64_t paired = (units + 7) / 8 * 8 * ((p.mtw + 1) / 2) * p.W;
-  p.pair = p.colmajor = paired >= 16 * 512;
+  p.pair = p.colmajor = paired >= 4 * 512;
   const int64_t nblocks = p.pair ? paired : (units + 7) / 8 * 8 * p.mtw * p.W;
   constexpr size_t lds = WLds<TM, TN, WB_MEM, 1>::bytes;
 #define GPZ_WM(ATRI, EPI) return launch_wide(gemmw_kernel<TM, TN, WB_MEM, ATRI, EPI, 0, 1>, lds, p, nblocks, s)

@@ -16,14 +16,15 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [
     # cfg, N, M, L, d
-    (3, 12288, 2048, 2, 2),      # one config-3 chunk: 16 blocks (short launch: single row tiles per workgroup)
-    (3, 12288, 2048, 24, 2),     # ... with enough latents for the long-launch schedule (pairs of row tiles, column-major)
+    (3, 12288, 2048, 2, 2),      # one config-3 chunk: 16 blocks (2 rounds of workgroups: single row tiles per workgroup)
+    (3, 12288, 2048, 24, 2),     # ... with enough latents for the paired schedule (pairs of row tiles, column-major)
     (3, 5000, 2048, 1, 2),       # ragged last column tile
     (3, 3000, 3000, 2, 2),       # Mp = 3072, padded rows
     (3, 2000, 384, 3, 2),        # 3 blocks: partial last row tile of both tile heights
     (3, 1500, 640, 2, 2),        # 5 blocks
     (3, 777, 100, 2, 2),         # a single block
-    (2, 20000, 512, 8, 2),       # config 2's kernel (RBF), one 512-row tile
+    (2, 20000, 512, 8, 2),       # config 2's kernel (RBF), four row tiles, single tiles per workgroup
+    (2, 50000, 512, 8, 2),       # configs[1] itself: pairs of row tiles, column-major, a partial last column tile
     (2, 4000, 640, 3, 1),        # 1-D inputs
     (3, 4000, 640, 3, 1),
 ]
@@ -117,7 +118,8 @@ def test_backward_wide_matches_narrow(N, M, L, retain, whitened):
 
 def test_backward_wide_matches_narrow_on_the_paired_schedule():
     """One config-3 chunk (N=12288, M=2048, L=32: 24 rounds of workgroups) puts every wide product of the backward pass on
-    the long-launch schedule (two row tiles per workgroup, column-major dispatch); same comparison as above."""
+    the paired schedule (two row tiles per workgroup, column-major dispatch); same comparison as above (whose shapes run
+    both schedules: N=5000, M=640 is 2.3 rounds, the others less)."""
     from gpzoo_amd import ops
     c, g, spec, extra = _problem(3, 12288, 2048, 32, 2)
     out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], True, want_Lu=False, retain_wt=0.5, **extra)
