@@ -25,7 +25,13 @@ for a in sys.argv[2:]:
     k, v = a.split("=")
     kw[k] = int(v)
 dev = torch.device("cuda", 0)
+dense_lu = kw.pop("dense_lu", 0)
+zero_mu = kw.pop("zero_lu", 0)
 c = make_config(cfg, **kw)
+if dense_lu:      # a dense, O(1) lower factor instead of identity + 0.01 noise: does the stage-2 rate depend on the operand VALUES?
+    c["Lu_raw"] = 0.5 * torch.randn(c["Lu_raw"].shape, generator=torch.Generator().manual_seed(7))
+if zero_mu:
+    c["Lu_raw"] = torch.zeros_like(c["Lu_raw"])
 g = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
 spec, extra = spec_for_config(g, dev)
 N, M = c["X"].shape[0], c["Z"].shape[0]
