@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
   // (rows r, chunk q) then cover sixteen distinct 16-byte slots of the 256-byte bank row
   auto gperm = [](int w) { const int t = (w >> 2) & 3; return (((t >> 1) ^ t) & 1) << 1 | (t >> 1); };
   const int a_voff = ((lane >> 2) * (int)p.lda + (((lane & 3) ^ gperm(lane >> 2)) * 4)) * (int)sizeof(float);
-  // B from memory: wave w fetches the 1-KB piece w = k rows 2w, 2w + 1 of the step (TN = 128)
+  // B from memory: wave w fetches the 1-KB pieces w, w + NW, ... of the step (TN = 256: a piece is one k row, two per wave)
   const int b_voff = ((lane / (TN / 4)) * (int)p.ldb + (lane % (TN / 4)) * 4) * (int)sizeof(float);
   bool abl_first = true;
   auto stage_load = [&](int buf) __attribute__((always_inline)) {

@@ -64,6 +64,31 @@ def test_three_paths_agree_bitwise_in_wt(cfg, N, M, L, d):
         assert torch.equal(out["kl"], ref["kl"])
 
 
+def _random_shapes(n, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        N = int(torch.randint(200, 40000, (1,), generator=g))
+        M = int(torch.randint(20, 1700, (1,), generator=g))
+        L = int(torch.randint(1, 9, (1,), generator=g))
+        out.append((N, M, L))
+    return out
+
+
+@pytest.mark.parametrize("N,M,L", _random_shapes(14) + [(30000, 1100, 8), (26000, 640, 16)])   # + two paired launches with an odd block count
+def test_wide_tiles_agree_with_narrow_tiles_on_random_shapes(N, M, L):
+    """Odd counts of row and column tiles, partial last tiles, one to a dozen strips, both schedules of the wide kernel
+    (single row tiles / pairs dispatched column-major, decided by the launch size): Wt bit for bit the narrow kernel's."""
+    c, g, spec, extra = _problem(3, N, M, L, 2)
+    Mp, ncp = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    nwt = L * Mp * ncp
+    ref = _run(c, g, spec, extra, materialize_kzx=True, narrow_tiles=True)
+    out = _run(c, g, spec, extra)
+    assert torch.equal(out["wt_cache"].view(torch.int32)[:nwt], ref["wt_cache"].view(torch.int32)[:nwt])
+    torch.testing.assert_close(out["scale"], ref["scale"], rtol=1e-5, atol=0)
+    assert float(out["elbo"]) == pytest.approx(float(ref["elbo"]), rel=1e-7)
+
+
 @pytest.mark.parametrize("materialize", [None, True, False])
 def test_each_path_against_the_oracle(materialize):
     """N=3000, M=300, L=3 Matern-3/2 fp32 (a partial 512-row tile, padded rows and columns) against the CPU oracle."""
