@@ -38,10 +38,8 @@ from bench import gemm_source_hash  # noqa: E402
 out = {"kernel": stage1, "gemm_src_sha16": gemm_source_hash(), "workload": {"config": 3, "N": N, "M": M, "L": L, "chunk": 0, "launches_per_eval": launches},
        "FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"],
        "hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
-       # the x2 of the gfx950 note is calibrated on 16-byte-per-lane reads that form 128-byte requests; the wide kernel's A
-       # tiles are read as 64-byte row segments (three quarters of its L2 requests: TCC_HIT + TCC_MISS = A bytes / 64 +
-       # B bytes / 128 + written bytes / 128), for which the counter may already be exact -- so the figure above is an
-       # upper bound and this one the lower bound
+       # the x2 of the gfx950 note holds for this kernel's 64-byte row-segment reads too: tools/fetch_probe.hip (L2 fetches
+       # whole 128-byte lines and tallies each as 64 bytes); the raw figure is kept for reference
        "hbm_bytes_per_launch_undoubled": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
        "l2_requests_per_launch": v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0),
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh), averaged over "
