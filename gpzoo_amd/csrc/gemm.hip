@@ -8,9 +8,10 @@
 // non-transposed B tile is staged [k][n].  Because the MFMA sums its four k
 // slots, lane group q may own k = VEC*q .. VEC*q+VEC-1 as long as A and B agree,
 // which is what makes the wide read legal.  Tiles reach LDS through registers (global load -> ds_write),
-// double buffered, one barrier per k-tile; the kernel template also carries an LDS-DMA staging form (STG = 1) and
-// 64 x 64 wave tiles (NI = 4) that were measured in round 2 -- neither is instantiated in
-// the shipped library.  The two big fp32 products of the forward pass run on csrc/gemmw.hip instead.
+// double buffered, one barrier per k-tile; the kernel template also carries an LDS-DMA staging form (STG = 1), which
+// the two big fp64 products of the forward pass use (gemm_launch), and 64 x 64 wave tiles (NI = 4) that were measured
+// in round 2 and are not instantiated.  The two big fp32 products of the forward pass run on
+// csrc/gemmw.hip instead.
 //
 // Triangular structure (L^{-1} and Lu^T are triangular, SYRK only needs the lower
 // tiles) is expressed as a per-tile k-range in units of the 128-block, so no
@@ -657,7 +658,15 @@ int gemm_launch(const GemmParams<T>& p, int epilogue, hipStream_t s) {
     return launch(gemm128_kernel<T, NI, false, EPI_STATS, STG>, GemmLds<T, false, STG>::bytes);
   };
   using std::integral_constant;
-  // one staging form and one wave tile ship: registers, 64 x 32 (the alternatives measured slower or equal, see above)
+  // one wave tile ships (64 x 32) and, but for one case, one staging form: through registers (the alternatives measured
+  // slower or equal, see above)
+  // ... except the two big fp64 products of the forward pass (the epilogues with column statistics), which take their
+  // tiles by LDS-DMA: N=100 000, M=2048, L=8 fp64 (configs[4] per GPU) stage 1 67.5 -> 68.7 TF, stage 2 70.3 -> 70.8,
+  // the evaluation 103.0 -> 101.9 ms.  (In fp32 the same switch lost 4 %: there the MFMAs are half as long and the
+  // register-staged form's instruction order matters more; the fp32 products have their own kernel now, gemmw.hip.)
+  if constexpr (sizeof(T) == 8) {
+    if (epilogue == EPI_STORE_STATS || epilogue == EPI_STATS) return run(integral_constant<int, 1>{}, integral_constant<int, 2>{});
+  }
   return run(integral_constant<int, 0>{}, integral_constant<int, 2>{});
 }
 
