@@ -127,6 +127,27 @@ def _allreduce_scalar(e: torch.Tensor, group=None, comm: Optional["AbiCommunicat
     return e
 
 
+def allreduce_shared_grads(params, group=None) -> None:
+    """Training on latent shards: the per-latent parameters (mu, Lu, vector sigma / lengthscale) live on the rank that owns
+    the latent and need no exchange, but a parameter every latent shares -- the inducing points Z, a scalar kernel
+    hyper-parameter, MGGP's group_diff_param -- receives on each rank only its shard's part of the gradient.  Call this after
+    ``loss.backward()`` with those parameters: their ``.grad`` tensors are summed over the ranks in one flattened all-reduce
+    (RCCL with the ``nccl`` backend; the reference has no multi-GPU code -- its optimizer step, ``utilities.py:485-489``,
+    then runs unchanged on every rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    grads = [p.grad for p in params if p is not None and p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1).to(torch.float64) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    o = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[o:o + n].reshape(g.shape).to(g.dtype))
+        o += n
+
+
 def sharded_elbo(problem: dict, L: int, local_eval: Callable[[dict], torch.Tensor] = hip_local_elbo,
                  group=None, local_terms: Optional[Callable] = None, comm: Optional[AbiCommunicator] = None) -> torch.Tensor:
     """ELBO of an L-latent model summed over all ranks of ``group``.

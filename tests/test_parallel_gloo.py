@@ -63,3 +63,44 @@ def test_two_rank_sum_matches_single_rank(L):
     ref = float(_oracle_eval(make_config(2, N=400, M=48, L=L, dtype=torch.float64)))
     assert e == pytest.approx(ref, rel=1e-12)
     assert e2 == pytest.approx(ref, rel=1e-12)
+
+
+def _grad_worker(rank, world, port, L, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpzoo_amd.parallel import allreduce_shared_grads, shard_problem
+    torch.set_num_threads(2)
+    full = make_config(2, N=300, M=40, L=L, dtype=torch.float64)
+    p = shard_problem(full, L, world, rank)
+    Z = p["Z"].clone().requires_grad_(True)              # shared by every latent: its gradient needs the exchange
+    mu = p["mu"].clone().requires_grad_(True)            # per latent: owned by this rank
+    q_ = dict(p, Z=Z, mu=mu)
+    loss = -_oracle_eval(q_)
+    loss.backward()
+    allreduce_shared_grads([Z])
+    q.put((rank, p["latents"].start, p["latents"].stop, Z.grad.clone(), mu.grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shared_parameter_gradients_sum_over_latent_shards():
+    """World size 2, gloo: after allreduce_shared_grads the gradient of the (negative) ELBO w.r.t. the shared inducing points
+    equals the single-process gradient on every rank; the per-latent gradients are the single-process rows of the shard."""
+    L = 5
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, L, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = [q.get() for _ in range(2)]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    full = make_config(2, N=300, M=40, L=L, dtype=torch.float64)
+    Z = full["Z"].clone().requires_grad_(True)
+    mu = full["mu"].clone().requires_grad_(True)
+    (-_oracle_eval(dict(full, Z=Z, mu=mu))).backward()
+    for rank, lo, hi, gz, gmu in got:
+        torch.testing.assert_close(gz, Z.grad, rtol=1e-10, atol=1e-12)
+        torch.testing.assert_close(gmu, mu.grad[lo:hi], rtol=1e-10, atol=1e-12)
