@@ -140,7 +140,12 @@ def allreduce_shared_grads(params, group=None) -> None:
     if not grads:
         return
     flat = torch.cat([g.reshape(-1).to(torch.float64) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":      # rehearsals: through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     o = 0
     for g in grads:
         n = g.numel()
