@@ -642,9 +642,13 @@ def multiblock_cases():
     """The reference itself beyond one 128-block: M = 300 (three blocks: panel solves, a trailing update, one level of the
     triangular inverse, partial wide tiles), N = 2000, L = 3.  The inputs are regenerated from their seed by the tests
     (tests/golden/inputs.py); stored are (L,N) / (L,M) outputs and scalars only (~100 KB per case)."""
-    for name, gpc, kind, whitened in (("wsvgp_matern32", "WSVGP", "matern32", True), ("svgp_nsf_rbf", "SVGP", "nsf_rbf", False)):
+    for prefix, meta0 in (("multiblock", dict(seed=4242, N=2000, M=300, d=2, L=3, span=25.0)),
+                          # nine blocks, an odd count: four levels of the triangular inverse with a ragged tail segment, four
+                          # paired trailing updates + a last single panel, odd row-tile counts in every product kernel
+                          ("multiblock9", dict(seed=4343, N=1500, M=1100, d=2, L=2, span=40.0))):
+      for name, gpc, kind, whitened in (("wsvgp_matern32", "WSVGP", "matern32", True), ("svgp_nsf_rbf", "SVGP", "nsf_rbf", False)):
         for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
-            meta = dict(seed=4242, N=2000, M=300, d=2, L=3, span=25.0)
+            meta = dict(meta0)
             inp = make_inputs(meta["seed"], N=meta["N"], M=meta["M"], d=meta["d"], L=meta["L"], span=meta["span"])
             kern = build_kernel(kind, meta["L"])
             out = run_case(name, getattr(rgp, gpc), kern, inp, dtype, 1e-2, 0.5, whitened, False)
@@ -656,8 +660,8 @@ def multiblock_cases():
             keep["grad_Lu_absmax"] = np.float64(np.abs(out["grad_Lu"]).max())
             keep.update({k: np.float64(v) if isinstance(v, float) else np.int64(v) for k, v in meta.items()})
             keep["kind"] = np.array(kind); keep["whitened"] = np.array(whitened)
-            np.savez_compressed(os.path.join(HERE, f"multiblock_{name}_{tag}.npz"), **keep)
-            print(f"multiblock_{name}_{tag}: elbo={float(out['elbo']):.10f}")
+            np.savez_compressed(os.path.join(HERE, f"{prefix}_{name}_{tag}.npz"), **keep)
+            print(f"{prefix}_{name}_{tag}: elbo={float(out['elbo']):.10f}")
 
 
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "multiblock"):

@@ -62,12 +62,15 @@ def spec_from_case(c, device):
 
 
 MULTIBLOCK = ("multiblock_wsvgp_matern32_f64", "multiblock_wsvgp_matern32_f32", "multiblock_svgp_nsf_rbf_f64",
-              "multiblock_svgp_nsf_rbf_f32")
+              "multiblock_svgp_nsf_rbf_f32",
+              # nine blocks (M = 1100, N = 1500, L = 2): an odd block count through every multi-level path
+              "multiblock9_wsvgp_matern32_f64", "multiblock9_wsvgp_matern32_f32", "multiblock9_svgp_nsf_rbf_f64",
+              "multiblock9_svgp_nsf_rbf_f32")
 
 
 def load_multiblock(name):
-    """A reference-generated fixture beyond one 128-block (M = 300, N = 2000, L = 3): outputs and scalars come from the
-    file, the inputs are regenerated from the stored seed exactly as tests/golden/make_golden.py drew them."""
+    """A reference-generated fixture beyond one 128-block (M = 300, N = 2000, L = 3; M = 1100, N = 1500, L = 2): outputs and
+    scalars come from the file, the inputs are regenerated from the stored seed exactly as tests/golden/make_golden.py drew them."""
     import sys
     sys.path.insert(0, GOLDEN)
     from inputs import make_inputs

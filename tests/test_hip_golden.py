@@ -63,21 +63,27 @@ def test_forward_and_elbo(name):
 @pytest.mark.parametrize("name", __import__("helpers").MULTIBLOCK)
 def test_reference_beyond_one_block(name):
     """The reference itself at M = 300 (three 128-blocks: panel solves, a trailing update, a triangular-inverse level,
-    partial wide tiles), N = 2000, L = 3 -- forward moments, KL, ELBO, the factor's diagonal (pure rtol: strictly
+    partial wide tiles), N = 2000, L = 3, and at M = 1100 (nine blocks: every level of the factor path with an odd count),
+    N = 1500, L = 2 -- forward moments, KL, ELBO, the factor's diagonal (pure rtol: strictly
     positive quantities) and the reference's autograd gradients of -ELBO w.r.t. mu and Lu."""
     from gpzoo.utilities import whitened_KL_batched
     from helpers import load_multiblock, rtol_for
     from test_hip_api import build
     c = load_multiblock(name)
     rt = rtol_for(c["X"].dtype)
-    model = build(name[len("multiblock_"):], c)
+    model = build(name.split("_", 1)[1], c)
     gp = model.gp
     for t in [gp.Z, *gp.kernel.parameters()]:
         t.requires_grad_(False)
     X, y = c["X"].cuda(), c["y"].cuda()
     pY, qF, qU, pU = model(X=X, E=1)
-    torch.testing.assert_close(qF.mean.detach().cpu(), c["mean"], rtol=rt, atol=rt * float(c["mean"].abs().max()))
-    torch.testing.assert_close(qF.scale.detach().cpu(), c["scale"], rtol=rt, atol=0)
+    # element-wise against the reference's fp64 run (SURVEY section 8d: the reference's own fp32 run is off by more than the
+    # tolerance in places -- at M = 1100 un-whitened its scale misses its fp64 value by up to 1.1e-3); the scalars below
+    # are compared with the fixture of the same precision
+    truth = load_multiblock(name[:-3] + "f64") if name.endswith("f32") else c
+    torch.testing.assert_close(qF.mean.detach().cpu().double(), truth["mean"].double(), rtol=rt,
+                               atol=rt * float(truth["mean"].abs().max()))
+    torch.testing.assert_close(qF.scale.detach().cpu().double(), truth["scale"].double(), rtol=rt, atol=0)
     s = torch.nn.functional.softplus(model.noise)
     if c["whitened"]:
         kl = whitened_KL_batched(qU.mean, qU.scale_tril)
