@@ -646,13 +646,18 @@ def multiblock_cases():
                           # nine blocks, an odd count: four levels of the triangular inverse with a ragged tail segment, four
                           # paired trailing updates + a last single panel, odd row-tile counts in every product kernel
                           ("multiblock9", dict(seed=4343, N=1500, M=1100, d=2, L=2, span=40.0))):
-      for name, gpc, kind, whitened in (("wsvgp_matern32", "WSVGP", "matern32", True), ("svgp_nsf_rbf", "SVGP", "nsf_rbf", False)):
+      cases = [("wsvgp_matern32", "WSVGP", "matern32", True, 0), ("svgp_nsf_rbf", "SVGP", "nsf_rbf", False, 0)]
+      if prefix == "multiblock":       # the int64 group gather and the (latent, group-pair) table beyond one block
+          cases.append(("mggp_wsvgp_mggp_nsf_rbf", "MGGP_WSVGP", "mggp_nsf_rbf", True, 3))
+      for name, gpc, kind, whitened, n_groups in cases:
         for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
-            meta = dict(meta0)
-            inp = make_inputs(meta["seed"], N=meta["N"], M=meta["M"], d=meta["d"], L=meta["L"], span=meta["span"])
+            meta = dict(meta0, n_groups=n_groups)
+            inp = make_inputs(meta["seed"], N=meta["N"], M=meta["M"], d=meta["d"], L=meta["L"], n_groups=n_groups, span=meta["span"])
             kern = build_kernel(kind, meta["L"])
-            out = run_case(name, getattr(rgp, gpc), kern, inp, dtype, 1e-2, 0.5, whitened, False)
+            out = run_case(name, getattr(rgp, gpc), kern, inp, dtype, 1e-2, 0.5, whitened, n_groups > 0)
             keep = {k: out[k] for k in ("mean", "scale", "kl", "elbo", "grad_mu", "sigma", "lengthscale", "jitter", "noise_sd")}
+            if n_groups:
+                keep.update({k: out[k] for k in ("embedding", "group_diff", "input_dim", "grad_group_diff")})
             keep["chol_diag"] = np.diagonal(out["chol"], axis1=-2, axis2=-1).copy()
             keep["chol_rowsum"] = out["chol"].sum(-1)
             keep["grad_Lu_rowsum"] = out["grad_Lu"].sum(-1)

@@ -62,7 +62,7 @@ def spec_from_case(c, device):
 
 
 MULTIBLOCK = ("multiblock_wsvgp_matern32_f64", "multiblock_wsvgp_matern32_f32", "multiblock_svgp_nsf_rbf_f64",
-              "multiblock_svgp_nsf_rbf_f32",
+              "multiblock_svgp_nsf_rbf_f32", "multiblock_mggp_wsvgp_mggp_nsf_rbf_f64", "multiblock_mggp_wsvgp_mggp_nsf_rbf_f32",
               # nine blocks (M = 1100, N = 1500, L = 2): an odd block count through every multi-level path
               "multiblock9_wsvgp_matern32_f64", "multiblock9_wsvgp_matern32_f32", "multiblock9_svgp_nsf_rbf_f64",
               "multiblock9_svgp_nsf_rbf_f32")
@@ -77,9 +77,10 @@ def load_multiblock(name):
     c = load_case(name)
     meta = {k: int(c.pop(k)) for k in ("seed", "N", "M", "d", "L")}
     span = float(c.pop("span"))
+    n_groups = int(c.pop("n_groups")) if "n_groups" in c else 0
     dt = torch.float64 if name.endswith("f64") else torch.float32
-    inp = make_inputs(meta["seed"], N=meta["N"], M=meta["M"], d=meta["d"], L=meta["L"], span=span)
+    inp = make_inputs(meta["seed"], N=meta["N"], M=meta["M"], d=meta["d"], L=meta["L"], n_groups=n_groups, span=span)
     c.update({k: (v.to(dt) if v.is_floating_point() else v) for k, v in inp.items()})
-    if c["kind"] == "nsf_rbf":     # NSF_RBF keeps (L,1,1) parameters
+    if c["kind"] in ("nsf_rbf", "mggp_nsf_rbf"):     # the NSF kernels keep (L,1,1) parameters
         c["sigma"], c["lengthscale"] = c["sigma"].reshape(-1, 1, 1), c["lengthscale"].reshape(-1, 1, 1)
     return c

@@ -76,7 +76,8 @@ def test_reference_beyond_one_block(name):
     for t in [gp.Z, *gp.kernel.parameters()]:
         t.requires_grad_(False)
     X, y = c["X"].cuda(), c["y"].cuda()
-    pY, qF, qU, pU = model(X=X, E=1)
+    fkw = dict(groupsX=c["gX"].cuda()) if "gX" in c else {}
+    pY, qF, qU, pU = model(X=X, E=1, **fkw)
     # element-wise against the reference's fp64 run (the reference's own fp32 run is off by more than the
     # tolerance in places -- at M = 1100 un-whitened its scale misses its fp64 value by up to 1.1e-3); the scalars below
     # are compared with the fixture of the same precision

@@ -48,16 +48,18 @@ def test_oracle_matches_reference(name):
 def test_oracle_matches_reference_beyond_one_block(name):
     """M = 300, N = 2000, L = 3 run through the reference itself (make_golden.py multiblock_cases): the oracle on the
     regenerated inputs reproduces the reference's moments, KL, ELBO and the factor's diagonal / row sums."""
-    from helpers import load_multiblock
+    from helpers import load_multiblock, oracle_kwargs
     c = load_multiblock(name)
     f64 = c["X"].dtype == torch.float64
+    kw = oracle_kwargs(c)
     e, mean, scale = O.elbo_eval(c["kind"], c["whitened"], c["X"], c["y"], c["Z"], c["sigma"], c["lengthscale"], c["mu"],
-                                 c["Lu_raw"], c["jitter"], c["noise_sd"])
+                                 c["Lu_raw"], c["jitter"], c["noise_sd"], **kw)
     tol = dict(rtol=1e-9, atol=1e-11) if f64 else dict(rtol=2e-3, atol=2e-4)
     torch.testing.assert_close(mean, c["mean"], **tol)
     torch.testing.assert_close(scale, c["scale"], **tol)
     assert float(e) == pytest.approx(c["elbo"], rel=1e-10 if f64 else 1e-5)
-    Kzz = O.add_jitter_(O.kernel_matrix(c["kind"], c["Z"], c["Z"], c["sigma"], c["lengthscale"]).contiguous(), c["jitter"])
+    kz = dict(gA=kw["gZ"], gB=kw["gZ"], embedding=kw["embedding"], group_diff=kw["group_diff"], input_dim=kw["input_dim"]) if kw else {}
+    Kzz = O.add_jitter_(O.kernel_matrix(c["kind"], c["Z"], c["Z"], c["sigma"], c["lengthscale"], **kz).contiguous(), c["jitter"])
     chol = torch.linalg.cholesky(Kzz)
     torch.testing.assert_close(torch.diagonal(chol, dim1=-2, dim2=-1), c["chol_diag"], **(tol if f64 else dict(rtol=1e-3, atol=0)))
     torch.testing.assert_close(chol.sum(-1), c["chol_rowsum"], **(tol if f64 else dict(rtol=1e-3, atol=1e-3)))
