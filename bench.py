@@ -474,6 +474,14 @@ def main():
                                  y=g["y"][..., :n].contiguous(), noise_sd=c["noise_sd"], want_Lu=False, **ex)
             cb["sample_elbo_hip"] = float(o["elbo"])
             cb["sample_rel_diff"] = abs(cb["sample_elbo_hip"] - cb["sample_elbo"]) / abs(cb["sample_elbo"])
+            # ... and, where the build container ran the REFERENCE itself on this very slice (a committed fixture: data,
+            # tests/golden/make_baseline_golden.py), its fp64 ELBO next to ours
+            fx = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "baseline_cfg3_slice.npz")
+            if cfg_id == 3 and (N, M, Lper, n) == (200_000, 2048, 32, 8192) and os.path.exists(fx):
+                import numpy as np
+                ref = float(np.load(fx, allow_pickle=False)["f64_elbo"])
+                cb["sample_elbo_reference_fp64"] = ref
+                cb["sample_rel_diff_vs_reference"] = abs(cb["sample_elbo_hip"] - ref) / abs(ref)
             res["cpu_baseline"] = cb
         elif not a.no_cpu_baseline:
             res["cpu_baseline"] = None

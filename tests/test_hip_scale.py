@@ -62,6 +62,44 @@ def test_config2_full_size_against_oracle():
     check(make_config(2), 1e-3)
 
 
+def _against_reference_run(fixture, c):
+    """HIP path (the configuration's own precision, fp32) against the reference's fp32 and fp64 runs of the same inputs
+    (tests/golden/make_baseline_golden.py): ELBO and its parts to the fp32 tolerance (they agree far inside it), q(F) at the
+    stored spot indices element-wise against the reference's fp64 run."""
+    import os
+    import numpy as np
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, fixture), allow_pickle=False)
+    assert c["X"].shape[0] == int(z["f64_n"])
+    out = hip_eval(c)
+    rt = 1e-3
+    for tag in ("f32", "f64"):
+        assert float(out["elbo"]) == pytest.approx(float(z[f"{tag}_elbo"]), rel=rt)
+        torch.testing.assert_close(out["kl"].cpu(), torch.from_numpy(z[f"{tag}_kl"]), rtol=rt, atol=0)
+        torch.testing.assert_close(out["loglik"].cpu(), torch.from_numpy(z[f"{tag}_loglik"]), rtol=rt, atol=0)
+    assert float(out["elbo"]) == pytest.approx(float(z["f64_elbo"]), rel=2e-6)         # what it actually achieves
+    idx = torch.from_numpy(z["f64_idx"])
+    mean, scale = torch.from_numpy(z["f64_mean"]), torch.from_numpy(z["f64_scale"])
+    torch.testing.assert_close(out["mean"].cpu()[:, idx].double(), mean, rtol=rt, atol=rt * float(mean.abs().max()))
+    torch.testing.assert_close(out["scale"].cpu()[:, idx].double(), scale, rtol=rt, atol=0)
+
+
+def test_config2_as_stated_against_the_reference_itself():
+    """BASELINE configs[1] exactly as stated (N=50 000, M=512, L=8, NSF_RBF, fp32), evaluated by the reference's own WSVGP
+    in the build container (ELBO -5873658.18 in fp64, -5873663.16 in its fp32)."""
+    from gpzoo_amd.synthetic import make_config
+    _against_reference_run("baseline_cfg2.npz", make_config(2))
+
+
+def test_config3_benchmark_slice_against_the_reference_itself():
+    """BASELINE configs[2] (N=200 000, M=2048, L=32, Matern-3/2, fp32) on its first 8192 spots -- the slice bench.py's
+    cpu_baseline leg times and compares -- evaluated by the reference's own WSVGP (ELBO -4830793.248 in fp64)."""
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(3)
+    c["X"], c["y"] = c["X"][:8192].contiguous(), c["y"][:, :8192].contiguous()
+    _against_reference_run("baseline_cfg3_slice.npz", c)
+
+
 def test_config5_multi_panel_fp64_against_oracle():
     """BASELINE configs[4]'s factor size: M=2048 (16 Cholesky panels, 4 trtri levels), MGGP_NSF_RBF, fp64,
     N=4096 spots over the 4 groups, L=2 -- element-wise against the oracle at 1e-5."""

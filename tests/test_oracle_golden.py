@@ -105,3 +105,20 @@ def test_oracle_vnngp(name):
     torch.testing.assert_close(mean, t["mean"], **tol)
     torch.testing.assert_close(scale, t["scale"], **tol)
     torch.testing.assert_close(chol.reshape(t["chol"].shape), t["chol"], **tol)
+
+
+def test_oracle_reproduces_the_reference_on_config2_as_stated():
+    """BASELINE configs[1] (N=50 000, M=512, L=8, NSF_RBF) evaluated by the reference itself (make_baseline_golden.py): the
+    oracle on the same seeded inputs reproduces its fp64 ELBO, log-likelihood and KL parts and q(F) at the stored indices."""
+    import os
+    from gpzoo_amd.synthetic import make_config
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "baseline_cfg2.npz"), allow_pickle=False)
+    c = make_config(2)           # the configuration's fp32 inputs, evaluated in fp64 arithmetic (as the generator did)
+    c = {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in c.items()}
+    e, mean, scale = O.elbo_eval(c["kind"], c["whitened"], c["X"], c["y"], c["Z"], c["sigma"], c["lengthscale"], c["mu"],
+                                 c["Lu_raw"], c["jitter"], float(z["f64_noise_sd"]))     # softplus of the model's fp32-born noise parameter
+    assert float(e) == pytest.approx(float(z["f64_elbo"]), rel=1e-11)
+    idx = torch.from_numpy(z["f64_idx"])
+    torch.testing.assert_close(mean[:, idx], torch.from_numpy(z["f64_mean"]), rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(scale[:, idx], torch.from_numpy(z["f64_scale"]), rtol=1e-9, atol=1e-11)
