@@ -17,7 +17,7 @@ def pytest_configure(config):
 def golden_cases():
     names = sorted(f[:-4] for f in os.listdir(GOLDEN)
                    if f.endswith(".npz") and f not in ("kernels_only.npz", "kernel_grads.npz")
-                   and not f.startswith(("poisson_", "vnngp_", "ref_checkpoint_", "ref_trajectory_", "extra_", "exact_", "multiblock")))
+                   and not f.startswith(("poisson_", "vnngp_", "ref_checkpoint_", "ref_trajectory_", "extra_", "exact_", "multiblock", "baseline_")))
     return names
 
 
