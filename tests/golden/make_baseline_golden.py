@@ -9,7 +9,8 @@ synthetic inputs gpzoo_amd/synthetic.py draws for
     comparisons use, SURVEY section 8d);
   * configs[2] (N = 200 000, M = 2048, L = 32, Matern-3/2) on its first 8192 spots -- the slice bench.py's cpu_baseline leg
     evaluates; the reference cannot hold the whole configuration (157 GB) and is used on minibatches of this size in its
-    notebooks (utilities.py:605-609).
+    notebooks (utilities.py:605-609);
+  * configs[4] (MGGP: 4 groups x 50 000 spots, M = 2048, L = 32, MGGP_NSF_RBF, fp64) on every 24th spot, 8192 of them.
 Stored (data only, < 1 MB per file): the closed-form ELBO (mggp_test_exact.ipynb:157-159), its log-likelihood and KL
 parts, and q(F)'s mean / scale at 4096 (configs[1]) / 1024 (configs[2]) seeded spot indices.  The tests regenerate the inputs from the same seeds.
 """
@@ -39,10 +40,17 @@ def inv_softplus(v):
     return float(np.log(np.expm1(v)))
 
 
-def run(cfg, dtype, n_spots=None, nidx=4096, **kw):
+def run(cfg, dtype, n_spots=None, nidx=4096, stride=1, **kw):
     c = make_config(cfg, **kw)
     L, M = c["mu"].shape
-    if c["kind"] == "nsf_rbf":
+    mggp = c["kind"] == "mggp_nsf_rbf"
+    if mggp:
+        G = c["n_groups"]
+        k = rk.MGGP_NSF_RBF(n_groups=G, L=L)
+        k.sigma = nn.Parameter(c["sigma"].reshape(L, 1, 1).double().clone())
+        k.lengthscale = nn.Parameter(c["lengthscale"].reshape(L, 1, 1).double().clone())
+        k.group_diff_param = nn.Parameter(c["group_diff"].reshape(L, 1, 1).double().clone())
+    elif c["kind"] == "nsf_rbf":
         k = rk.NSF_RBF(L=L)
         k.sigma = nn.Parameter(c["sigma"].reshape(L, 1, 1).double().clone())
         k.lengthscale = nn.Parameter(c["lengthscale"].reshape(L, 1, 1).double().clone())
@@ -50,17 +58,23 @@ def run(cfg, dtype, n_spots=None, nidx=4096, **kw):
         k = rk.batched_Matern32()
         k.sigma = nn.Parameter(c["sigma"].double().clone())
         k.lengthscale = nn.Parameter(c["lengthscale"].double().clone())
-    gp = rgp.WSVGP(k, dim=2, M=M, jitter=c["jitter"])
+    gp = rgp.MGGP_WSVGP(k, dim=2, M=M, n_groups=c["n_groups"], jitter=c["jitter"]) if mggp else rgp.WSVGP(k, dim=2, M=M, jitter=c["jitter"])
+    if mggp:
+        gp.groupsZ = nn.Parameter(c["gZ"].clone(), requires_grad=False)
     gp.Z = nn.Parameter(c["Z"].double().clone())
     gp.mu = nn.Parameter(c["mu"].double().clone())
     gp.Lu = nn.Parameter(c["Lu_raw"].double().clone())
     model = rl.ExactLikelihood(gp, noise=inv_softplus(c["noise_sd"]))
     model = model.double() if dtype == torch.float64 else model.float()
+    if mggp and not isinstance(k.embedding, nn.Parameter):
+        k.embedding = k.embedding.to(dtype)          # a plain tensor attribute: .double() does not move it
     n = c["X"].shape[0] if n_spots is None else n_spots
-    X, y = c["X"][:n].to(dtype), c["y"][:, :n].to(dtype)
+    sel = torch.arange(0, n * stride, stride)        # every stride-th spot (configs[4]'s groups come in blocks of 50 000)
+    X, y = c["X"][sel].to(dtype), c["y"][:, sel].to(dtype)
+    fkw = dict(groupsX=c["gX"][sel]) if mggp else {}
     t0 = time.time()
     with torch.no_grad():
-        pY, qF, qU, pU = model(X=X, E=1)
+        pY, qF, qU, pU = model(X=X, E=1, **fkw)
         s = torch.nn.functional.softplus(model.noise).double()
         kl = torch.stack([whitened_KL(qU.mean[l], qU.scale_tril[l]) for l in range(L)]).double()
         loglik = (pY.log_prob(y).double() - (qF.scale.double() ** 2) / (2 * s ** 2)).sum(-1)      # (L,)
@@ -83,6 +97,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if os.environ.get("GPZ_BASELINE_ONLY", "") in ("", "2"):
         save("baseline_cfg2.npz", run(2, torch.float64), run(2, torch.float32))
+    if os.environ.get("GPZ_BASELINE_ONLY", "") in ("", "5"):     # configs[4]: MGGP, fp64 (its stated precision) and fp32, every 24th spot
+        save("baseline_cfg5_slice.npz", run(5, torch.float64, n_spots=8192, nidx=1024, stride=24),
+             run(5, torch.float32, n_spots=8192, nidx=1024, stride=24))
     if os.environ.get("GPZ_BASELINE_ONLY", "") not in ("", "3"):
         sys.exit(0)
     save("baseline_cfg3_slice.npz", run(3, torch.float64, n_spots=8192, nidx=1024), run(3, torch.float32, n_spots=8192, nidx=1024))

@@ -62,6 +62,31 @@ def test_config2_full_size_against_oracle():
     check(make_config(2), 1e-3)
 
 
+def test_config5_strided_slice_against_the_reference_itself():
+    """BASELINE configs[4] (MGGP: 4 groups x 50 000 spots, M=2048, L=32, MGGP_NSF_RBF, fp64) on every 24th spot (8192 of
+    them, all four groups), evaluated by the reference's own MGGP_WSVGP (ELBO -4863267.631 in fp64): the HIP fp64 path at the
+    fp64 tolerance, element-wise and in the ELBO's parts."""
+    import os
+    import numpy as np
+    from gpzoo_amd.synthetic import make_config
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "baseline_cfg5_slice.npz"), allow_pickle=False)
+    c = make_config(5)
+    sel = torch.arange(0, 8192 * 24, 24)
+    c["X"], c["y"], c["gX"] = c["X"][sel].contiguous(), c["y"][:, sel].contiguous(), c["gX"][sel].contiguous()
+    c["noise_sd"] = float(z["f64_noise_sd"])          # softplus of the model's fp32-born noise parameter
+    out = hip_eval(c)
+    rt = 1e-5
+    assert float(out["elbo"]) == pytest.approx(float(z["f64_elbo"]), rel=rt)
+    torch.testing.assert_close(out["kl"].cpu(), torch.from_numpy(z["f64_kl"]), rtol=rt, atol=0)
+    torch.testing.assert_close(out["loglik"].cpu(), torch.from_numpy(z["f64_loglik"]), rtol=rt, atol=0)
+    idx = torch.from_numpy(z["f64_idx"])
+    mean, scale = torch.from_numpy(z["f64_mean"]), torch.from_numpy(z["f64_scale"])
+    torch.testing.assert_close(out["mean"].cpu()[:, idx], mean, rtol=rt, atol=rt * float(mean.abs().max()))
+    torch.testing.assert_close(out["scale"].cpu()[:, idx], scale, rtol=rt, atol=0)
+    assert float(out["elbo"]) == pytest.approx(float(z["f64_elbo"]), rel=1e-9)      # what it actually achieves
+
+
 def _against_reference_run(fixture, c):
     """HIP path (the configuration's own precision, fp32) against the reference's fp32 and fp64 runs of the same inputs
     (tests/golden/make_baseline_golden.py): ELBO and its parts to the fp32 tolerance (they agree far inside it), q(F) at the
