@@ -86,6 +86,35 @@ def run(cfg, dtype, n_spots=None, nidx=4096, stride=1, **kw):
                 noise_sd=np.float64(float(s)))      # softplus of the (float32-initialised) noise parameter, as the model used it
 
 
+def run_grads(cfg, dtype, **kw):
+    """Gradients of -ELBO w.r.t. every parameter through the reference's own autograd graph (loss.backward(), utilities.py:485)."""
+    c = make_config(cfg, **kw)
+    L, M = c["mu"].shape
+    k = rk.NSF_RBF(L=L)
+    k.sigma = nn.Parameter(c["sigma"].reshape(L, 1, 1).double().clone())
+    k.lengthscale = nn.Parameter(c["lengthscale"].reshape(L, 1, 1).double().clone())
+    gp = rgp.WSVGP(k, dim=2, M=M, jitter=c["jitter"])
+    gp.Z = nn.Parameter(c["Z"].double().clone())
+    gp.mu = nn.Parameter(c["mu"].double().clone())
+    gp.Lu = nn.Parameter(c["Lu_raw"].double().clone())
+    model = rl.ExactLikelihood(gp, noise=inv_softplus(c["noise_sd"]))
+    model = model.double() if dtype == torch.float64 else model.float()
+    X, y = c["X"].to(dtype), c["y"].to(dtype)
+    t0 = time.time()
+    pY, qF, qU, pU = model(X=X, E=1)
+    s = torch.nn.functional.softplus(model.noise)
+    kl = torch.stack([whitened_KL(qU.mean[l], qU.scale_tril[l]) for l in range(L)]).sum()
+    loss = -(pY.log_prob(y).sum() - (qF.scale ** 2).sum() / (2 * s ** 2) - kl)
+    loss.backward()
+    gLu = gp.Lu.grad.detach()
+    print(f"cfg {cfg} grads {dtype}: loss {float(loss):.6f}  ({time.time() - t0:.1f} s)", flush=True)
+    return dict(loss=np.float64(float(loss)), noise_sd=np.float64(float(s)), grad_mu=gp.mu.grad.numpy(),
+                grad_Z=gp.Z.grad.numpy(), grad_sigma=k.sigma.grad.reshape(-1).numpy(),
+                grad_lengthscale=k.lengthscale.grad.reshape(-1).numpy(), grad_noise=np.float64(float(model.noise.grad)),
+                grad_Lu_rowsum=gLu.sum(-1).numpy(), grad_Lu_colsum=gLu.sum(-2).numpy(),
+                grad_Lu_diag=torch.diagonal(gLu, dim1=-2, dim2=-1).numpy().copy(), grad_Lu_absmax=np.float64(float(gLu.abs().max())))
+
+
 def save(name, f64, f32):
     out = {}
     for tag, r in (("f64", f64), ("f32", f32)):
@@ -97,6 +126,8 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if os.environ.get("GPZ_BASELINE_ONLY", "") in ("", "2"):
         save("baseline_cfg2.npz", run(2, torch.float64), run(2, torch.float32))
+    if os.environ.get("GPZ_BASELINE_ONLY", "") in ("", "2g"):    # configs[1]: the training step's gradients, all parameters
+        save("baseline_cfg2_grads.npz", run_grads(2, torch.float64), run_grads(2, torch.float32))
     if os.environ.get("GPZ_BASELINE_ONLY", "") in ("", "5"):     # configs[4]: MGGP, fp64 (its stated precision) and fp32, every 24th spot
         save("baseline_cfg5_slice.npz", run(5, torch.float64, n_spots=8192, nidx=1024, stride=24),
              run(5, torch.float32, n_spots=8192, nidx=1024, stride=24))

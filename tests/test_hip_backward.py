@@ -415,3 +415,47 @@ def test_forward_precomputed_is_differentiable(name, clamp):
     assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=rt)
     for n, t in (("mu", mu), ("Lu", Lur), ("sigma", sig)):
         torch.testing.assert_close(got[n], t.grad, rtol=rt, atol=rt * float(t.grad.abs().max()), msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_config2_training_step_gradients_against_the_reference_itself(dt):
+    """BASELINE configs[1] as stated (N=50 000, M=512, L=8, NSF_RBF): gradients of -ELBO w.r.t. EVERY parameter (mu, Lu, Z,
+    sigma, lengthscale, the noise) through the module API (HIP forward + backward) against the reference's own autograd run
+    of the same step in fp64 (tests/golden/make_baseline_golden.py): the configuration's fp32 at 1e-3 of each gradient's
+    scale, an fp64 run of the HIP path at 1e-5 (north_star tolerances)."""
+    import math
+    import os
+    import numpy as np
+    import torch.nn as nn
+    import gpzoo.gp as G
+    import gpzoo.kernels as K
+    from gpzoo.likelihoods import ExactLikelihood
+    from gpzoo.utilities import whitened_KL_batched
+    from gpzoo_amd.synthetic import make_config
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "baseline_cfg2_grads.npz"), allow_pickle=False)
+    c = make_config(2)                                    # fp32-representable inputs, as the generator used
+    L, M = c["mu"].shape
+    k = K.NSF_RBF(L=L)
+    k.sigma = nn.Parameter(c["sigma"].reshape(L, 1, 1).to(dt).clone())
+    k.lengthscale = nn.Parameter(c["lengthscale"].reshape(L, 1, 1).to(dt).clone())
+    gp = G.WSVGP(k, dim=2, M=M, jitter=c["jitter"])
+    gp.Z, gp.mu, gp.Lu = (nn.Parameter(c[n].to(dt).clone()) for n in ("Z", "mu", "Lu_raw"))
+    model = ExactLikelihood(gp, noise=math.log(math.expm1(0.5)))
+    model = (model.double() if dt == torch.float64 else model.float()).cuda()
+    X, y = c["X"].to(dt).cuda(), c["y"].to(dt).cuda()
+    pY, qF, qU, pU = model(X=X, E=1)
+    s = torch.nn.functional.softplus(model.noise)
+    loss = -(pY.log_prob(y).sum() - (qF.scale ** 2).sum() / (2 * s ** 2) - whitened_KL_batched(qU.mean, qU.scale_tril).sum())
+    loss.backward()
+    rt = 1e-5 if dt == torch.float64 else 1e-3
+    assert float(loss) == pytest.approx(float(z["f64_loss"]), rel=rt)
+    gLu = gp.Lu.grad.double().cpu()
+    got = {"grad_mu": gp.mu.grad, "grad_Z": gp.Z.grad, "grad_sigma": k.sigma.grad.reshape(-1),
+           "grad_lengthscale": k.lengthscale.grad.reshape(-1), "grad_Lu_rowsum": gLu.sum(-1), "grad_Lu_colsum": gLu.sum(-2),
+           "grad_Lu_diag": torch.diagonal(gLu, dim1=-2, dim2=-1)}
+    for n, v in got.items():
+        ref = torch.from_numpy(z["f64_" + n])
+        scale = float(z["f64_grad_Lu_absmax"]) * (10 if "sum" in n else 1) if n.startswith("grad_Lu") else float(ref.abs().max())
+        torch.testing.assert_close(v.double().cpu().reshape(ref.shape), ref, rtol=rt, atol=rt * scale, msg=lambda m: f"{n}: {m}")
+    assert float(model.noise.grad) == pytest.approx(float(z["f64_grad_noise"]), rel=rt)
