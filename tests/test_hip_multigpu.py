@@ -139,20 +139,22 @@ def test_config5_mggp_fp64_as_eight_shards_full_size():
     assert a["mean"].dtype == torch.float64 and a["mean"].shape == (32, 200_000)
 
 
-def test_bench_two_ranks_is_baseline_configs3_strong_scaled():
-    """`python bench.py --gpus 2` defaults to BASELINE configs[3]: the L=256 model, 128 latents per rank, strong scaling
-    (a gloo rehearsal on this one-GPU box); the all-reduced ELBO is the single-process L=256 ELBO on the same spots."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_two_ranks_is_baseline_configs3_strong_scaled(world):
+    """`python bench.py --gpus N` defaults to BASELINE configs[3]: the L=256 model, 256 / N latents per rank (128 on two
+    GPUs, 64 on four), strong scaling (a gloo rehearsal on this one-GPU box); the all-reduced ELBO is the single-process
+    L=256 ELBO on the same spots."""
     from gpzoo_amd import ops
     from gpzoo_amd.configs import spec_for_config
     from gpzoo_amd.synthetic import make_config
     env = dict(os.environ, GPZ_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--N", "8192", "--steps", "1",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--N", "8192", "--steps", "1",
                         "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["scaling"] == "strong"
-    assert res["config"]["latents_total"] == 256 and res["config"]["latents_per_rank"] == [128, 128]
+    assert res["n_gpus"] == world and res["ranks"] == world and res["scaling"] == "strong"
+    assert res["config"]["latents_total"] == 256 and res["config"]["latents_per_rank"] == [256 // world] * world
     assert "configs[3]" in res["config"]["workload"] and "L=256" in res["config"]["workload"]
     assert res["value"] == pytest.approx(1e3 / res["ms_per_step"], rel=1e-9)      # L=256-latent evaluations per second
     assert res["value_per_32_latents"] == pytest.approx(8 * res["value"], rel=1e-12)
