@@ -1,22 +1,9 @@
 // diag128.hip -- Cholesky factor AND inverse of a 128x128 SPD diagonal block, one workgroup per
 // matrix, fp64, everything resident in LDS (the "LDS staging of the diagonal panel" of the
-// blocked right-looking factorisation, reference call sites gp.py:213/270/360).
-//
-// The block is processed as a 4x4 grid of 32x32 sub-blocks:
-//   * a 32x32 diagonal sub-block is factored and inverted by ONE wave with the rows held in
-//     registers; the pivot column / the row being eliminated is broadcast with v_readlane, so the
-//     sweep needs no LDS traffic and no barrier (wavefront-level reductions);
-//   * the sub-panel solve  L[a][s] = A[a][s] inv(L[s][s])^T  and the in-block trailing update
-//     A[a][b] -= L[a][s] L[b][s]^T  run on v_mfma_f64_16x16x4_f64 with operands read from LDS;
-//   * the inverse of the whole block is assembled by recursive doubling (32 -> 64 -> 128), again on
-//     MFMA; the accumulator tile of C*A is fed straight back as the B operand of -B*(C*A) (the f64
-//     C/D layout row = (lane>>4) + 4*reg makes register g of a tile exactly k-step g's operand).
-// Storage: S[128][129] doubles.  L lives row-major in the lower triangle; the inverse X is kept
-// transposed and shifted one column right, X[i][c] at S[c][i+1], which is free space.  A compact
-// [32][32] column buffer and the reciprocal diagonal of the sub-block in flight follow S.
+// blocked right-looking factorisation, reference call sites gp.py:213/270/360).  The phases live in
+// csrc/diag128.h (shared with the one-launch cooperative factorisation, csrc/coop.hip); this file is the
+// stand-alone kernel of the launch-per-step path and of the substitution solve (inverse-only mode).
 #include "common.h"
-
-#include <type_traits>
 
 namespace gpz {
 
@@ -31,423 +18,33 @@ __device__ unsigned long long g_diag_stamps[64];
       g_diag_stamps[i] = t_;                                                          \
     }                                                                                 \
   } while (0)
-#else
-#define GPZ_STAMP(i) do {} while (0)
 #endif
 
-namespace {
-constexpr int DP = 129;  // LDS pitch
-typedef double d4 __attribute__((ext_vector_type(4)));
+}  // namespace gpz
 
-__device__ __forceinline__ double bcast(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
+#include "diag128.h"
 
-__device__ __forceinline__ d4 mma(double a, double b, d4 c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-
-// X[i][c], i >= c, of the inverse
-__device__ __forceinline__ double& XT(double* S, int c, int i) { return S[c * DP + i + 1]; }
-
-// A zero the compiler cannot see through, held in a VGPR: added to a uniform LDS address it keeps the
-// broadcast loads in vector registers (otherwise every loaded value is moved to an SGPR pair with
-// v_readlane and the 500 live multipliers spill).
-__device__ __forceinline__ int vzero() {
-  int z;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-  return z;
-}
-
-// sqrt(d) and 1/sqrt(d) in fp64 from the hardware seed (v_rsq_f64, relative error ~2^-23) by two coupled Goldschmidt
-// steps  r = 1/2 - g h;  g += g r;  h += h r  (g -> sqrt(d), h -> 1/(2 sqrt(d)); quadratic: 2^-23 -> 2^-45 -> < 2^-53).
-// Both results come out of ONE chain of 6 dependent operations; Newton steps for 1/sqrt(d) followed by a corrected
-// product for sqrt(d) took 13, and this chain sits on the critical path of every column of the factorisation.
-__device__ __forceinline__ void sqrt_rsqrt(double d, double& sq, double& rs) {
-  const double y = __builtin_amdgcn_rsq(d);
-  double g = d * y, h = 0.5 * y;
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const double r = fma(-g, h, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-  }
-  sq = g;
-  rs = h + h;
-}
-
-// One wave: right-looking Cholesky of the 32x32 block at offset o.  Lane i (and its twin i+32) holds row i in
-// registers.  Per column the dependent chain is: pivot (v_readlane of the running diagonal), its reciprocal square
-// root (v_rsq_f64 + Newton steps: ~17 dependent fp64 operations, ~200 cycles), the multipliers l_ij = a_ij r.  What
-// the NEXT column needs from this one is only a_(i,j+1) and the running diagonal a_ii - sum_k l_ik^2, so those two are
-// updated at once (multiplier by v_readlane) and the other 30 - j row updates of the column are deferred into the next
-// column's body, where they issue in the latency shadow of its pivot chain with multipliers read back from the
-// compact column buffer CB[j][k] (uniform-address LDS broadcasts; the write -> read round trip is off the critical
-// path by then).  Stamps (tools/diag_stamps.sh): 600 -> ~250 cycles per column against everything done in place.
-// RI[j] = 1 / l_jj for the inverse.
-__device__ __forceinline__ void factor32(double* S, double* CBu, double* RI, int o, int lane, int32_t* info,
-                                         int64_t gbase, int64_t m_real) {
-  const int zz = vzero();          // also keeps the 32 lane-compare masks from being hoisted out of the caller's loop
-  const int i = (lane & 31) + zz;
-  const double* CB = CBu + zz;
-  double a[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) a[k] = S[(o + i) * DP + o + k];
-  double diag = S[(o + i) * DP + o + i];
-  double lprev = 0.0;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    double d = bcast(diag, j);
-    if (!(d > 0.0)) {
-      if (lane == 0 && gbase + j < m_real) atomicCAS(info, 0, (int)(gbase + j + 1));
-      d = 1.0;
-    }
-    // deferred row updates of column j-1 (k = j was done on the spot there): independent of the pivot chain below
-    if (j >= 1) {
-#pragma unroll
-      for (int k = j + 1; k < 32; ++k) a[k] = fma(-lprev, CB[(j - 1) * 32 + k], a[k]);
-    }
-    double sq, r;
-    sqrt_rsqrt(d, sq, r);
-    const double lj = (i == j) ? sq : a[j] * r;      // rows i < j carry garbage that is never read back
-    diag = fma(-lj, lj, diag);
-    if (j + 1 < 32) a[j + 1] = fma(-lj, bcast(lj, j + 1), a[j + 1]);   // what column j+1 needs, now
-    CBu[j * 32 + i] = lj;                             // twin lanes store the same value to the same address
-    if (i >= j) S[(o + i) * DP + o + j] = lj;
-    // RI[j] doubles as the "column j is in LDS" flag for the wave that inverts this sub-block behind us (it was zeroed
-    // before the sweep; 1 / l_jj > 0).  Stored LAST, as a release at WAVEFRONT scope: that only keeps the compiler from
-    // moving the stores above behind it -- the hardware executes a wave's LDS operations in order -- whereas a
-    // workgroup-scope release would make this wave drain its LDS queue in every column of the pivot chain.
-    __hip_atomic_store(&RI[j], r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WAVEFRONT);   // wave-uniform
-    lprev = lj;
-    // pin the updates to this column: LLVM otherwise sinks each one to the column that consumes it and keeps
-    // all 496 broadcast values alive until then (spills)
-#pragma unroll
-    for (int k = j + 1; k < 32; ++k) asm volatile("" : "+v"(a[k]));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// Inverse-only mode: the column buffer and reciprocal diagonal of an already factored block.
-__device__ __forceinline__ void stage32(const double* S, double* CB, double* RI, int o, int lane) {
-  const int i = lane & 31;
-  if (lane < 32) {
-    for (int k = 0; k <= i; ++k) CB[k * 32 + i] = S[(o + i) * DP + o + k];
-    RI[i] = 1.0 / S[(o + i) * DP + o + i];
-  }
-}
-
-// One wave: inverse of the factored 32x32 lower-triangular block by column-oriented forward
-// substitution; lane c owns column c of the inverse, x_ii = acc_ii / l_ii, then acc_m -= l_m,ii x_ii
-// (independent FMAs fed by broadcast reads of column ii).
-__device__ __forceinline__ void invert32(double* S, const double* CBu, const double* RIu, int o, int lane) {
-  const int z = vzero();
-  const int c = (lane & 31) + z;
-  const double* CB = CBu + z;
-  const double* RI = RIu + z;
-  double acc[32];
-#pragma unroll
-  for (int m = 0; m < 32; ++m) acc[m] = (m == c) ? 1.0 : 0.0;
-  // column ii of L (the multipliers of step ii) is fetched one step ahead into the other half of cb[][]: the factor is
-  // complete before this loop, so only the order of the loads decides whether each step waits for an LDS round trip
-  double cb[2][32], ri[2];
-#pragma unroll
-  for (int m = 1; m < 32; ++m) cb[0][m] = CB[m];
-  ri[0] = RI[0];
-#pragma unroll
-  for (int ii = 0; ii < 32; ++ii) {
-    if (ii + 1 < 32) {
-#pragma unroll
-      for (int m = ii + 2; m < 32; ++m) cb[(ii + 1) & 1][m] = CB[(ii + 1) * 32 + m];
-      ri[(ii + 1) & 1] = RI[ii + 1];
-    }
-    const double x = acc[ii] * ri[ii & 1];
-    if (lane < 32 && ii >= c) XT(S, o + c, o + ii) = x;
-#pragma unroll
-    for (int m = ii + 1; m < 32; ++m) acc[m] = fma(-cb[ii & 1][m], x, acc[m]);
-#pragma unroll
-    for (int m = ii + 1; m < 32; ++m) asm volatile("" : "+v"(acc[m]));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// invert32 run by a SECOND wave while the first one is still factoring the sub-block: step ii needs column ii of L
-// and 1 / l_ii only, which factor32 publishes column by column (RI[ii] turns non-zero last).  The substitution (~220-390 cycles per step) is faster than the factorisation (~415 per column), so this
-// wave trails by one step and the inverse is complete a few hundred cycles after the factor instead of 7 000.
-__device__ __forceinline__ void invert32_follow(double* S, const double* CBu, double* RIu, int o, int lane) {
-  const int z = vzero();
-  const int c = (lane & 31) + z;
-  const double* CB = CBu + z;
-  double* RI = RIu + z;
-  double acc[32];
-#pragma unroll
-  for (int m = 0; m < 32; ++m) acc[m] = (m == c) ? 1.0 : 0.0;
-#pragma unroll
-  for (int ii = 0; ii < 32; ++ii) {
-    double ri;
-    while ((ri = __hip_atomic_load(&RI[ii], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0.0) __builtin_amdgcn_s_sleep(2);
-    double cb[32];
-#pragma unroll
-    for (int m = ii + 1; m < 32; ++m) cb[m] = CB[ii * 32 + m];
-    const double x = acc[ii] * ri;
-    if (lane < 32 && ii >= c) XT(S, o + c, o + ii) = x;
-#pragma unroll
-    for (int m = ii + 1; m < 32; ++m) acc[m] = fma(-cb[m], x, acc[m]);
-#pragma unroll
-    for (int m = ii + 1; m < 32; ++m) asm volatile("" : "+v"(acc[m]));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-}  // namespace
+namespace gpz {
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void diag128_kernel(double* __restrict__ A, int64_t lda, int64_t stride, int bk,
                                                      double* __restrict__ Dinv, int64_t dinv_stride,
                                                      int32_t* __restrict__ info, int64_t m_real, int factor) {
   extern __shared__ __attribute__((aligned(16))) double S[];  // [128][129] + column buffer [32][32] + 1/diag [32]
-  double* CB = S + 128 * DP;
-  double* RI = CB + 32 * 32;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x;
   const int b = blockIdx.x;
   if (bk < 0) bk = blockIdx.y;   // all diagonal blocks in one launch (inverse-only mode)
   double* Ab = A + (int64_t)b * stride + (int64_t)bk * 128 * (lda + 1);
   GPZ_STAMP(0);
-  {
-    // the whole block with 32 independent 16-byte loads per thread in flight (a rolled load -> LDS loop pays
-    // one memory round trip per element: 64 x ~0.7 us); the strict upper triangle is zeroed on the way in
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    d2 v[32];
-#pragma unroll
-    for (int it = 0; it < 32; ++it) {
-      const int e2 = tid + 256 * it, i = e2 >> 6, j = (e2 & 63) * 2;
-      v[it] = *reinterpret_cast<const d2*>(Ab + (int64_t)i * lda + j);
-    }
-#pragma unroll
-    for (int it = 0; it < 32; ++it) {
-      const int e2 = tid + 256 * it, i = e2 >> 6, j = (e2 & 63) * 2;
-      S[i * DP + j] = (j <= i) ? v[it][0] : 0.0;
-      S[i * DP + j + 1] = (j + 1 <= i) ? v[it][1] : 0.0;
-    }
-  }
-  if (tid < 128) S[tid * DP + 128] = 0.0;
-  if (tid < 32) RI[tid] = 0.0;
+  diag::load_block<256>(S, Ab, lda, tid);
+  diag::prepare(S, tid);
   __syncthreads();
   GPZ_STAMP(1);
-
-  for (int s = 0; s < 4; ++s) {
-    const int o = 32 * s;
-    if (factor) {
-      // wave 0 factors, wave 1 inverts one column behind it.  (Letting the idle waves 2 and 3 write the finished block
-      // column of L back meanwhile was measured: the final write-back shrinks by 3.5 k cycles and factor32 grows by as
-      // much from the LDS contention.)
-      if (w == 0) {
-        factor32(S, CB, RI, o, lane, info + b, (int64_t)bk * 128 + o, m_real);
-        GPZ_STAMP(2 + 4 * s);
-      } else if (w == 1) {
-#ifndef GPZ_DIAG_NOFOLLOW
-        invert32_follow(S, CB, RI, o, lane);
-#endif
-      }
-    } else if (w == 0) {
-      stage32(S, CB, RI, o, lane);
-      invert32(S, CB, RI, o, lane);
-    }
-    __syncthreads();
-    if (factor && w == 2 && lane < 32) RI[lane] = 0.0;   // flags of the next sub-block (two barriers away)
-    GPZ_STAMP(3 + 4 * s);
-    if (!factor || s == 3) continue;
-    const int R0 = o + 32;
-    // ---- sub-panel: rows R0..127, columns o..o+31, in place: L = A * inv(Lss)^T ----
-    {
-      const int ntiles = ((128 - R0) / 16) * 2;
-      d4 acc[3];
-#pragma unroll
-      for (int u = 0; u < 3; ++u) acc[u] = d4{0, 0, 0, 0};
-      // every wave owns ntiles / 4 = 3 - s tiles (t = w, w+4, w+8): advanced together k-step by k-step, as independent
-      // MFMA chains, in a body specialised on that count (MFMAs under a run-time condition make hipcc shuffle the
-      // accumulators through VGPR copies: measured 2x slower)
-      auto panel = [&](auto nu_c) __attribute__((always_inline)) {
-        constexpr int NU = decltype(nu_c)::value;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const int k = 4 * kk + q;
-#pragma unroll
-          for (int u = 0; u < NU; ++u) {
-            const int t = w + 4 * u;
-            const int i0 = R0 + 16 * (t >> 1), j = 16 * (t & 1) + r;
-            const double av = S[(i0 + r) * DP + o + k];
-            const double bv = (j >= k) ? XT(S, o + k, o + j) : 0.0;   // inv(Lss)[j][k]
-            acc[u] = mma(av, bv, acc[u]);
-          }
-        }
-      };
-      if (s == 0) panel(std::integral_constant<int, 3>{});
-      else if (s == 1) panel(std::integral_constant<int, 2>{});
-      else panel(std::integral_constant<int, 1>{});
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int t = w + 4 * u;
-        if (t < ntiles) {
-          const int i0 = R0 + 16 * (t >> 1), j0 = 16 * (t & 1);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) S[(i0 + q + 4 * g) * DP + o + j0 + r] = acc[u][g];
-        }
-      }
-      __syncthreads();
-    }
-    GPZ_STAMP(4 + 4 * s);
-    // ---- in-block trailing update: A[a][b] -= L[a][s] L[b][s]^T, 16x16 tiles with a >= b ----
-    {
-      const int n16 = (128 - R0) / 16;
-      const int nl = n16 * (n16 + 1) / 2;
-      // two tiles of a wave at a time (t and t + 4), advanced together as independent MFMA chains; the loop condition
-      // makes both valid, so no MFMA sits under a branch; a possible last single tile follows
-      auto tile_of = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
-        int ta = 0, rem = t;
-        while (rem > ta) { rem -= ta + 1; ++ta; }
-        i0 = R0 + 16 * ta; j0 = R0 + 16 * rem;
-      };
-      int t = w;
-      for (; t + 4 < nl; t += 8) {
-        int ia, ja, ib, jb;
-        tile_of(t, ia, ja);
-        tile_of(t + 4, ib, jb);
-        d4 acc0, acc1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { acc0[g] = S[(ia + q + 4 * g) * DP + ja + r]; acc1[g] = S[(ib + q + 4 * g) * DP + jb + r]; }
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const int k = o + 4 * kk + q;
-          acc0 = mma(-S[(ia + r) * DP + k], S[(ja + r) * DP + k], acc0);
-          acc1 = mma(-S[(ib + r) * DP + k], S[(jb + r) * DP + k], acc1);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { S[(ia + q + 4 * g) * DP + ja + r] = acc0[g]; S[(ib + q + 4 * g) * DP + jb + r] = acc1[g]; }
-      }
-      if (t < nl) {
-        int i0, j0;
-        tile_of(t, i0, j0);
-        d4 acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = S[(i0 + q + 4 * g) * DP + j0 + r];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const int k = o + 4 * kk + q;
-          acc = mma(-S[(i0 + r) * DP + k], S[(j0 + r) * DP + k], acc);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) S[(i0 + q + 4 * g) * DP + j0 + r] = acc[g];
-      }
-      __syncthreads();
-    }
-    GPZ_STAMP(5 + 4 * s);
-  }
+  diag::factor_block(S, tid, info + b, (int64_t)bk * 128, m_real, factor);
   GPZ_STAMP(18);
-
-  // ---- write the factor back (zeros above the diagonal) ----
-  if (factor) {
-#pragma unroll 1
-    for (int e0 = tid; e0 < 128 * 128; e0 += 256 * 8) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + 256 * u, i = e >> 7, j = e & 127;
-        v[u] = (j <= i) ? S[i * DP + j] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + 256 * u;
-        Ab[(int64_t)(e >> 7) * lda + (e & 127)] = v[u];
-      }
-    }
-  }
-
+  if (factor) diag::store_factor<256>(S, Ab, lda, tid);
   GPZ_STAMP(19);
-  // ---- inverse, level 1: 32 -> 64.  wave = (pair p, column tile jt of the left block) ----
-  {
-    const int p = w >> 1, jt = w & 1;
-    const int oA = 64 * p, oB = oA + 32;
-    const int j = 16 * jt + r;
-    d4 T[2], X[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      T[it] = d4{0, 0, 0, 0};
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const int k = 4 * kk + q;
-        const double av = S[(oB + 16 * it + r) * DP + oA + k];                 // C = L[2p+1][2p]
-        const double bv = (k >= j) ? XT(S, oA + j, oA + k) : 0.0;              // A^-1[k][j]
-        T[it] = mma(av, bv, T[it]);
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      X[it] = d4{0, 0, 0, 0};
-      const int i = 16 * it + r;
-#pragma unroll
-      for (int kt = 0; kt <= it; ++kt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int k = 16 * kt + 4 * g + q;
-          const double av = (k <= i) ? XT(S, oB + k, oB + i) : 0.0;            // B^-1[i][k]
-          X[it] = mma(-av, T[kt][g], X[it]);
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) XT(S, oA + j, oB + 16 * it + q + 4 * g) = X[it][g];
-  }
-  __syncthreads();
-  GPZ_STAMP(20);
-  // ---- inverse, level 2: 64 -> 128.  wave = column tile jt of the left 64 columns ----
-  {
-    const int jt = w, j = 16 * jt + r;
-    d4 T[4], X[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) { T[kt] = d4{0, 0, 0, 0}; X[kt] = d4{0, 0, 0, 0}; }
-    // the four tiles of T (and then of X) advance together: independent MFMA chains in flight, B operand shared
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const int k = 4 * kk + q;
-      const double bv = (k >= j) ? XT(S, j, k) : 0.0;                          // A^-1[k][j], A = X[0:64][0:64]
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) T[kt] = mma(S[(64 + 16 * kt + r) * DP + k], bv, T[kt]);   // C = L[64:128][0:64]
-    }
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int k = 16 * kt + 4 * g + q;
-#pragma unroll
-        for (int it = kt; it < 4; ++it) {
-          const int i = 16 * it + r;
-          const double av = (k <= i) ? XT(S, 64 + k, 64 + i) : 0.0;            // B^-1[i][k], B = X[64:][64:]
-          X[it] = mma(-av, T[kt][g], X[it]);
-        }
-      }
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) XT(S, j, 64 + 16 * it + q + 4 * g) = X[it][g];
-  }
-  __syncthreads();
-  GPZ_STAMP(21);
-  double* Db = Dinv + (int64_t)b * dinv_stride + (int64_t)bk * 128 * 128;
-#pragma unroll 1
-  for (int e0 = tid; e0 < 128 * 128; e0 += 256 * 8) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + 256 * u, i = e >> 7, c = e & 127;
-      v[u] = (c <= i) ? XT(S, c, i) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) Db[e0 + 256 * u] = v[u];
-  }
+  diag::inverse_levels(S, tid);
+  diag::store_inverse<256>(S, Dinv + (int64_t)b * dinv_stride + (int64_t)bk * 128 * 128, 128, tid);
   GPZ_STAMP(22);
 }
 

@@ -17,9 +17,11 @@
 // inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]] is applied level by level,
 // two MFMA GEMMs per level batched over all pairs and latents.
 #include "common.h"
+#include "factor.h"
 #include "gemm.h"
 
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 namespace gpz {
@@ -56,9 +58,24 @@ static int diag_lds_attr() {
 
 // In-place Cholesky of `batch` padded (Mp,Mp) fp64 matrices; Dinv receives the inverse of
 // every diagonal 128-block: (batch, Mp/128, 128, 128).
+bool factor_use_coop(int64_t Mp, bool inverse) {
+  static const bool launches = [] {
+    const char* e = std::getenv("GPZ_FACTOR_PATH");
+    return e && std::string(e) == "launches";
+  }();
+  return !launches && coop_supported(Mp, inverse);
+}
+
 int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                 int32_t* info, hipStream_t s, bool clear_info) {
+                 int32_t* info, hipStream_t s, bool clear_info, uint32_t* sync) {
   GPZ_REQUIRE(Mp % NB == 0 && Mp > 0, "potrf: padded order %lld is not a multiple of %d", (long long)Mp, NB);
+  if (sync && factor_use_coop(Mp, false)) {
+    if (clear_info) GPZ_HIP_OK(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, s));
+    prof_begin(PROF_POTRF_ALL, s);
+    if (int rc = factor_coop(A, Mp, lda, stride, batch, m_real, Dinv, nullptr, nullptr, sync, info, s)) return rc;
+    prof_end(PROF_POTRF_ALL, s);
+    return 0;
+  }
   const int nblk = (int)(Mp / NB);
   const int64_t dstride = (int64_t)nblk * NB * NB;
   const size_t lds = DIAG_LDS_BYTES;
@@ -165,6 +182,21 @@ int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* 
   return 0;
 }
 
+int factor_invert_padded(double* A, int64_t Mp, int64_t batch, int64_t m_real, double* Dinv, double* Linv, double* T,
+                         uint32_t* sync, int32_t* info, hipStream_t s) {
+  if (sync && factor_use_coop(Mp, true)) {
+    // one launch for both; the two profile slots then bracket the same interval
+    prof_begin(PROF_POTRF_ALL, s);
+    prof_begin(PROF_TRTRI, s);
+    if (int rc = factor_coop(A, Mp, Mp, Mp * Mp, batch, m_real, Dinv, Linv, T, sync, info, s)) return rc;
+    prof_end(PROF_TRTRI, s);
+    prof_end(PROF_POTRF_ALL, s);
+    return 0;
+  }
+  if (int rc = potrf_padded(A, Mp, Mp, Mp * Mp, batch, m_real, Dinv, info, s, false, nullptr)) return rc;
+  return trtri_padded(A, Mp, Mp * Mp, Dinv, Linv, Mp, batch, T, s);
+}
+
 // ---- ragged <-> padded copies for the public entry points (strided-batched, storage type S <-> fp64) ----
 // dst (batch, rp, cp) fp64 = src (batch, m, n) of type S, zero (or identity on the diagonal) outside the real extents
 template <typename S>
@@ -226,6 +258,7 @@ extern "C" size_t gpz_potrf_workspace_bytes(int64_t M, int64_t batch) {
   Carver c(nullptr);
   c.take<double>(batch * Mp * Mp);              // padded copy
   c.take<double>(batch * (Mp / NB) * NB * NB);  // Dinv
+  c.take<uint32_t>(coop_sync_words(Mp, batch)); // tickets and flags of the one-launch path
   return c.used();
 }
 
@@ -240,10 +273,11 @@ extern "C" int gpz_potrf_batched(void* A, int32_t dtype, int64_t M, int64_t lda,
   Carver c(ws);
   double* Ap = c.take<double>(batch * Mp * Mp);
   double* Dinv = c.take<double>(batch * (Mp / NB) * NB * NB);
+  uint32_t* sync = c.take<uint32_t>(coop_sync_words(Mp, batch));
   if (int rc = dtype == GPZ_F32 ? copy_in<float>(A, lda, stride_a, M, M, Ap, Mp, Mp, batch, 1, s)
                                 : copy_in<double>(A, lda, stride_a, M, M, Ap, Mp, Mp, batch, 1, s))
     return rc;
-  if (int rc = potrf_padded(Ap, Mp, Mp, Mp * Mp, batch, M, Dinv, info, s, true)) return rc;
+  if (int rc = potrf_padded(Ap, Mp, Mp, Mp * Mp, batch, M, Dinv, info, s, true, sync)) return rc;
   return dtype == GPZ_F32 ? copy_out<float>(Ap, Mp, Mp * Mp, A, lda, stride_a, M, M, batch, 1, s)
                           : copy_out<double>(Ap, Mp, Mp * Mp, A, lda, stride_a, M, M, batch, 1, s);
 }
@@ -310,4 +344,15 @@ extern "C" int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_
   }
   return dtype == GPZ_F32 ? copy_out<float>(Bp, Np, Mp * Np, B, ldb, stride_b, M, N, batch, 0, s)
                           : copy_out<double>(Bp, Np, Mp * Np, B, ldb, stride_b, M, N, batch, 0, s);
+}
+
+// Diagnostics (tools/coop_trace.py): factor + invert `batch` padded fp64 matrices (Mp a multiple of 128, pitch Mp) in
+// place; Dinv (batch, Mp/128, 128, 128), Linv and T (batch, Mp, Mp), sync: gpz_debug_factor_sync_words() words.
+extern "C" size_t gpz_debug_factor_sync_words(int64_t Mp, int64_t batch) { return coop_sync_words(Mp, batch); }
+extern "C" int gpz_debug_factor_invert(double* A, int64_t Mp, int64_t batch, double* Dinv, double* Linv, double* T,
+                                       uint32_t* sync, int32_t* info, void* stream) {
+  GPZ_REQUIRE(Mp % NB == 0 && Mp > 0, "gpz_debug_factor_invert: Mp must be a multiple of 128");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  GPZ_HIP_OK(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, s));
+  return factor_invert_padded(A, Mp, batch, Mp, Dinv, Linv, T, sync, info, s);
 }

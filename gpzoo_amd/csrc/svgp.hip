@@ -17,17 +17,13 @@
 // never stored.  All reductions are slab-based (no atomics): bitwise reproducible.
 #include "common.h"
 #include "gemmw.h"
+#include "factor.h"
 #include "gemm.h"
 
 #include <algorithm>
 #include <cstdlib>
 
 namespace gpz {
-
-int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                 int32_t* info, hipStream_t s, bool clear_info = true);
-int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* Dinv, double* Linv, int64_t Mp,
-                 int64_t batch, double* T, hipStream_t s);
 
 struct KgradArgs {
   const void* Kbar; int64_t ld, stride;
@@ -339,6 +335,7 @@ static Plan make_plan(const gpz_svgp_problem* p, int64_t chunk) {
 template <typename T>
 struct Buffers {
   double *Kzz, *Dinv, *Linv, *Tmp, *LuD, *LuW;
+  uint32_t* fsync;            // tickets and flags of the one-launch factorisation
   T *LinvG, *LuT, *muE, *Kc, *Wc, *ps1, *pm1, *ps2;
   double *ll_part, *lu_part, *fro_part, *mu_part, *chol_logdiag, *contrib;
   size_t bytes;
@@ -385,7 +382,8 @@ static Buffers<T> carve(const Plan& pl, bool whitened, void* ws) {
   b.Kzz = c.take<double>(mm);
   b.Dinv = c.take<double>(pl.L * pl.nblk * NB * NB);
   b.Linv = c.take<double>(mm);
-  b.Tmp = c.take<double>(mm / 2);
+  b.Tmp = c.take<double>(mm);
+  b.fsync = c.take<uint32_t>(coop_sync_words(pl.Mp, pl.L));
   b.LuD = whitened ? nullptr : c.take<double>(mm);
   b.LuW = whitened ? nullptr : c.take<double>(mm);
   b.LinvG = sizeof(T) == 8 ? reinterpret_cast<T*>(b.Linv) : c.take<T>(mm);
@@ -424,11 +422,10 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
     if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, p->gZ, p->gZ, b.Kzz, Mp, mm, p->jitter, 1,
                               GPZ_F64, s, p->info))
       return rc;
-    if (int rc = potrf_padded(b.Kzz, Mp, Mp, mm, L, M, b.Dinv, p->info, s, false)) return rc;
+    if (int rc = factor_invert_padded(b.Kzz, Mp, L, M, b.Dinv, b.Linv, b.Tmp, b.fsync, p->info, s)) return rc;
     hipLaunchKernelGGL((chol_out_kernel<T>), dim3(p->chol ? 64 : 1, L32), dim3(256), 0, s, b.Kzz, Mp, M,
                        static_cast<T*>(p->chol), b.chol_logdiag);
     GPZ_LAUNCH_OK();
-    if (int rc = trtri_padded(b.Kzz, Mp, mm, b.Dinv, b.Linv, Mp, L, b.Tmp, s)) return rc;
     if (sizeof(T) == 4) {
       hipLaunchKernelGGL((cast_kernel<T>), dim3(2048), dim3(256), 0, s, b.Linv, b.LinvG, L * mm);
       GPZ_LAUNCH_OK();

@@ -22,16 +22,12 @@
 //                     bitwise); the dense tails -- dS -> dLu, Cholesky backward of dLoss/dchol, the
 //                     contraction with dKzz/d(sigma, lengthscale, Z) -- reuse the fp64 GEMM and kgrad.hip.
 #include "common.h"
+#include "factor.h"
 #include "gemm.h"
 
 #include <algorithm>
 
 namespace gpz {
-
-int potrf_padded(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                 int32_t* info, hipStream_t s, bool clear_info = true);
-int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* Dinv, double* Linv, int64_t Mp,
-                 int64_t batch, double* T, hipStream_t s);
 
 struct KgradArgs {   // kgrad.hip
   const void* Kbar; int64_t ld, stride;

@@ -210,6 +210,9 @@ def _group_ids(g, n: int, dev, name: str) -> torch.Tensor:
 def _raise_info(info: torch.Tensor, what: str):
     """LAPACK convention: info > 0 = not positive-definite (order of the failing minor), info < 0 = an argument
     was illegal -- here: a group id outside [0, n_groups), flagged by the covariance fill on the device."""
+    if bool((info == -7).any()):
+        raise RuntimeError(f"{what}: a hand-off inside the one-launch factorisation timed out (info = -7); "
+                           "set GPZ_FACTOR_PATH=launches to use the launch-per-step path")
     if bool((info < 0).any()):
         raise IndexError("index out of range in self: a group id (groupsX / groupsZ) is outside [0, n_groups)")
     _raise_not_pd(info, what)
@@ -249,7 +252,7 @@ def cholesky(A: torch.Tensor) -> torch.Tensor:
     rc = lib.gpz_potrf_batched(_ptr(W), _dt(W), M, M, M * M, batch, _ptr(info), _ptr(ws), ws.numel(), _stream(A.device))
     _lib.check(rc, "gpz_potrf_batched")
     if bool(info.any()):
-        _raise_not_pd(info, "linalg.cholesky")
+        _raise_info(info, "linalg.cholesky")
     return W.reshape(A.shape)
 
 
