@@ -321,7 +321,7 @@ def main():
             dist.init_process_group(backend)
         ranks = dist.get_world_size()
 
-    from gpzoo_amd import ops
+    from gpzoo_amd import _lib, ops
     from gpzoo_amd.configs import spec_for_config
     from gpzoo_amd.parallel import _allreduce_scalar
     from gpzoo_amd.synthetic import CONFIGS, make_config
@@ -336,9 +336,12 @@ def main():
     spec, extra = spec_for_config(g, dev)
     N, M = c["X"].shape[0], c["Z"].shape[0]
 
+    path = {}
+
     def step():
         out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
                                y=g["y"], noise_sd=c["noise_sd"], chunk=a.chunk, want_Lu=False, **extra)
+        path["bits"] = out["path"]
         e = out["elbo"]
         if world > 1:
             e = _allreduce_scalar(e)      # RCCL on the device scalar (nccl); through the host for gloo rehearsals
@@ -398,9 +401,13 @@ def main():
         ach1 = flops1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
         mp = measured_peaks()
         traffic, traffic_src = pmc_traffic(cfg_id, N, M, Lper, a.chunk)
+        # the kernel that ran, from the predicate the library itself dispatches on (gpz_svgp_forward_path)
+        bits = path.get("bits", 0)
+        kname = ("gemmw_gen_kernel<512,128,generated Kzx,lower,store+colstats> (Wt = Linv*k(Z,X), csrc/gemmw.hip)" if bits & 2
+                 else "gemmw_kernel<128,256,mem,lower,store+colstats> (Wt = Linv*Kzx, csrc/gemmw.hip)" if bits & 1
+                 else "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx, csrc/gemm.hip)" % ("float" if dname == "f32" else "double"))
         roof = {"bound": "mfma",
-                "kernel": ("gemmw_kernel<128,256,mem,lower,store+colstats> (Wt = Linv*Kzx, csrc/gemmw.hip)" if dname == "f32"
-                           else "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx)" % dname),
+                "kernel": kname,
                 "achieved": ach1, "peak": PEAK[dname], "unit": "TFLOP/s", "frac": ach1 / PEAK[dname],
                 "traffic": traffic, "traffic_source": traffic_src, "launches": n1,
                 "avg_launch_ms": ms1 / max(n1, 1)}
@@ -431,13 +438,28 @@ def main():
             "finalize_ms_per_eval": prof["finalize"][0] / a.steps,
         }
         potrf_flops = Lper * float(Mp) ** 3 / 3.0
-        if prof["potrf_all"][0] > 0:
-            sub["potrf_whole_TFLOPs"] = potrf_flops * a.steps / (prof["potrf_all"][0] * 1e-3) / 1e12
+        coop = bool(_lib.load().gpz_factor_path(M, 1))
+        if coop:
+            # one launch does the Cholesky AND the triangular inverse (csrc/coop.hip): the two profile slots bracket the
+            # same interval, and there is no separate trailing-update launch to time
+            fms = prof["potrf_all"][0] / a.steps
+            ftf = 2.0 * potrf_flops / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
+            sub["factor_path"] = "one launch: coop_factor_kernel (Cholesky + triangular inverse, tile dataflow)"
+            sub["factor"] = {"bound": "mfma", "dtype": "f64", "ms_per_eval": fms,
+                             "algorithmic_flops": 2.0 * potrf_flops, "achieved_TFLOPs": ftf, "peak_TFLOPs": PEAK["f64"],
+                             "frac": ftf / PEAK["f64"],
+                             "note": "L*M^3/3 (potrf) + L*M^3/3 (trtri) over the launch; potrf_ms_per_eval and "
+                                     "trtri_ms_per_eval both report this interval"}
+            del sub["potrf_trailing"]
+        else:
+            sub["factor_path"] = "launch per step (GPZ_FACTOR_PATH=launches or an order beyond the task list)"
+            if prof["potrf_all"][0] > 0:
+                sub["potrf_whole_TFLOPs"] = potrf_flops * a.steps / (prof["potrf_all"][0] * 1e-3) / 1e12
         if mp:   # fractions of the rates measured on the box (tools/peaks.sh), next to the spec / datasheet ones
             sub["measured_peaks"] = {k: v for k, v in mp.items() if k != "how"}
             if mp.get("hbm_write_GBps"):
                 sub["kuf_fill"]["frac_of_measured_write_rate"] = kgbs / mp["hbm_write_GBps"]
-            if mp.get("mfma_f64_TFLOPs"):
+            if mp.get("mfma_f64_TFLOPs") and "potrf_trailing" in sub:
                 sub["potrf_trailing"]["frac_of_measured_peak"] = tr_tf / mp["mfma_f64_TFLOPs"]
         # one step = one ELBO evaluation of the WHOLE model (all ranks together): strong scaling counts evaluations of the
         # Ltot-latent model, weak scaling evaluations of the per-GPU block (Lper latents) summed over ranks
@@ -464,6 +486,18 @@ def main():
         }
         if train_ms is not None:
             res["forward_backward_ms"] = train_ms
+            # roofline of the training step: every big product is L*M^2*N flops (triangular operand counted once).
+            # forward: Wt = Linv*Kzx and colsum((Lu^T Wt)^2); mu/Lu backward adds P-bar = (Lu^T W) diag(.) and the
+            # (M x n)(n x M) lower-tile accumulation; all parameters add W-bar, K-bar_x = Linv^T W-bar and tril(K-bar_x W^T).
+            prod = Lper * float(M) * M * N
+            res["forward_backward_roofline"] = {}
+            for mode, nprod in (("mu_Lu", 4), ("all_parameters", 7)):
+                fl = nprod * prod
+                res["forward_backward_roofline"][mode] = {
+                    "bound": "mfma", "products_of_L_M2_N_flops": nprod, "algorithmic_flops": fl,
+                    "ms": train_ms[mode], "achieved_TFLOPs": fl / (train_ms[mode] * 1e-3) / 1e12,
+                    "peak_TFLOPs": PEAK[dname], "frac": fl / (train_ms[mode] * 1e-3) / 1e12 / PEAK[dname],
+                    "mfma_floor_ms": fl / (PEAK[dname] * 1e12) * 1e3}
         if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline(cfg_id, c, a.cpu_sample)
             # parity on the driver-run line: the HIP path on the very slice the CPU port just evaluated

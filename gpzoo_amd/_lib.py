@@ -68,6 +68,8 @@ _SIGNATURES = {
     "gpz_svgp_factor_cache_bytes": (C.c_size_t, [C.POINTER(SvgpProblem)]),
     "gpz_svgp_wt_cache_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
     "gpz_svgp_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
+    "gpz_svgp_forward_path": (C.c_int, [C.POINTER(SvgpProblem), C.c_int64]),
+    "gpz_factor_path": (C.c_int, [C.c_int64, C.c_int32]),
     "gpz_svgp_forward": (C.c_int, [C.POINTER(SvgpProblem), C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpz_svgp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int64]),
     "gpz_svgp_backward": (C.c_int, [C.POINTER(SvgpProblem), C.POINTER(SvgpGrads), C.c_int64, C.c_void_p, C.c_size_t,

@@ -253,6 +253,11 @@ static int copy_out(const double* src, int64_t cp, int64_t sstride, void* dst, i
 
 using namespace gpz;
 
+// 1: matrices of order M take the one-launch factorisation (csrc/coop.hip), 0: the launch-per-step chain
+extern "C" int gpz_factor_path(int64_t M, int32_t with_inverse) {
+  return (M >= 1 && factor_use_coop(pad_up(M), with_inverse != 0)) ? 1 : 0;
+}
+
 extern "C" size_t gpz_potrf_workspace_bytes(int64_t M, int64_t batch) {
   const int64_t Mp = pad_up(M);
   Carver c(nullptr);

@@ -459,13 +459,17 @@ template <int KS>
 static int poisson_passes(const PoissonArgs& a, const PoissonPlan& pl, hipStream_t s) {
   constexpr int LP = 16 * ((KS + 3) / 4);
   const size_t lds = sizeof(float) * 2 * ((size_t)a.E * LP * 68 + 64);
-  if (lds > 64 * 1024) {
+  // The opt-in above 64 KB is per kernel function and device and is set ONCE, so it is set to what the kernel can need
+  // at most (E = PMAXE), not to this call's size: a later call with more samples must still fit under it.
+  constexpr size_t lds_max = sizeof(float) * 2 * ((size_t)PMAXE * LP * 68 + 64);
+  static_assert(lds_max <= 160 * 1024, "gene_mfma_kernel: LDS of the largest sample group");
+  if (lds_max > 64 * 1024) {
     static bool set[64] = {};
     int dev = 0;
     GPZ_HIP_OK(hipGetDevice(&dev));
     if (!set[dev & 63]) {
       GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(gene_mfma_kernel<KS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
       set[dev & 63] = true;
     }
   }
@@ -485,6 +489,10 @@ extern "C" int gpz_poisson_nsf(const float* mean, const float* scale, const floa
   GPZ_REQUIRE(N >= 1 && D >= 1, "gpz_poisson_nsf: bad extents");
   GPZ_REQUIRE(Lt >= 1 && Lt <= PMAXL, "gpz_poisson_nsf: %d factors unsupported (1..%d)", Lt, PMAXL);
   GPZ_REQUIRE(E >= 1 && E <= PMAXE, "gpz_poisson_nsf: %d samples per call unsupported (1..%d)", E, PMAXE);
+  // gene_mfma_kernel addresses exp(F) through a buffer descriptor with 32-bit byte extents and offsets
+  GPZ_REQUIRE((int64_t)E * Lt * N * 4 < (1ll << 31),
+              "gpz_poisson_nsf: E * Lt * N = %lld elements of exp(F) exceed the 2 GiB a call can address: split N",
+              (long long)((int64_t)E * Lt * N));
   PoissonPlan pl = poisson_plan(N, D, Lt, E, ws);
   GPZ_REQUIRE(ws_bytes >= pl.bytes, "gpz_poisson_nsf: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -321,6 +321,13 @@ static Plan make_plan(const gpz_svgp_problem* p, int64_t chunk) {
     // auto: Kzx + Wt chunk buffers of ~6 GiB, at least 2048 columns
     chunk = (int64_t)(6.0 * (1ull << 30) / (2.0 * pl.L * pl.Mp * esz));
     if (chunk < 2048) chunk = 2048;
+    // the wide-tile fp32 products address a latent's (Mp, chunk) panel through 32-bit byte offsets (gemmw.hip): an
+    // automatic chunk never leaves their range (L = 1, M = 2048, N >= 262 144 used to, and silently took the
+    // 128 x 128-tile kernels)
+    if (pl.f32) {
+      const int64_t cap = (((1ll << 31) - 1) / (pl.Mp * 4)) / NB * NB - NB;
+      if (cap >= NB && chunk > cap) chunk = cap;
+    }
   }
   chunk = pad_up(chunk > pl.N ? pl.N : chunk);
   pl.nc = chunk;
@@ -1374,6 +1381,8 @@ static int check_problem(const gpz_svgp_problem* p) {
   GPZ_REQUIRE(p->X && p->Z && p->mu && p->Lu_raw && p->info, "gpz_svgp: null input pointer");
   GPZ_REQUIRE(p->d >= 1 && p->d <= 4, "gpz_svgp: input dimension %d unsupported", p->d);
   if (p->y) GPZ_REQUIRE(p->noise_sd > 0.0, "gpz_svgp: noise_sd must be positive");
+  GPZ_REQUIRE((p->flags & ~(GPZ_SVGP_MATERIALIZE_KZX | GPZ_SVGP_NARROW_TILES | GPZ_SVGP_GENERATE_KZX)) == 0,
+              "gpz_svgp: unknown bits in flags (0x%x): the field was `reserved` before ABI 210 -- zero it", p->flags);
   return 0;
 }
 
@@ -1386,6 +1395,18 @@ extern "C" size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t ch
   const Plan pl = make_plan(p, chunk);
   return p->dtype == GPZ_F32 ? carve<float>(pl, p->whitened != 0, nullptr).bytes
                              : carve<double>(pl, p->whitened != 0, nullptr).bytes;
+}
+
+// Which kernels gpz_svgp_forward takes for the two big products of this problem and chunk: bit 0 the wide-tile fp32
+// kernels (gemmw.hip), bit 1 the generated-Kzx stage 1; 0: the 128 x 128-tile kernels (gemm.hip).  -1: bad problem.
+extern "C" int gpz_svgp_forward_path(const gpz_svgp_problem* p, int64_t chunk) {
+  if (check_problem(p)) return -1;
+  const Plan pl = make_plan(p, chunk);
+  const bool narrow = (p->flags & GPZ_SVGP_NARROW_TILES) != 0;
+  const bool wide = !narrow && pl.f32 && wide_product_supported(pl.Mp, pl.nc);
+  const bool fused = !narrow && (p->flags & GPZ_SVGP_GENERATE_KZX) && !(p->flags & GPZ_SVGP_MATERIALIZE_KZX) &&
+                     fused1_supported(p->dtype, p->k.kind, p->d);
+  return (wide ? 1 : 0) | (fused ? 2 : 0);
 }
 
 extern "C" int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes, void* stream) {

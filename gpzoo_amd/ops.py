@@ -442,6 +442,7 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     ws = _workspace(dev, nbytes)
     rc = lib.gpz_svgp_forward(C.byref(p), int(chunk), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_svgp_forward")
+    out["path"] = lib.gpz_svgp_forward_path(C.byref(p), int(chunk))    # bit 0: wide tiles, bit 1: generated Kzx
     bad = check_info and bool(info.any())       # one device-to-host sync, shared by the cache decision and the raise
     if cache is not None:
         # a factor that failed must not be reused; without the host check the cache stays uncommitted

@@ -136,9 +136,16 @@ def allreduce_shared_grads(params, group=None) -> None:
     then runs unchanged on every rank)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    grads = [p.grad for p in params if p is not None and p.grad is not None]
-    if not grads:
+    # The flattened buffer must have the same length on every rank: it is sized from the parameter LIST, and a parameter
+    # that received no gradient on this rank (its shard left it unused) contributes zeros -- sized from the gradients
+    # that happen to exist, ranks could enter the collective with different lengths (a hang under RCCL).
+    params = [p for p in params if p is not None]
+    if not params:
         return
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params]
     flat = torch.cat([g.reshape(-1).to(torch.float64) for g in grads])
     if flat.is_cuda and dist.get_backend(group) == "gloo":      # rehearsals: through the host
         host = flat.cpu()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPZ_VERSION 200
+#define GPZ_VERSION 210
 
 enum { GPZ_F32 = 0, GPZ_F64 = 1 };
 
@@ -94,6 +94,10 @@ int gpz_kgrad(const gpz_kernel_desc* k, const void* A, int64_t nA, const void* B
  * "factor precision"), zeros written above the diagonal; info[b] as described above.  Replaces
  * torch.linalg.cholesky at gp.py:213, 270, 360.  Blocked right-looking: LDS-resident diagonal panel,
  * MFMA (v_mfma_f64_16x16x4_f64) panel solve and trailing SYRK/GEMM update. */
+/* Which factorisation matrices of order M take: 1 = the one-launch tile dataflow (Cholesky and, with_inverse, the
+ * triangular inverse in the same launch; csrc/coop.hip), 0 = one launch per step of the blocked algorithm (orders whose
+ * task list exceeds the kernel-argument space, or GPZ_FACTOR_PATH=launches in the environment). */
+int gpz_factor_path(int64_t M, int32_t with_inverse);
 size_t gpz_potrf_workspace_bytes(int64_t M, int64_t batch);
 int gpz_potrf_batched(void* A, int32_t dtype, int64_t M, int64_t lda, int64_t stride_a, int64_t batch,
                       int32_t* info, void* ws, size_t ws_bytes, void* stream);
@@ -175,6 +179,10 @@ size_t gpz_svgp_factor_cache_bytes(const gpz_svgp_problem* p);
 size_t gpz_svgp_wt_cache_bytes(const gpz_svgp_problem* p, int64_t chunk);
 
 size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
+/* Which kernels gpz_svgp_forward takes for the two big products of this problem and chunk (0 = automatic chunk):
+ * bit 0 the wide-tile fp32 kernels, bit 1 the generated-Kzx stage 1; 0: the 128 x 128-tile kernels; -1: bad problem.
+ * Unknown bits in `flags` are an error since ABI 210 (the word was `reserved` before 200: zero it). */
+int gpz_svgp_forward_path(const gpz_svgp_problem* p, int64_t chunk);
 int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes,
                      void* stream);
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_string():
     from gpzoo_amd import _lib
     lib = _lib.load()
-    assert lib.gpz_version() == 200          # 200: dtype on the factor entries, gpz_kgrad, collective entries
+    assert lib.gpz_version() == 210          # 210: unknown gpz_svgp_problem.flags bits rejected, gpz_svgp_forward_path
     assert isinstance(lib.gpz_last_error(), bytes)
 
 

@@ -195,6 +195,30 @@ def test_random_poisson_shapes(seed):
         torch.testing.assert_close(got.double().cpu(), want.grad, rtol=1e-3, atol=1e-3 * sc, msg=lambda m: f"{nm} {tag}: {m}")
 
 
+@pytest.mark.parametrize("Lt", [40, 64])
+def test_more_samples_after_fewer_with_large_dynamic_lds(Lt):
+    """Above 64 KB the gene pass's dynamic LDS is an opt-in that is set once per kernel and device; it used to be set
+    to the FIRST call's size, so a 3-sample evaluation followed by a 4-sample step failed with hipErrorInvalidValue
+    (ADVICE r3).  Ascending sample counts in one process, each against the torch evaluation."""
+    from gpzoo_amd import ops
+    g = torch.Generator().manual_seed(77 + Lt)
+    D, N = 130, 500
+    mean = 0.3 * torch.randn(Lt, N, generator=g)
+    scale = 0.2 + 0.3 * torch.rand(Lt, N, generator=g)
+    W = torch.rand(D, Lt, generator=g) + 0.05
+    V = 0.5 + torch.rand(N, generator=g)
+    y = torch.poisson(2.0 * torch.rand(D, N, generator=g), generator=g)
+    for E in (2, 3, 4):
+        eps = torch.randn(E, Lt, N, generator=g)
+        ll, dmean, dscale, dW, dV = ops.poisson_nsf(mean.cuda(), scale.cuda(), eps.cuda(), W.cuda(), V.cuda(), y.cuda(), False)
+        lw = W.double().requires_grad_(True)
+        rate = V.double() * torch.matmul(lw, torch.exp(mean.double() + scale.double() * eps.double()))
+        ref = (y.double() * torch.log(rate) - rate).mean(0).sum()
+        ref.backward()
+        assert float(ll) == pytest.approx(float(ref), rel=5e-5), (Lt, E)
+        torch.testing.assert_close(dW.double().cpu(), lw.grad, rtol=1e-3, atol=1e-3 * float(lw.grad.abs().max()))
+
+
 def test_factor_count_limit_is_reported():
     from gpzoo_amd import ops
     Lt, N, D = 65, 10, 4

@@ -283,3 +283,27 @@ def test_config3_full_size_fp32_against_fp64():
     assert float((a["mean"].double() - m64).abs().max()) <= 1e-4 * float(m64.abs().max())
     assert float(((a["scale"].double() - s64).abs() / s64).max()) <= 1e-4
     torch.testing.assert_close(a["kl"], b["kl"], rtol=1e-6, atol=0)
+
+
+def test_one_latent_beyond_the_32_bit_panel_keeps_the_wide_tile_kernels():
+    """L = 1, M = 2048, N = 300 000: the automatic chunk (6 GiB / (2 L Mp esz)) used to be 2.46e9 bytes per latent panel,
+    beyond the 32-bit byte offsets of the wide-tile fp32 products, and the forward silently took the 128 x 128-tile kernels
+    (VERDICT r3 weak #8).  The chunk is capped now: the wide kernels run (gpz_svgp_forward_path), the ELBO of the whole
+    problem equals the sum over explicit 100 000-spot chunks, and an 8192-spot slice matches the oracle."""
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(3, N=300_000, M=2048, L=1)
+    out = hip_eval(c, want_Lu=False)
+    assert out["path"] & 1, "the forward left the wide-tile kernels"
+    small = hip_eval(c, chunk=100_000, want_Lu=False)
+    assert small["path"] & 1
+    assert float(out["elbo"]) == pytest.approx(float(small["elbo"]), rel=1e-9)
+    torch.testing.assert_close(out["mean"], small["mean"], rtol=0, atol=0)      # chunk invariance, bit for bit
+    sl = {k: (v[..., :8192].contiguous() if k == "y" else v[:8192].contiguous() if k == "X" else v) for k, v in c.items()}
+    ref, mean, scale = oracle_eval(sl)
+    got = hip_eval(sl, want_Lu=False)
+    assert float(got["elbo"]) == pytest.approx(float(ref), rel=1e-3)
+    torch.testing.assert_close(out["scale"][:, :8192].double().cpu().reshape(scale.shape), scale, rtol=1e-3, atol=0)
+    # a chunk asked for explicitly beyond the range is honoured and reported as what it is
+    wide_off = hip_eval(c, chunk=280_000, want_Lu=False)
+    assert not (wide_off["path"] & 1)
+    assert float(wide_off["elbo"]) == pytest.approx(float(out["elbo"]), rel=1e-6)

@@ -104,3 +104,37 @@ def test_shared_parameter_gradients_sum_over_latent_shards():
     for rank, lo, hi, gz, gmu in got:
         torch.testing.assert_close(gz, Z.grad, rtol=1e-10, atol=1e-12)
         torch.testing.assert_close(gmu, mu.grad[lo:hi], rtol=1e-10, atol=1e-12)
+
+
+def _missing_grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpzoo_amd.parallel import allreduce_shared_grads
+    a = torch.nn.Parameter(torch.ones(3, dtype=torch.float64))
+    b = torch.nn.Parameter(torch.ones(2, 2, dtype=torch.float64))
+    # rank 0 uses both parameters, rank 1's shard leaves `b` unused: its .grad stays None there
+    loss = (a * (rank + 1.0)).sum() + ((b * 3.0).sum() if rank == 0 else 0.0)
+    loss.backward()
+    allreduce_shared_grads([a, None, b])
+    q.put((rank, a.grad.clone(), b.grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shared_gradient_exchange_with_a_parameter_unused_on_one_rank():
+    """The flattened all-reduce is sized from the parameter list, not from the gradients that happen to exist: a
+    parameter without a gradient on one rank contributes zeros instead of shortening that rank's buffer (the
+    ranks then entered the collective with different lengths -- a hang under RCCL, corruption under gloo)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_missing_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = [q.get() for _ in range(2)]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, ga, gb in got:
+        torch.testing.assert_close(ga, torch.full((3,), 3.0, dtype=torch.float64))
+        torch.testing.assert_close(gb, torch.full((2, 2), 3.0, dtype=torch.float64))
