@@ -93,6 +93,9 @@ _SIGNATURES = {
     "gpz_comm_unique_id": (C.c_int, [C.c_void_p]),
     "gpz_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "gpz_allreduce_sum_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gpz_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gpz_reduce_scatter_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gpz_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gpz_comm_destroy": (C.c_int, [C.c_void_p]),
     "gpz_profile_enable": (C.c_int, [C.c_int32]),
     "gpz_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32]),

@@ -1,4 +1,6 @@
-// collective.hip -- the one exchange of the sharded evaluation: a sum of fp64 scalars over the ranks.
+// collective.hip -- the exchanges of the sharded evaluations: a sum of fp64 scalars over the ranks (Gaussian ELBO), and
+// for the latent-sharded Poisson NSF step (reference likelihoods.py:49-53, 74-97: the rate mixes latents) an all-gather
+// of q(F)'s moments with the matching reduce-scatter / all-reduce of their gradients.
 //
 // Latent GPs shard across the GPUs of a node with no data-path collective; what remains is
 // one all-reduce of the per-rank ELBO (1-3 doubles) per evaluation -- RCCL over xGMI, latency bound.  The
@@ -23,6 +25,8 @@ namespace {
 struct RcclId { char internal[128]; };          // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
 typedef void* RcclComm;                          // ncclComm_t
 constexpr int kRcclFloat64 = 8;                  // ncclFloat64
+constexpr int kRcclFloat32 = 7;                  // ncclFloat32
+constexpr int kRcclUint8 = 1;                    // ncclUint8
 constexpr int kRcclSum = 0;                      // ncclSum
 
 struct Rccl {
@@ -30,6 +34,8 @@ struct Rccl {
   int (*GetUniqueId)(RcclId*) = nullptr;
   int (*CommInitRank)(RcclComm*, int, RcclId, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
   int (*CommDestroy)(RcclComm) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
@@ -55,11 +61,13 @@ void load_rccl() {
   r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
   r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
   r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+  r.ReduceScatter = reinterpret_cast<decltype(r.ReduceScatter)>(dlsym(h, "ncclReduceScatter"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  if (r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy) g_rccl = r;
+  if (r.GetUniqueId && r.CommInitRank && r.AllReduce && r.AllGather && r.ReduceScatter && r.CommDestroy) g_rccl = r;
   else snprintf(g_rccl_why, sizeof(g_rccl_why), "symbol missing: librccl was loaded but lacks ncclGetUniqueId / "
-                "ncclCommInitRank / ncclAllReduce / ncclCommDestroy");
+                "ncclCommInitRank / ncclAllReduce / ncclAllGather / ncclReduceScatter / ncclCommDestroy");
 }
 
 int need_rccl() {
@@ -107,6 +115,28 @@ extern "C" int gpz_allreduce_sum_f64(void* comm, double* buf, int64_t n, void* s
   GPZ_REQUIRE(comm && buf && n >= 1, "gpz_allreduce_sum_f64: bad arguments");
   if (int rc = need_rccl()) return rc;
   GPZ_RCCL_OK(g_rccl.AllReduce(buf, buf, (size_t)n, kRcclFloat64, kRcclSum, comm, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int gpz_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream) {
+  GPZ_REQUIRE(comm && buf && n >= 1, "gpz_allreduce_sum_f32: bad arguments");
+  if (int rc = need_rccl()) return rc;
+  GPZ_RCCL_OK(g_rccl.AllReduce(buf, buf, (size_t)n, kRcclFloat32, kRcclSum, comm, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int gpz_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream) {
+  GPZ_REQUIRE(comm && send && recv && bytes_per_rank >= 1, "gpz_allgather: bad arguments");
+  if (int rc = need_rccl()) return rc;
+  GPZ_RCCL_OK(g_rccl.AllGather(send, recv, (size_t)bytes_per_rank, kRcclUint8, comm, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int gpz_reduce_scatter_sum_f32(void* comm, const float* send, float* recv, int64_t n_per_rank, void* stream) {
+  GPZ_REQUIRE(comm && send && recv && n_per_rank >= 1, "gpz_reduce_scatter_sum_f32: bad arguments");
+  if (int rc = need_rccl()) return rc;
+  GPZ_RCCL_OK(g_rccl.ReduceScatter(send, recv, (size_t)n_per_rank, kRcclFloat32, kRcclSum, comm,
+                                   static_cast<hipStream_t>(stream)));
   return 0;
 }
 

@@ -283,6 +283,16 @@ int gpz_wsvgp_precomputed_backward(const void* W, const void* sigma, const void*
 int gpz_comm_unique_id(void* id128_host);
 int gpz_comm_init(void** comm_out, int32_t world, int32_t rank, const void* id128_host);
 int gpz_allreduce_sum_f64(void* comm, double* buf, int64_t n, void* stream);
+/* The latent-sharded Poisson NSF step (reference likelihoods.py:49-53, 74-97: rate = softplus(W) @ exp(F) mixes the
+ * latents, SURVEY §8e "Caveat"): every rank gathers q(F)'s moments of all latents -- gpz_allgather, `bytes_per_rank`
+ * bytes from each rank into recv[rank * bytes_per_rank ...), 2 L N_b s bytes in all against D N_b s for exchanging
+ * partial rates -- runs gpz_poisson_nsf on its block of genes, and the gradients w.r.t. the moments return to the
+ * latents' owners by gpz_reduce_scatter_sum_f32 (recv = this rank's n_per_rank block of the element-wise sum of every
+ * rank's world * n_per_rank values; send and recv may not overlap); gpz_allreduce_sum_f32 sums replicated fp32
+ * gradients (the size factors V) in place.  All asynchronous on `stream`. */
+int gpz_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+int gpz_reduce_scatter_sum_f32(void* comm, const float* send, float* recv, int64_t n_per_rank, void* stream);
+int gpz_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
 int gpz_comm_destroy(void* comm);
 
 /* Timing hooks used by bench.py: HIP events recorded on `stream` around the
