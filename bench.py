@@ -313,7 +313,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ranks = 1
-    if world > 1:
+    # GPZ_BENCH_GROUP=1: create the process group and run every collective branch with ONE rank too (under the driver's
+    # launcher with --nproc-per-node 1): the RCCL code path of this file executed end to end on a one-GPU box
+    grouped = world > 1 or (os.environ.get("GPZ_BENCH_GROUP") == "1" and "WORLD_SIZE" in os.environ)
+    if grouped:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -343,12 +346,12 @@ def main():
                                y=g["y"], noise_sd=c["noise_sd"], chunk=a.chunk, want_Lu=False, **extra)
         path["bits"] = out["path"]
         e = out["elbo"]
-        if world > 1:
+        if grouped:
             e = _allreduce_scalar(e)      # RCCL on the device scalar (nccl); through the host for gloo rehearsals
         return e
 
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -368,7 +371,7 @@ def main():
     prof = ops.profile_read()
     ops.profile_enable(False)
     tmax = torch.tensor([dt_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
+    if grouped:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     t = float(tmax)
     elbo = float(elbo)
@@ -472,7 +475,7 @@ def main():
             "metric": "ELBO evals/sec (L=%d-latent evaluations, all GPUs) at M=%d inducing, N=%d, %s"
                       % (unit_L, M, N, shard),
             "value": value, "unit": "ELBO evals/s", "n_gpus": world, "ranks": ranks,
-            "backend": backend if world > 1 else None, "devices": ndev, "steps": a.steps,
+            "backend": backend if grouped else None, "devices": ndev, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": dname, "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %s, N=%d spots, M=%d, %s, %s, %s"
@@ -520,7 +523,7 @@ def main():
         elif not a.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -22,7 +22,8 @@
 namespace gpz {
 
 constexpr int PMAXL = 64;   // factors (spatial + non-spatial): the notebooks' hybrids run L = 20 spatial + T = 19..20
-constexpr int PMAXE = 4;    // Monte-Carlo samples handled per launch group
+constexpr int PMAXE = 32;   // Monte-Carlo samples per call (the reference's benchmark notebooks run E = 20)
+constexpr int PEG = 4;      // ... of which pass B holds this many exp(F) tiles in LDS at a time (a "sample group")
 
 struct PoissonArgs {
   const float* mean; const float* scale; const float* eps;   // (Lt,N), (Lt,N), (E,Lt,N)
@@ -254,8 +255,11 @@ template <int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void gene_mfma_kernel(PoissonArgs a, int SN) {
   constexpr int LT16 = (KS + 3) / 4, LP = 16 * LT16, PF = 68;      // factor rows staged (zero padded), row pitch
   extern __shared__ float smem_p[];
-  const int FB = a.E * LP * PF;                 // one buffer of exp(F): [E][LP][PF]
-  float* sF = smem_p;                           // [2][E][LP][PF]
+  // Samples go through LDS in groups of EG <= PEG: the spot tile's y stays in registers across the groups, so y is
+  // read once per pass for ANY number of samples (E = 20 in the reference's benchmarks).
+  const int EG = a.E < PEG ? a.E : PEG, NG = (a.E + EG - 1) / EG;
+  const int FB = EG * LP * PF;                  // one buffer of exp(F): [EG][LP][PF]
+  float* sF = smem_p;                           // [2][EG][LP][PF]
   float* sV = smem_p + 2 * FB;                  // [2][64]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -279,8 +283,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
   for (int lt = 0; lt < LT16; ++lt) dwt[lt] = f32x4{0, 0, 0, 0};
   const int arow = 16 * (r >> 2) + (r & 3);     // A row r of sub-tile c is spot 16 (r >> 2) + 4c + (r & 3) of the tile
   // exp(F) and V tiles arrive by LDS-DMA (one 256-byte row of 64 spots per wave instruction, no registers), double
-  // buffered: tile t + 1 travels while tile t is computed.  Reads past the end of a row's valid spots return the next
-  // row's (finite) values or, past the array, zero: those spots are masked below.  The padded factor rows are zeroed once.
+  // buffered: (tile, sample group) s + 1 travels while s is computed.  Reads past the end of a row's valid spots return
+  // the next row's (finite) values or, past the array, zero: those spots are masked below.  The padded factor rows are
+  // zeroed once.
   typedef __attribute__((address_space(3))) void lds_void;
   for (int i = threadIdx.x; i < 2 * FB; i += 256) sF[i] = 0.f;
   __syncthreads();
@@ -290,13 +295,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.V), 0, (int)(a.N * sizeof(float)), 0x00020000);
 #endif
-  auto stage = [&](int64_t tt, int buf) __attribute__((always_inline)) {
+  auto stage = [&](int64_t tt, int gi, int buf) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int64_t n0 = tt * 64;
-    for (int i = wave; i < a.E * a.Lt; i += 4) {
-      const int e = i / a.Lt, l = i - e * a.Lt;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rsrc, (lds_void*)(sF + buf * FB + (e * LP + l) * PF), 4, lane * 4,
-                                               (int)((e * per + (int64_t)l * a.N + n0) * 4), 0, 0);
+    const int e0 = gi * EG, ne = (a.E - e0 < EG) ? a.E - e0 : EG;
+    for (int i = wave; i < ne * a.Lt; i += 4) {
+      const int el = i / a.Lt, l = i - el * a.Lt;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rsrc, (lds_void*)(sF + buf * FB + (el * LP + l) * PF), 4, lane * 4,
+                                               (int)(((e0 + el) * per + (int64_t)l * a.N + n0) * 4), 0, 0);
     }
     if (wave == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(sV + buf * 64), 4, lane * 4, (int)(n0 * 4), 0, 0);
@@ -319,51 +325,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
   };
   f32x4 yv[4], yn[4];
-  if (t_lo < t_hi) { stage(t_lo, 0); load_y(t_lo, yv); }
+  if (t_lo < t_hi) { stage(t_lo, 0, 0); load_y(t_lo, yv); }
+  int buf = 0;
   for (int64_t tt = t_lo; tt < t_hi; ++tt) {
-    const int buf = (int)(tt - t_lo) & 1;
     const int64_t n0 = tt * 64;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                            // tile tt has landed; every wave is done with the other buffer
-    if (tt + 1 < t_hi) { stage(tt + 1, buf ^ 1); load_y(tt + 1, yn); }
-    f32x4 vv[4];
+    for (int gi = 0; gi < NG; ++gi, buf ^= 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                          // (tile, group) has landed; every wave is done with the other buffer
+      if (gi + 1 < NG) stage(tt, gi + 1, buf ^ 1);
+      else if (tt + 1 < t_hi) { stage(tt + 1, 0, buf ^ 1); load_y(tt + 1, yn); }
+      f32x4 vv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) vv[c] = *reinterpret_cast<const f32x4*>(sV + buf * 64 + 16 * q + 4 * c);
-    for (int e = 0; e < a.E; ++e) {
-      const float* fe = sF + buf * FB + e * LP * PF;
-      f32x4 z[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        z[c] = f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) z[c] = mfma4(fe[(4 * ks + q) * PF + arow + 4 * c], wb[ks], z[c]);
-      }
-      // G^T in place of Z^T (its common factor 1 / E is applied to dW at the end); interior tiles without masks
-      if (d_full && n0 + 64 <= a.N) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) z[c][g] = __builtin_fmaf(yv[c][g], __builtin_amdgcn_rcpf(z[c][g]), -vv[c][g]);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const bool ok = dok && n0 + 16 * q + 4 * c + g < a.N;
-            const float zz = ok ? z[c][g] : 1.f;
-            z[c][g] = ok ? __builtin_fmaf(yv[c][g], __builtin_amdgcn_rcpf(zz), -vv[c][g]) : 0.f;
-          }
-      }
-      // dW^T[factor][gene] += sum over the tile's spots: k-step (c, g) pairs G^T's register g of sub-tile c (spot
-      // 16q + 4c + g) with A[row = factor 16 lt + r][k slot q] = expF[factor][that spot]
-#pragma unroll
-      for (int lt = 0; lt < LT16; ++lt)
+      for (int c = 0; c < 4; ++c) vv[c] = *reinterpret_cast<const f32x4*>(sV + buf * 64 + 16 * q + 4 * c);
+      const int ne = (a.E - gi * EG < EG) ? a.E - gi * EG : EG;
+      for (int e = 0; e < ne; ++e) {
+        const float* fe = sF + buf * FB + e * LP * PF;
+        f32x4 z[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const f32x4 fa = *reinterpret_cast<const f32x4*>(fe + (16 * lt + r) * PF + 16 * q + 4 * c);
+          z[c] = f32x4{0, 0, 0, 0};
 #pragma unroll
-          for (int g = 0; g < 4; ++g) dwt[lt] = mfma4(fa[g], z[c][g], dwt[lt]);
+          for (int ks = 0; ks < KS; ++ks) z[c] = mfma4(fe[(4 * ks + q) * PF + arow + 4 * c], wb[ks], z[c]);
         }
+        // G^T in place of Z^T (its common factor 1 / E is applied to dW at the end); interior tiles without masks
+        if (d_full && n0 + 64 <= a.N) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) z[c][g] = __builtin_fmaf(yv[c][g], __builtin_amdgcn_rcpf(z[c][g]), -vv[c][g]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const bool ok = dok && n0 + 16 * q + 4 * c + g < a.N;
+              const float zz = ok ? z[c][g] : 1.f;
+              z[c][g] = ok ? __builtin_fmaf(yv[c][g], __builtin_amdgcn_rcpf(zz), -vv[c][g]) : 0.f;
+            }
+        }
+        // dW^T[factor][gene] += sum over the tile's spots: k-step (c, g) pairs G^T's register g of sub-tile c (spot
+        // 16q + 4c + g) with A[row = factor 16 lt + r][k slot q] = expF[factor][that spot]
+#pragma unroll
+        for (int lt = 0; lt < LT16; ++lt)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(fe + (16 * lt + r) * PF + 16 * q + 4 * c);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dwt[lt] = mfma4(fa[g], z[c][g], dwt[lt]);
+          }
+      }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) yv[c] = yn[c];
@@ -458,10 +468,10 @@ extern "C" size_t gpz_poisson_nsf_workspace_bytes(int64_t N, int64_t D, int32_t 
 template <int KS>
 static int poisson_passes(const PoissonArgs& a, const PoissonPlan& pl, hipStream_t s) {
   constexpr int LP = 16 * ((KS + 3) / 4);
-  const size_t lds = sizeof(float) * 2 * ((size_t)a.E * LP * 68 + 64);
+  const size_t lds = sizeof(float) * 2 * ((size_t)(a.E < PEG ? a.E : PEG) * LP * 68 + 64);
   // The opt-in above 64 KB is per kernel function and device and is set ONCE, so it is set to what the kernel can need
-  // at most (E = PMAXE), not to this call's size: a later call with more samples must still fit under it.
-  constexpr size_t lds_max = sizeof(float) * 2 * ((size_t)PMAXE * LP * 68 + 64);
+  // at most (a full sample group), not to this call's size: a later call with more samples must still fit under it.
+  constexpr size_t lds_max = sizeof(float) * 2 * ((size_t)PEG * LP * 68 + 64);
   static_assert(lds_max <= 160 * 1024, "gene_mfma_kernel: LDS of the largest sample group");
   if (lds_max > 64 * 1024) {
     static bool set[64] = {};

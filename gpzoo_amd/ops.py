@@ -662,7 +662,7 @@ def poisson_nsf(mean, scale, eps, W_pos, V_pos, y, with_lgamma: bool = True):
 
     mean, scale (Lt,N); eps (E,Lt,N); W_pos (D,Lt) and V_pos (N,) positive; y (D,N).  Returns
     (loglik fp64 scalar, dmean, dscale, dW, dV) with the mean over the E samples already applied.
-    Samples are processed in groups of four."""
+    Up to 32 samples go through one call (y is read once per pass whatever E is); more are split."""
     _need_cuda(mean, scale, eps, W_pos, V_pos, y)
     lib = _lib.load()
     f32 = torch.float32
@@ -672,7 +672,7 @@ def poisson_nsf(mean, scale, eps, W_pos, V_pos, y, with_lgamma: bool = True):
     Lt, N = mean.shape
     E, D = eps.shape[0], y.shape[0]
     dev = mean.device
-    eg = 4                                   # samples per call (PMAXE of csrc/poisson.hip)
+    eg = 32                                  # samples per call (PMAXE of csrc/poisson.hip)
     total = torch.zeros((), dtype=torch.float64, device=dev)
     acc = [torch.zeros((Lt, N), dtype=f32, device=dev), torch.zeros((Lt, N), dtype=f32, device=dev),
            torch.zeros((D, Lt), dtype=f32, device=dev), torch.zeros((N,), dtype=f32, device=dev)]

@@ -180,3 +180,35 @@ def test_bench_self_launches_two_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["backend"] == "gloo" and res["scaling"] == "weak"
     assert res["value"] > 0 and res["unit"] == "ELBO evals/s"
+
+
+def test_bench_under_the_drivers_launcher_with_rccl_at_one_rank():
+    """The driver's own command line -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --
+    with N = 1 and GPZ_BENCH_GROUP=1: bench.main creates the nccl (= RCCL) process group bound to the device, all-reduces the
+    device ELBO scalar every step, fences with dist.barrier, takes the MAX of the step time on a DEVICE tensor and tears the
+    group down -- every multi-rank branch of the file, executed end to end on this one-GPU box.  (An 8-rank rehearsal is not
+    possible here: the pool admits at most 6 processes on a GPU; the 8 x 32 plan itself is pinned by
+    test_bench_launcher.py::test_latent_plan_is_baseline_configs3_for_several_gpus, the eight shards at full size by
+    test_config4_256_latents_as_eight_shards_full_size, and 2- and 4-rank rehearsals run above.)"""
+    env = dict(os.environ, GPZ_DIST_BACKEND="nccl", GPZ_BENCH_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--N", "20000", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["ranks"] == 1 and res["backend"] == "nccl"
+    assert res["value"] == pytest.approx(1e3 / res["ms_per_step"], rel=1e-9) and res["roofline"]["frac"] > 0.3
+    # the all-reduced ELBO of one rank is the local one
+    from gpzoo_amd import ops
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import make_config
+    g = _to_dev(make_config(3, N=20000))
+    spec, extra = spec_for_config(g, torch.device("cuda", 0))
+    o = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], g["jitter"], g["whitened"], y=g["y"],
+                         noise_sd=g["noise_sd"], want_Lu=False, want_moments=False, **extra)
+    assert res["elbo"] == pytest.approx(float(o["elbo"]), rel=1e-12)

@@ -174,7 +174,7 @@ def test_random_poisson_shapes(seed):
     g = torch.Generator().manual_seed(900 + seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))   # noqa: E731
     D, N = [1, 7, 130, 257, 1000][ri(0, 4)], [1, 63, 64, 500, 3001][ri(0, 4)]
-    Lt, E = [1, 3, 8, 9, 20, 33, 40, 64][ri(0, 7)], [1, 2, 3, 8][ri(0, 3)]      # 40 = the notebooks' L=20 + T=20 hybrids
+    Lt, E = [1, 3, 8, 9, 20, 33, 40, 64][ri(0, 7)], [1, 2, 3, 8][ri(0, 3)]      # (8 samples: two LDS groups of pass B)      # 40 = the notebooks' L=20 + T=20 hybrids
     with_lgamma = bool(seed % 2)
     mean = 0.3 * torch.randn(Lt, N, generator=g)
     scale = 0.2 + 0.3 * torch.rand(Lt, N, generator=g)
@@ -217,6 +217,31 @@ def test_more_samples_after_fewer_with_large_dynamic_lds(Lt):
         ref.backward()
         assert float(ll) == pytest.approx(float(ref), rel=5e-5), (Lt, E)
         torch.testing.assert_close(dW.double().cpu(), lw.grad, rtol=1e-3, atol=1e-3 * float(lw.grad.abs().max()))
+
+
+@pytest.mark.parametrize("E", [5, 20, 33])
+def test_many_samples_in_one_call(E):
+    """E = 20 is what the reference's benchmark notebooks run (NSF_benchmarks.ipynb:330, 392): one call of the kernel --
+    pass B walks the samples in LDS groups of four with y held in registers, E = 5 leaves a partial last group, E = 33
+    is split by the host into 32 + 1 -- against the torch evaluation."""
+    from gpzoo_amd import ops
+    g = torch.Generator().manual_seed(500 + E)
+    D, N, Lt = 70, 300, 20
+    mean = 0.3 * torch.randn(Lt, N, generator=g)
+    scale = 0.2 + 0.3 * torch.rand(Lt, N, generator=g)
+    eps = torch.randn(E, Lt, N, generator=g)
+    W = torch.rand(D, Lt, generator=g) + 0.05
+    V = 0.5 + torch.rand(N, generator=g)
+    y = torch.poisson(2.0 * torch.rand(D, N, generator=g), generator=g)
+    ll, dmean, dscale, dW, dV = ops.poisson_nsf(mean.cuda(), scale.cuda(), eps.cuda(), W.cuda(), V.cuda(), y.cuda(), True)
+    lv = [t.double().requires_grad_(True) for t in (mean, scale, W, V)]
+    rate = lv[3] * torch.matmul(lv[2], torch.exp(lv[0] + lv[1] * eps.double()))
+    ref = torch.distributions.Poisson(rate).log_prob(y.double()).mean(0).sum()
+    ref.backward()
+    assert float(ll) == pytest.approx(float(ref), rel=5e-5)
+    for got, want, nm in zip((dmean, dscale, dW, dV), lv, ("dmean", "dscale", "dW", "dV")):
+        torch.testing.assert_close(got.double().cpu(), want.grad, rtol=1e-3, atol=1e-3 * float(want.grad.abs().max()),
+                                   msg=lambda m: f"{nm} E={E}: {m}")
 
 
 def test_factor_count_limit_is_reported():

@@ -3,6 +3,7 @@ all-reduce reproduce the single-rank ELBO.
 The per-rank evaluator is injected (the oracle stands in for the HIP pass, which needs a GPU)."""
 import os
 import socket
+import sys
 
 import pytest
 import torch
@@ -10,6 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from gpzoo_amd.synthetic import make_config
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # bench.py
 
 
 def _oracle_eval(p):
@@ -31,11 +34,11 @@ def _oracle_terms(p):
     return O.gaussian_elbo(p["y"], mean, scale, p["noise_sd"], zero), kl.sum()
 
 
-def _worker(rank, world, port, L, q):
+def _worker(rank, world, port, L, q, threads=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gpzoo_amd.parallel import sharded_elbo
-    torch.set_num_threads(2)
+    torch.set_num_threads(threads)
     full = make_config(2, N=400, M=48, L=L, dtype=torch.float64)
     e = sharded_elbo(full, L, local_eval=_oracle_eval, local_terms=_oracle_terms)   # L < world: spots shard
     # a rank may also draw only its own block (what bench.py does): same numbers, same sum
@@ -63,6 +66,28 @@ def test_two_rank_sum_matches_single_rank(L):
     ref = float(_oracle_eval(make_config(2, N=400, M=48, L=L, dtype=torch.float64)))
     assert e == pytest.approx(ref, rel=1e-12)
     assert e2 == pytest.approx(ref, rel=1e-12)
+
+
+def test_eight_rank_plan_of_baseline_configs3_sums_to_the_single_rank_elbo():
+    """The 8-GPU plan of BASELINE configs[3] rehearsed on the CPU: eight gloo ranks, 256 latents block-sharded 32 per rank
+    (the blocks bench.plan_latents deals), one scalar all-reduce -- the sum equals the single-process 256-latent ELBO.  (On
+    the GPU pool at most 6 processes may share a card, so this world size is rehearsed here, with the oracle as evaluator.)"""
+    L, world = 256, 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, L, q, 1)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    e, e2 = q.get()
+    ref = float(_oracle_eval(make_config(2, N=400, M=48, L=L, dtype=torch.float64)))
+    assert e == pytest.approx(ref, rel=1e-12)
+    assert e2 == pytest.approx(ref, rel=1e-12)
+    import bench
+    assert [len(bench.plan_latents(3, world, r, None, L, None)[3]) for r in range(world)] == [32] * world
 
 
 def _grad_worker(rank, world, port, L, q):
