@@ -24,7 +24,7 @@
 //
 // Hand-offs follow the agent-scope protocol of the CDNA4 guide: producer plain stores -> every wave s_waitcnt vmcnt(0)
 // -> barrier -> one lane: release fence, s_waitcnt, relaxed agent flag store; consumer one wave polls relaxed (sc1)
-// loads -> one lane acquire fence, s_waitcnt -> barrier -> plain loads.  A poll that sees nothing for GPZ_COOP_TIMEOUT
+// loads -> one lane acquire fence, s_waitcnt -> barrier -> plain loads.  A poll that sees nothing for five seconds
 // raises the launch's abort word, which every poll loop reads: all workgroups then leave and info reports -7.
 #include "common.h"
 #include "diag128.h"
@@ -771,7 +771,7 @@ int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batc
   p.sync = sync + 32; p.abort_word = sync;
   p.nblk = nblk; p.batch = (int)batch;
   p.gmax = std::max(1, std::min(32, 3 * nblk / 2));
-  p.timeout_ticks = 100000000ull;   // 1 s
+  p.timeout_ticks = 500000000ull;   // 5 s of the 100 MHz clock: far beyond any wait a healthy launch sees, even beside another process's kernels
   p.trace = g_coop_trace;
   const int nclus = (int)std::min<int64_t>(batch, 256);
   const int nwg = std::min(256, (nclus * p.gmax + 7) / 8 * 8);

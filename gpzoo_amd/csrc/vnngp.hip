@@ -307,6 +307,7 @@ struct VnnPlan {
   int64_t L, N, M, Mp; int K; size_t bytes;
   double *Kzz, *Kfac, *Dinv, *LuD, *S, *scratch; int64_t* idx;
   double *Linv, *Tmp, *LuE, *muE;                       // KL(qU || pU): L^{-1}, L^{-1} Lu, L^{-1} mu
+  uint32_t* fsync;                                       // tickets and flags of the one-launch Cholesky (csrc/coop.hip)
   double *gmu, *gS, *gK, *kacc, *G, *D1, *D2; void* PS;  // backward only
 };
 
@@ -327,6 +328,7 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
   pl.Tmp = c.take<double>(mm / 2 + 64);
   pl.LuE = c.take<double>(mm);
   pl.muE = c.take<double>(pl.L * pl.Mp);
+  pl.fsync = c.take<uint32_t>(coop_sync_words(pl.Mp, pl.L));
   pl.gmu = pl.gS = pl.gK = pl.kacc = pl.G = pl.D1 = pl.D2 = nullptr;
   pl.PS = nullptr;
   if (bwd) {
@@ -372,7 +374,7 @@ static int vnn_prepare(const gpz_svgp_problem* p, VnnPlan& pl, const int64_t* id
   if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, nullptr, nullptr, pl.Kzz, Mp, mm, p->jitter, 1, GPZ_F64, s))
     return rc;
   GPZ_HIP_OK(hipMemcpyAsync(pl.Kfac, pl.Kzz, sizeof(double) * L * mm, hipMemcpyDeviceToDevice, s));
-  if (int rc = potrf_padded(pl.Kfac, Mp, Mp, mm, L, M, pl.Dinv, p->info, s)) return rc;
+  if (int rc = potrf_padded(pl.Kfac, Mp, Mp, mm, L, M, pl.Dinv, p->info, s, true, pl.fsync)) return rc;
   if (p->chol) {
     hipLaunchKernelGGL((vnn_chol_out_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)M, L32), dim3(256), 0, s,
                        pl.Kfac, Mp, M, static_cast<T*>(p->chol));

@@ -158,8 +158,9 @@ def test_fp32_at_reference_default_jitter(M, small_Lu):
         rec["scale_max_rel"] = float(((out["scale"].double().cpu() - scale).abs() / scale).max())
         rec["mean_max_abs"] = float((out["mean"].double().cpu() - mean).abs().max())
         assert rec["elbo_rel"] < 1e-3
-        torch.testing.assert_close(out["mean"].double().cpu(), mean, rtol=1e-3, atol=1e-3)
-        torch.testing.assert_close(out["scale"].double().cpu(), scale, rtol=1e-3, atol=1e-3)
+        # the mean changes sign: norm-wise; the scale is strictly positive: PURE rtol (measured 7e-7 ... 5e-5)
+        torch.testing.assert_close(out["mean"].double().cpu(), mean, rtol=1e-3, atol=1e-3 * float(mean.abs().max()))
+        torch.testing.assert_close(out["scale"].double().cpu(), scale, rtol=1e-3, atol=0)
     finally:
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         try:

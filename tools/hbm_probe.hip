@@ -20,6 +20,28 @@ __global__ __launch_bounds__(256) void copy_k(const float4* __restrict__ src, fl
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// Write-only variants, to find what the write path can sustain (the Kzx fill is measured against it):
+//   chunk_k   every workgroup owns contiguous CHUNK-byte pieces and walks each front to back (1 KB per wave store,
+//             4 KB per workgroup step): long sequential runs per workgroup instead of a grid-strided interleave
+//   streams_k the fill's own shape: a workgroup step writes one 4 KB run into each of NS far-apart streams (the L
+//             latent matrices), then moves on by 4 KB in all of them
+__global__ __launch_bounds__(256) void chunk_k(float4* __restrict__ dst, size_t n, size_t chunk_vec) {
+  const float4 v = make_float4(1.f, 2.f, 3.f, (float)threadIdx.x);
+  const size_t nchunks = n / chunk_vec;
+  for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    float4* p = dst + c * chunk_vec;
+    for (size_t i = threadIdx.x; i < chunk_vec; i += 256) p[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void streams_k(float4* __restrict__ dst, size_t n, int ns, size_t run_vec) {
+  const float4 v = make_float4(1.f, 2.f, 3.f, (float)threadIdx.x);
+  const size_t per = n / ns;                     // float4s per stream
+  const size_t steps = per / 256;                // 4 KB workgroup steps per stream
+  for (size_t st = blockIdx.x * run_vec; st < steps; st += (size_t)gridDim.x * run_vec)
+    for (size_t k = 0; k < run_vec && st + k < steps; ++k)
+      for (int s = 0; s < ns; ++s) dst[(size_t)s * per + (st + k) * 256 + threadIdx.x] = v;
+}
+
 template <typename F>
 static double best_ms(F launch) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -44,6 +66,20 @@ int main() {
     const double c = best_ms([&] { hipLaunchKernelGGL(copy_k, dim3(grid), dim3(256), 0, 0, a, b, n); });
     printf("hbm blocks/CU=%d  write %.0f GB/s  read %.0f GB/s  copy %.0f GB/s (read+write bytes)\n", bpc, bytes / w / 1e6,
            bytes / r / 1e6, 2.0 * bytes / c / 1e6);
+  }
+  for (size_t chunk : {(size_t)16 << 10, (size_t)64 << 10, (size_t)1 << 20}) {
+    const double w = best_ms([&] { hipLaunchKernelGGL(chunk_k, dim3(256 * 8), dim3(256), 0, 0, a, n, chunk / 16); });
+    printf("hbm write, contiguous %zu KB pieces per workgroup: %.0f GB/s\n", chunk >> 10, bytes / w / 1e6);
+  }
+  for (int ns : {1, 8, 32}) {
+    for (size_t run : {(size_t)1, (size_t)8}) {
+      const double w = best_ms([&] { hipLaunchKernelGGL(streams_k, dim3(256 * 8), dim3(256), 0, 0, a, n, ns, run); });
+      printf("hbm write, %d streams, %zu x 4 KB per stream and workgroup turn: %.0f GB/s\n", ns, run, bytes / w / 1e6);
+    }
+  }
+  {
+    const double w = best_ms([&] { hipMemsetAsync(a, 0, bytes, 0); });
+    printf("hbm hipMemsetAsync: %.0f GB/s\n", bytes / w / 1e6);
   }
   return 0;
 }
