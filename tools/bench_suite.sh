@@ -7,10 +7,13 @@ import json, sys
 r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 k = r["kernels"]
 clk = r.get("clocks") or {}
-print("  value %.4f %s | %.2f ms/step | stage1 %.1f TF (frac %.3f; sclk %.0f MHz: frac at that clock %.3f) | stage2 %.1f TF | kfill %.0f GB/s | potrf %.2f ms (trailing %.1f TF) | trtri %.2f ms%s" % (
+fac = ("factor (Cholesky + inverse, one launch) %.3f ms = %.1f TF fp64" % (k["factor"]["ms_per_eval"], k["factor"]["achieved_TFLOPs"])
+       if "factor" in k else "potrf %.2f ms (trailing %.1f TF) | trtri %.2f ms" % (
+           k["potrf_ms_per_eval"], k["potrf_trailing"]["achieved_TFLOPs"], k["trtri_ms_per_eval"]))
+print("  value %.4f %s | %.2f ms/step | stage1 %.1f TF (frac %.3f; sclk %.0f MHz: frac at that clock %.3f) | stage2 %.1f TF | kfill %.0f GB/s | %s%s" % (
     r["value"], r["unit"], r["ms_per_step"], r["roofline"]["achieved"], r["roofline"]["frac"], clk.get("sclk_MHz_mean", 0.0),
     r["roofline"].get("frac_at_sampled_clock", 0.0), k["stage2_LuT_Wt"]["achieved_TFLOPs"],
-    k["kuf_fill"]["achieved_GBps"], k["potrf_ms_per_eval"], k["potrf_trailing"]["achieved_TFLOPs"], k["trtri_ms_per_eval"],
+    k["kuf_fill"]["achieved_GBps"], fac,
     (" | fwd+bwd %s ms" % {a: round(b, 1) for a, b in r["forward_backward_ms"].items()}) if "forward_backward_ms" in r else ""))
 PY
 }
@@ -26,14 +29,27 @@ echo "== config 4 on one GPU: L=256"
 python3 bench.py --L 256 --steps 1 --warmup 1 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== minibatch training step (N_b=7000, M=3000, L=20, fp32): tools/minibatch_step.py"
 python3 tools/minibatch_step.py 2>/dev/null | grep step
-echo "== Poisson NSF minibatch step: tools/poisson_step.py"
+echo "== Poisson NSF minibatch step: tools/poisson_step.py (E = 3, then E = 20 in one call)"
 python3 tools/poisson_step.py 2>/dev/null | tail -4
+python3 tools/poisson_step.py 20 2>/dev/null | tail -1
 echo "== VNNGP: tools/vnngp_step.py"
 python3 tools/vnngp_step.py 2>/dev/null | grep VNNGP
 echo "== batched Cholesky alone, L=32 M=2048 fp64: tools/potrf_only.py"
 python3 tools/potrf_only.py 32 2048 2>/dev/null | tail -2
 echo "== batched Cholesky alone, L=8 M=512 fp64 (config 2's factor): tools/potrf_only.py"
 python3 tools/potrf_only.py 8 512 2>/dev/null | tail -2
+echo "== the same two through the launch-per-step chain of rounds 1-3 (GPZ_FACTOR_PATH=launches)"
+GPZ_FACTOR_PATH=launches python3 tools/potrf_only.py 32 2048 2>/dev/null | tail -2
+GPZ_FACTOR_PATH=launches python3 tools/potrf_only.py 8 512 2>/dev/null | tail -2
+echo "== one-launch factorisation, timeline of a traced launch (tools/coop_trace.py: Cholesky alone, then with the inverse)"
+python3 tools/coop_trace.py 32 2048 2>/dev/null | grep -v "    D("
+python3 tools/coop_trace.py 32 2048 1 2>/dev/null | grep -v "    D("
+python3 tools/coop_trace.py 8 512 1 2>/dev/null | grep -v "    D("
+python3 tools/coop_trace.py 20 3072 1 2>/dev/null | grep -v "    D("
+echo "== config 3 with the launch-per-step factor path, for comparison"
+GPZ_FACTOR_PATH=launches python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== minibatch step with the launch-per-step factor path"
+GPZ_FACTOR_PATH=launches python3 tools/minibatch_step.py 2>/dev/null | grep step
 echo "== python bench.py --gpus 2 as typed (two ranks on this one GPU, gloo rendezvous: a rehearsal, not a scaling number)"
 GPZ_DIST_BACKEND=gloo python3 bench.py --gpus 2 --N 40000 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
