@@ -53,6 +53,7 @@ struct CoopParams {
   double* Dinv; int64_t sD;            // (batch, nblk, 128, 128) inverses of the diagonal blocks
   double* Linv; int64_t sL;            // (batch, Mp, Mp) inverse of the factor (pitch Mp), or null: factor only
   double* XT; int64_t sX;              // (batch, Mp, Mp) scratch: transpose of Linv
+  float* Linv32;                       // (batch, Mp, Mp) fp32 copy of Linv written beside it (stride sL), or null
   int32_t* info; int64_t m_real;
   uint32_t* sync; int64_t sS;          // per matrix: [0] ticket, then flags of C tiles, then flags of X tiles
   uint32_t* abort_word;
@@ -304,6 +305,34 @@ __device__ __forceinline__ void store_rows(const Ctx& c, double* dst, int64_t ld
 #endif
 }
 
+// image -> global as fp32 rows (the GEMM-precision copy of the inverse the fp32 products read: written here, one pass
+// over HBM less than a cast kernel behind the launch); `zeros`: a second fp32 tile cleared in the same sweep.
+__device__ __forceinline__ void store_rows_f32(const Ctx& c, float* dst, int64_t ld, float* zeros) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const double* T = lds_tiles();
+#pragma unroll 4
+  for (int it = 0; it < 8; ++it) {
+    const int e = c.tid + CO_THREADS * it, n = e >> 5, c4 = (e & 31) * 4;
+    const d2v a = *reinterpret_cast<const d2v*>(T + n * TP + c4), b = *reinterpret_cast<const d2v*>(T + n * TP + c4 + 2);
+    *reinterpret_cast<f4v*>(dst + (int64_t)n * ld + c4) = f4v{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+    if (zeros) *reinterpret_cast<f4v*>(zeros + (int64_t)n * ld + c4) = f4v{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// The diagonal block's inverse as fp32 rows (lower triangular, zeros above)
+__device__ __forceinline__ void store_block_inverse_f32(const Ctx& c, float* dst, int64_t ld) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const double* S = lds_tiles();
+#pragma unroll 4
+  for (int it = 0; it < 8; ++it) {
+    const int e = c.tid + CO_THREADS * it, row = e >> 5, c4 = (e & 31) * 4;
+    f4v v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (c4 + u <= row) ? (float)S[(c4 + u) * DP + row + 1] : 0.f;
+    *reinterpret_cast<f4v*>(dst + (int64_t)row * ld + c4) = v;
+  }
+}
+
 // The inverse X of the diagonal block in S (csrc/diag128.h: X[i][c] at S[c][i + 1]) -> global, lower triangular with
 // zeros above (TRANS: its transpose), 16-byte write-through stores.
 template <bool TRANS>
@@ -379,13 +408,14 @@ __device__ __forceinline__ void multiply_image(const Ctx& c, d4 (&acc)[4][2], co
 // One matrix of the batch.  The pointers travel to the noinline task functions through memory; stored as generic
 // pointers they would come back as flat_ accesses, so the struct keeps integers and the accessors rebuild global ones.
 struct Mat {
-  uintptr_t Ab_, Db_, Lb_, Xb_, fC_, fX_, info_;
+  uintptr_t Ab_, Db_, Lb_, Xb_, L32_, fC_, fX_, info_;
   int64_t lda, ldl;
   int nblk;
   __device__ __forceinline__ double* Ab() const { return (double*)(gdouble*)Ab_; }
   __device__ __forceinline__ double* Db() const { return (double*)(gdouble*)Db_; }
   __device__ __forceinline__ double* Lb() const { return (double*)(gdouble*)Lb_; }
   __device__ __forceinline__ double* Xb() const { return (double*)(gdouble*)Xb_; }
+  __device__ __forceinline__ float* L32() const { return (float*)(__attribute__((address_space(1))) float*)L32_; }
   __device__ __forceinline__ guint* fC() const { return (guint*)fC_; }
   __device__ __forceinline__ guint* fX() const { return (guint*)fX_; }
   __device__ __forceinline__ int32_t* info() const { return (int32_t*)(guint*)info_; }
@@ -453,6 +483,7 @@ __device__ __attribute__((noinline)) bool task_chol_diag(const Ctx& c_in, const 
   if (m.Lb()) {
     store_block_inverse<false>(c, m.Lb() + (int64_t)j * 128 * (m.ldl + 1), m.ldl);
     store_block_inverse<true>(c, m.Xb() + (int64_t)j * 128 * (m.ldl + 1), m.ldl);
+    if (m.L32_) store_block_inverse_f32(c, m.L32() + (int64_t)j * 128 * (m.ldl + 1), m.ldl);
   }
   publish(c, m.fC() + j * nblk + j);
   return true;
@@ -536,6 +567,8 @@ __device__ __attribute__((noinline)) bool task_inverse(const Ctx& c_in, const Ma
   stage_image<true, true>(c, acc, 1.0);
   __syncthreads();
   store_rows(c, Lt, ldl, nullptr);
+  if (m.L32_)
+    store_rows_f32(c, m.L32() + (int64_t)i * 128 * ldl + (int64_t)j * 128, ldl, m.L32() + (int64_t)j * 128 * ldl + (int64_t)i * 128);
   publish(c, m.fX() + i * nblk + j);
   return true;
 }
@@ -549,6 +582,7 @@ __device__ __forceinline__ bool run_matrix(const Ctx& c, const CoopOrder& ord, i
   m.Db_ = (uintptr_t)(p.Dinv + (int64_t)b * p.sD);
   m.Lb_ = p.Linv ? (uintptr_t)(p.Linv + (int64_t)b * p.sL) : 0;
   m.Xb_ = p.Linv ? (uintptr_t)(p.XT + (int64_t)b * p.sX) : 0;
+  m.L32_ = p.Linv32 ? (uintptr_t)(p.Linv32 + (int64_t)b * p.sL) : 0;
   m.lda = p.lda; m.ldl = (int64_t)p.nblk * 128;
   uint32_t* sync = p.sync + (int64_t)b * p.sS;
   m.fC_ = (uintptr_t)(sync + CO_SYNC_HEAD);
@@ -756,7 +790,7 @@ size_t coop_sync_words(int64_t Mp, int64_t batch) {
 // diagonal blocks in Dinv and -- when Linv is given -- the inverse of the factor in Linv (pitch Mp; its blocks above
 // the diagonal are NOT written) with XT (batch, Mp, Mp) as scratch.  info as potrf_padded; -7: a hand-off timed out.
 int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                double* Linv, double* XT, uint32_t* sync, int32_t* info, hipStream_t s) {
+                double* Linv, double* XT, uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32) {
   GPZ_REQUIRE(coop_supported(Mp, Linv != nullptr), "factor_coop: order %lld not supported", (long long)Mp);
   GPZ_REQUIRE(!Linv || XT, "factor_coop: the inverse needs its transposed scratch");
   GPZ_REQUIRE(lda * 128 * 8 < (1ll << 31), "factor_coop: leading dimension too large for 32-bit lane offsets");
@@ -766,6 +800,7 @@ int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batc
   p.Dinv = Dinv; p.sD = (int64_t)nblk * 128 * 128;
   p.Linv = Linv; p.sL = Mp * Mp;
   p.XT = XT; p.sX = Mp * Mp;
+  p.Linv32 = Linv ? Linv32 : nullptr;
   p.info = info; p.m_real = m_real;
   p.sS = CO_SYNC_HEAD + 2 * nblk * nblk;
   p.sync = sync + 32; p.abort_word = sync;

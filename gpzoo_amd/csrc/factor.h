@@ -8,7 +8,7 @@ namespace gpz {
 bool coop_supported(int64_t Mp, bool inverse);
 size_t coop_sync_words(int64_t Mp, int64_t batch);
 int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                double* Linv, double* XT, uint32_t* sync, int32_t* info, hipStream_t s);
+                double* Linv, double* XT, uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32 = nullptr);
 
 // Which path the entries below take: the one-launch dataflow unless GPZ_FACTOR_PATH=launches (the launch-per-step
 // chain of rounds 1-3, kept for comparison and for orders the dataflow's task list cannot hold).
@@ -24,8 +24,9 @@ int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* 
                  int64_t batch, double* T, hipStream_t s);
 
 // Both: A <- chol(A) in place (pitch Mp), Linv <- inverse of the factor (pitch Mp, zeros above the diagonal).
-// T: batch * Mp * Mp doubles of scratch; sync as above (null: launch-per-step path).
+// T: batch * Mp * Mp doubles of scratch; sync as above (null: launch-per-step path).  Linv32 (nullable): an fp32 copy
+// of Linv, written by the one-launch path itself; *wrote32 tells whether it was (the caller casts otherwise).
 int factor_invert_padded(double* A, int64_t Mp, int64_t batch, int64_t m_real, double* Dinv, double* Linv, double* T,
-                         uint32_t* sync, int32_t* info, hipStream_t s);
+                         uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32 = nullptr, bool* wrote32 = nullptr);
 
 }  // namespace gpz

@@ -429,11 +429,14 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
     if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, p->gZ, p->gZ, b.Kzz, Mp, mm, p->jitter, 1,
                               GPZ_F64, s, p->info))
       return rc;
-    if (int rc = factor_invert_padded(b.Kzz, Mp, L, M, b.Dinv, b.Linv, b.Tmp, b.fsync, p->info, s)) return rc;
+    bool wrote32 = false;     // the one-launch factorisation writes the fp32 copy of the inverse itself
+    if (int rc = factor_invert_padded(b.Kzz, Mp, L, M, b.Dinv, b.Linv, b.Tmp, b.fsync, p->info, s,
+                                      sizeof(T) == 4 ? reinterpret_cast<float*>(b.LinvG) : nullptr, &wrote32))
+      return rc;
     hipLaunchKernelGGL((chol_out_kernel<T>), dim3(p->chol ? 64 : 1, L32), dim3(256), 0, s, b.Kzz, Mp, M,
                        static_cast<T*>(p->chol), b.chol_logdiag);
     GPZ_LAUNCH_OK();
-    if (sizeof(T) == 4) {
+    if (sizeof(T) == 4 && !wrote32) {
       hipLaunchKernelGGL((cast_kernel<T>), dim3(2048), dim3(256), 0, s, b.Linv, b.LinvG, L * mm);
       GPZ_LAUNCH_OK();
     }

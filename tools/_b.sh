@@ -1,2 +1,2 @@
 #!/bin/bash
-cd /root/repo && python -m gpzoo_amd.build 2>&1 | grep -E "rror|warning: v" ; ls -la /root/repo/gpzoo_amd/libgpzoo_hip.so
+python -m gpzoo_amd.build > /tmp/w/build.log 2>&1; rc=$?; grep -E "error|undefined|RuntimeError" /tmp/w/build.log | head -20; echo "build rc=$rc"; ls -la /root/repo/gpzoo_amd/libgpzoo_hip.so
