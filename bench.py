@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--Ltotal", type=int, default=256, help="strong scaling: latents of the whole model (configs[3]: 256)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generate-kzx", action="store_true",
+                    help="stage 1 generates its covariance operand inside the product (GPZ_SVGP_GENERATE_KZX) instead of "
+                         "reading a materialised Kzx: the selectable path of DESIGN.md section 5, not the default")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="spots in the CPU-baseline sample (SURVEY §8d: 8192)")
     ap.add_argument("--with-backward", action="store_true",
                     help="also time one forward + backward (mu, Lu gradients) pass, outside the timed region")
@@ -343,7 +346,8 @@ def main():
 
     def step():
         out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
-                               y=g["y"], noise_sd=c["noise_sd"], chunk=a.chunk, want_Lu=False, **extra)
+                               y=g["y"], noise_sd=c["noise_sd"], chunk=a.chunk, want_Lu=False,
+                               materialize_kzx=False if a.generate_kzx else None, **extra)
         path["bits"] = out["path"]
         e = out["elbo"]
         if grouped:

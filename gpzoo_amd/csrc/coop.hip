@@ -149,23 +149,12 @@ __device__ __forceinline__ int wait_ready(const Ctx& c, int kb0, int kb1, Ready 
 // acc += A * B^T over the 16-wide k-tiles [t0, t1) (multiples of 8: k-blocks are 8 tiles), A and B [128 rows][k] with
 // pitches lda / ldb, k-tile t at column 16 t.  Every wave must be done with the tile buffers on entry (a barrier
 // since their last use); they are free again behind the barrier that follows the call's last use by the caller.
-// MODE (the two multiplications by a diagonal block's inverse, K = 128, t0 = 0):
-//   1: B is lower triangular ([n][k] = 0 for k > n): a wave's two 16-column sub-tiles are c = wn and 7 - wn instead of
-//      2 wn and 2 wn + 1 (every wave then has 9 of 16 sub-tile steps: equal work on the four SIMDs) and k-tile t is
-//      skipped for the sub-tiles c < t;
-//   2: A is lower triangular: 16-row sub-tile mi of the wave skips the k-tiles t > 4 wm + mi (each SIMD holds one
-//      wave of either row half: equal work again).
-// The skipped MFMAs sit under wave-uniform branches around whole blocks, in bodies specialised on what is active.
-template <int MODE>
 __device__ __forceinline__ void run_tiles(const Ctx& c, d4 (&acc)[4][2], const double* Ag, int64_t lda, const double* Bg,
                                           int64_t ldb, int t0, int t1) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef __attribute__((address_space(3))) void lds_void;
   const int wave_u = __builtin_amdgcn_readfirstlane(c.wave);
-  const int wm_u = wave_u >> 2, wn_u = wave_u & 3;
-  // rows of the B image this wave's sub-tile ni reads
-  const int fr_b0 = MODE == 1 ? (16 * wn_u + c.r) * 16 + ((c.q ^ (c.r & 7)) * 2) : c.fr_b;
-  const int fr_b1 = MODE == 1 ? (16 * (7 - wn_u) + c.r) * 16 + ((c.q ^ (c.r & 7)) * 2) : c.fr_b + 256;
+  const int fr_b0 = c.fr_b, fr_b1 = c.fr_b + 256;       // rows of the B image the wave's two 16-column sub-tiles read
   uint32_t a_off[2], b_off[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -201,32 +190,15 @@ __device__ __forceinline__ void run_tiles(const Ctx& c, d4 (&acc)[4][2], const d
       fb[kc][1] = *reinterpret_cast<const d2v*>(sB + (fr_b1 ^ (kc * 8)));
     }
   };
-  // the MFMAs of one tile over the sub-tiles mi >= MI_LO, ni >= NI_LO (compile-time ranges)
-  auto mfmas_sub = [&](const FragA& fa, const FragB& fb, auto mi_lo, auto ni_lo) __attribute__((always_inline)) {
-    constexpr int MI_LO = decltype(mi_lo)::value, NI_LO = decltype(ni_lo)::value;
+  auto mfmas = [&](int, const FragA& fa, const FragB& fb) __attribute__((always_inline)) {
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int mi = MI_LO; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int ni = NI_LO; ni < 2; ++ni) acc[mi][ni] = diag::mma(fa[kc][mi][j], fb[kc][ni][j], acc[mi][ni]);
-  };
-  using std::integral_constant;
-  auto mfmas = [&](int t, const FragA& fa, const FragB& fb) __attribute__((always_inline)) {
-    if constexpr (MODE == 1) {
-      if (t <= wn_u) mfmas_sub(fa, fb, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-      else if (t <= 7 - wn_u) mfmas_sub(fa, fb, integral_constant<int, 0>{}, integral_constant<int, 1>{});
-    } else if constexpr (MODE == 2) {
-      const int lo = t - 4 * wm_u;
-      if (lo <= 0) mfmas_sub(fa, fb, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-      else if (lo == 1) mfmas_sub(fa, fb, integral_constant<int, 1>{}, integral_constant<int, 0>{});
-      else if (lo == 2) mfmas_sub(fa, fb, integral_constant<int, 2>{}, integral_constant<int, 0>{});
-      else if (lo == 3) mfmas_sub(fa, fb, integral_constant<int, 3>{}, integral_constant<int, 0>{});
-    } else {
-      mfmas_sub(fa, fb, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-    }
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = diag::mma(fa[kc][mi][j], fb[kc][ni][j], acc[mi][ni]);
   };
   // Four stages.  Tile t + 3 is requested while tile t is consumed (with one workgroup per CU nobody else hides the
   // latency of a request that misses L2), and the fragments of tile t + 1 are read from LDS into a second register set
@@ -434,7 +406,7 @@ __device__ __forceinline__ bool accumulate(const Ctx& c, d4 (&acc)[4][2], const 
     if (n < 0) return false;
     const unsigned long long tr0 = (c.p->trace && c.tid == 0) ? realtime() : 0ull;
     const unsigned long long tc0 = (c.p->trace && c.tid == 0) ? __builtin_readcyclecounter() : 0ull;
-    run_tiles<0>(c, acc, Ag, lda, Bg, ldb, kb * 8, (kb + n) * 8);
+    run_tiles(c, acc, Ag, lda, Bg, ldb, kb * 8, (kb + n) * 8);
     if (c.p->trace && c.tid == 0) {
       lds_scalars()[3] = lds_scalars()[3] + (int)(realtime() - tr0);
       lds_scalars()[4] = lds_scalars()[4] + 1;

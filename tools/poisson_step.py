@@ -12,7 +12,7 @@ from gpzoo_amd import ops  # noqa: E402
 
 def main():
     g = torch.Generator().manual_seed(1)
-    D, N, Lt = 17702, 7000, 20
+    D, N, Lt = int(os.environ.get("GPZ_PS_D", 17702)), 7000, 20
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     dev = torch.device("cuda")
     mean = (0.3 * torch.randn(Lt, N, generator=g)).to(dev)
