@@ -200,12 +200,14 @@ __global__ __launch_bounds__(256) void vnngp_point_kernel(VnnArgs<T> a) {
 
 template <typename T>
 struct VnnBwdArgs {
-  VnnArgs<T> f;                 // scratch holds (K*K + 4K) columns here
+  VnnArgs<T> f;                 // scratch holds (K*K + 4K + 4) columns here: A, kx, w, sw, v, then gm, gcov, dsigma, dell
   const T* g_mean; const T* g_scale;
   double* gmu;                  // (L,Mp)
   double* gS;                   // (L,Mp,Mp)  T with dLoss/dS = T + T^T
   double* gK;                   // (L,Mp,Mp)  T with T + T^T = 2 sym(dLoss/d(Kzz + jitter I)) from the K x K blocks, or null
   double* kacc;                 // (L,Mp,8)   dz0..3, dsigma, dlengthscale (kgrad.hip layout), or null
+  const int32_t* inv;           // (N*K) entries n * K + p grouped by the inducing point they name, ascending inside a group
+  const int32_t* start;         // (M + 1) group boundaries in inv
 };
 
 template <typename T>
@@ -241,39 +243,166 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_kernel(VnnBwdArgs<T> b) {
     for (int k = i + 1; k < K; ++k) r -= A[(int64_t)(k * K + i) * total] * v[k * total];
     v[i * total] = r / A[(int64_t)(i * K + i) * total];
   }
-  double* gmu = b.gmu + (int64_t)l * a.Mp;
-  double* gS = b.gS + (int64_t)l * a.Mp * a.Mp;
-  double* gK = b.gK ? b.gK + (int64_t)l * a.Mp * a.Mp : nullptr;
+  // What the scatter needs per point stays in its scratch columns (w, v, kx are there already): the sums over the
+  // points that name an inducing point are formed by vnngp_gather_kernel in a FIXED order (no atomics: the backward is
+  // bitwise reproducible; rounds 1-3 added these contributions with fp64 atomics in arrival order).
   const double sg = (double)a.sigma[l], el = (double)a.ell[l], il2 = 1.0 / (el * el);
   double dsig = gcov * 2.0 * sg, dell = 0.0;
-  for (int p = 0; p < K; ++p) {
-    const int64_t ip = id[p];
-    const double wp = w[p * total], vp = v[p * total];
-    if (gm != 0.0) unsafeAtomicAdd(gmu + ip, gm * wp);
-    // both accumulators are only ever used symmetrised (T + T^T): one atomic per unordered pair, the
-    // diagonal at half weight for dS
-    for (int q = 0; q <= p; ++q) {
-      const double wq = w[q * total];
-      if (gcov != 0.0) unsafeAtomicAdd(gS + ip * a.Mp + id[q], (p == q ? 0.5 : 1.0) * gcov * wp * wq);
-      if (gK) unsafeAtomicAdd(gK + ip * a.Mp + id[q], p == q ? -vp * wq : -(vp * wq + v[q * total] * wp));
-    }
-    if (b.kacc) {
-      const double kv = kx[p * total], gk = (vp - gcov * wp) * kv;   // dLoss/dk_p * k_p
+  if (b.kacc)
+    for (int p = 0; p < K; ++p) {
+      const int64_t ip = id[p];
+      const double gk = (v[p * total] - gcov * w[p * total]) * kx[p * total];   // dLoss/dk_p * k_p
       double d2 = 0.0;
-      double* acc = b.kacc + ((int64_t)l * a.Mp + ip) * 8;
       for (int k = 0; k < a.d; ++k) {
         const double df = (double)a.X[n * a.d + k] - (double)a.Z[ip * a.d + k];
         d2 += df * df;
-        unsafeAtomicAdd(acc + k, gk * df * il2);                     // dk/dz = k (x - z) / l^2
       }
       dsig += gk * 2.0 / sg;
       dell += gk * d2 * il2 / el;
     }
+  double* ex = v + (int64_t)K * total;
+  ex[0] = gm; ex[total] = gcov; ex[2 * total] = dsig; ex[3 * total] = dell;
+}
+
+// ---- the neighbour table inverted: for every inducing point the (point, slot) entries that name it, in ascending order ----
+// A stable counting sort of the N K entries e = n K + p by idx[e], in blocks of VNN_IB consecutive entries:
+// per-block histograms (integer atomics: the totals are exact), their running sums over the blocks per inducing point,
+// an exclusive scan over the inducing points, then every entry's place = start of its group + entries of its group in
+// earlier blocks + entries of its group earlier in its own block.
+constexpr int VNN_IB = 1024;
+
+__global__ __launch_bounds__(256) void vnn_inv_hist_kernel(const int64_t* __restrict__ idx, int64_t NK, int64_t M,
+                                                          int32_t* __restrict__ H) {
+  const int64_t b = blockIdx.x;
+  for (int i = threadIdx.x; i < VNN_IB; i += 256) {
+    const int64_t e = b * VNN_IB + i;
+    if (e < NK) atomicAdd(H + b * M + idx[e], 1);
   }
-  if (b.kacc) {
-    double* acc = b.kacc + ((int64_t)l * a.Mp + id[0]) * 8;
-    unsafeAtomicAdd(acc + 4, dsig);
-    unsafeAtomicAdd(acc + 5, dell);
+}
+
+// one thread per inducing point: H[b][m] <- entries of m in blocks < b; count[m] = total
+__global__ __launch_bounds__(256) void vnn_inv_scan_kernel(int32_t* __restrict__ H, int64_t B, int64_t M,
+                                                          int32_t* __restrict__ count) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  int32_t run = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t c = H[b * M + m];
+    H[b * M + m] = run;
+    run += c;
+  }
+  count[m] = run;
+}
+
+// one block: start[m] = sum of count[0..m), start[M] = N K
+__global__ __launch_bounds__(256) void vnn_inv_start_kernel(const int32_t* __restrict__ count, int32_t* __restrict__ start,
+                                                           int64_t M) {
+  __shared__ int32_t part[256];
+  const int64_t per = (M + 255) / 256, lo = threadIdx.x * per, hi = lo + per < M ? lo + per : M;
+  int32_t t = 0;
+  for (int64_t m = lo; m < hi; ++m) t += count[m];
+  part[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t run = 0;
+    for (int i = 0; i < 256; ++i) { const int32_t c = part[i]; part[i] = run; run += c; }
+    start[M] = run;
+  }
+  __syncthreads();
+  int32_t run = part[threadIdx.x];
+  for (int64_t m = lo; m < hi; ++m) { start[m] = run; run += count[m]; }
+}
+
+__global__ __launch_bounds__(256) void vnn_inv_fill_kernel(const int64_t* __restrict__ idx, int64_t NK, int64_t M,
+                                                          const int32_t* __restrict__ H, const int32_t* __restrict__ start,
+                                                          int32_t* __restrict__ inv) {
+  __shared__ int32_t key[VNN_IB];
+  const int64_t b = blockIdx.x;
+  for (int i = threadIdx.x; i < VNN_IB; i += 256) {
+    const int64_t e = b * VNN_IB + i;
+    key[i] = e < NK ? (int32_t)idx[e] : -1;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < VNN_IB; i += 256) {
+    const int32_t m = key[i];
+    if (m < 0) continue;
+    int32_t r = 0;
+    for (int j = 0; j < i; ++j) r += key[j] == m;
+    inv[start[m] + H[b * M + m] + r] = (int32_t)(b * VNN_IB + i);
+  }
+}
+
+// One wave per (inducing point ip, latent l): walks the entries that name ip in ascending order and forms, with the two
+// rows resident in LDS, row ip of T_S and T_K, gmu[ip] and the dz part of kacc -- the sums the point kernel used to
+// scatter with atomics.  The dsigma / dlengthscale totals of a latent go through vnn_theta_sum_kernel.
+template <typename T>
+__global__ __launch_bounds__(64) void vnngp_gather_kernel(VnnBwdArgs<T> b) {
+  extern __shared__ double vnn_rows[];       // [2][Mp]
+  const VnnArgs<T>& a = b.f;
+  const int64_t ip = blockIdx.x;
+  const int l = blockIdx.y, lane = threadIdx.x, K = a.K;
+  const int64_t total = (int64_t)a.L * a.N;
+  double* rowS = vnn_rows;
+  double* rowK = vnn_rows + a.Mp;
+  for (int64_t j = lane; j < 2 * a.Mp; j += 64) vnn_rows[j] = 0.0;
+  __syncthreads();
+  const double* kxc = a.scratch + (int64_t)K * K * total;
+  const double* wc = kxc + (int64_t)K * total;
+  const double* vc = wc + 2 * (int64_t)K * total;
+  const double* ex = vc + (int64_t)K * total;
+  const double el = (double)a.ell[l], il2 = 1.0 / (el * el);
+  double gmu = 0.0, dz = 0.0;                 // lane 0: gmu; lanes k < d: dz_k
+  const int32_t e0 = b.start[ip], e1 = b.start[ip + 1];
+  for (int32_t ei = e0; ei < e1; ++ei) {
+    const int32_t e = b.inv[ei];
+    const int64_t n = e / K;
+    const int p = e - (int32_t)n * K;
+    const int64_t t = (int64_t)l * a.N + n;
+    const double gm = ex[t], gcov = ex[total + t];
+    const double wp = wc[(int64_t)p * total + t], vp = vc[(int64_t)p * total + t];
+    if (lane <= p) {                          // one unordered pair (p, q <= p) per lane: distinct columns of the rows
+      const int q = lane;
+      const int64_t iq = a.idx[n * K + q];
+      const double wq = wc[(int64_t)q * total + t];
+      if (gcov != 0.0) rowS[iq] += (p == q ? 0.5 : 1.0) * gcov * wp * wq;
+      if (b.gK) rowK[iq] += p == q ? -vp * wq : -(vp * wq + vc[(int64_t)q * total + t] * wp);
+    }
+    if (lane == 0) gmu += gm * wp;
+    if (b.kacc && lane < a.d) {
+      const double gk = (vp - gcov * wp) * kxc[(int64_t)p * total + t];
+      dz += gk * ((double)a.X[n * a.d + lane] - (double)a.Z[ip * a.d + lane]) * il2;      // dk/dz = k (x - z) / l^2
+    }
+  }
+  __syncthreads();
+  double* gS = b.gS + ((int64_t)l * a.Mp + ip) * a.Mp;
+  for (int64_t j = lane; j < a.Mp; j += 64) gS[j] = rowS[j];
+  if (b.gK) {
+    double* gK = b.gK + ((int64_t)l * a.Mp + ip) * a.Mp;
+    for (int64_t j = lane; j < a.Mp; j += 64) gK[j] = rowK[j];
+  }
+  if (lane == 0) b.gmu[(int64_t)l * a.Mp + ip] = gmu;
+  if (b.kacc && lane < a.d) b.kacc[((int64_t)l * a.Mp + ip) * 8 + lane] = dz;
+}
+
+// kacc[l][row 0][4, 5] = sum over the points of a latent of dsigma, dlengthscale (fixed order: strided partial sums, tree)
+template <typename T>
+__global__ __launch_bounds__(256) void vnn_theta_sum_kernel(VnnBwdArgs<T> b) {
+  __shared__ double sh[256];
+  const VnnArgs<T>& a = b.f;
+  const int l = blockIdx.x, K = a.K;
+  const int64_t total = (int64_t)a.L * a.N;
+  const double* ex = a.scratch + (int64_t)(K * K + 4 * K) * total;
+  for (int q = 0; q < 2; ++q) {
+    double v = 0.0;
+    for (int64_t n = threadIdx.x; n < a.N; n += 256) v += ex[(2 + q) * total + (int64_t)l * a.N + n];
+    __syncthreads();
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) b.kacc[(int64_t)l * a.Mp * 8 + 4 + q] = sh[0];
   }
 }
 
@@ -309,6 +438,7 @@ struct VnnPlan {
   double *Linv, *Tmp, *LuE, *muE;                       // KL(qU || pU): L^{-1}, L^{-1} Lu, L^{-1} mu
   uint32_t* fsync;                                       // tickets and flags of the one-launch Cholesky (csrc/coop.hip)
   double *gmu, *gS, *gK, *kacc, *G, *D1, *D2; void* PS;  // backward only
+  int32_t *inv, *istart, *ihist, *itmp;                  // backward only: the inverted neighbour table and its scratch
 };
 
 // M is a few thousand at most on this path: every mode carves the same (generous) set of M x M buffers
@@ -322,7 +452,7 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
   pl.Dinv = c.take<double>(pl.L * (pl.Mp / 128) * 128 * 128);
   pl.LuD = c.take<double>(mm);
   pl.S = c.take<double>(mm);
-  pl.scratch = c.take<double>((int64_t)(K * K + (bwd ? 4 : 2) * K) * pl.L * pl.N);
+  pl.scratch = c.take<double>((int64_t)(K * K + (bwd ? 4 : 2) * K + (bwd ? 4 : 0)) * pl.L * pl.N);
   pl.idx = own_idx ? c.take<int64_t>(pl.N * K) : nullptr;
   pl.Linv = c.take<double>(mm);
   pl.Tmp = c.take<double>(mm / 2 + 64);
@@ -331,7 +461,13 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
   pl.fsync = c.take<uint32_t>(coop_sync_words(pl.Mp, pl.L));
   pl.gmu = pl.gS = pl.gK = pl.kacc = pl.G = pl.D1 = pl.D2 = nullptr;
   pl.PS = nullptr;
+  pl.inv = pl.istart = pl.ihist = pl.itmp = nullptr;
   if (bwd) {
+    const int64_t NK = pl.N * K, IB = (NK + VNN_IB - 1) / VNN_IB;
+    pl.inv = c.take<int32_t>(NK);
+    pl.istart = c.take<int32_t>(pl.M + 2);
+    pl.itmp = c.take<int32_t>(pl.M + 2);
+    pl.ihist = c.take<int32_t>(IB * pl.M);
     pl.gmu = c.take<double>(pl.L * pl.Mp);
     pl.gS = c.take<double>(mm);
     pl.G = c.take<double>(mm);
@@ -659,6 +795,7 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
   if (int rc = vnn_prepare<T>(&q, pl, idx_in, b.f, s)) return rc;
   if (g_kl || with_chol)             // Linv (and, for the KL, LuE = Linv Lu and muE = Linv mu)
     if (int rc = vnn_kl_prepare<T>(p, pl, nullptr, s)) return rc;
+  // rows >= M of the accumulators are padding: zero; rows < M are written whole by the gather below
   GPZ_HIP_OK(hipMemsetAsync(pl.gmu, 0, sizeof(double) * L * Mp, s));
   GPZ_HIP_OK(hipMemsetAsync(pl.gS, 0, sizeof(double) * L * mm, s));
   if (kgrads) {
@@ -669,6 +806,41 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
   b.gmu = pl.gmu; b.gS = pl.gS; b.gK = kgrads ? pl.gK : nullptr; b.kacc = kgrads ? pl.kacc : nullptr;
   hipLaunchKernelGGL((vnngp_point_bwd_kernel<T>), dim3((unsigned)((L * pl.N + 255) / 256)), dim3(256), 0, s, b);
   GPZ_LAUNCH_OK();
+  {
+    // the neighbour table inverted (stable counting sort of the N K entries by the inducing point they name), then the
+    // sums per inducing point in that fixed order
+    const int64_t NK = pl.N * K, IB = (NK + VNN_IB - 1) / VNN_IB;
+    GPZ_REQUIRE(NK < (1ll << 31), "gpz_vnngp_backward: N * K = %lld entries exceed the 32-bit neighbour index", (long long)NK);
+    GPZ_REQUIRE(2 * Mp * sizeof(double) <= 128 * 1024, "gpz_vnngp_backward: M = %lld inducing points exceed the gather's LDS rows",
+                (long long)M);
+    GPZ_HIP_OK(hipMemsetAsync(pl.ihist, 0, sizeof(int32_t) * IB * M, s));
+    hipLaunchKernelGGL(vnn_inv_hist_kernel, dim3((unsigned)IB), dim3(256), 0, s, b.f.idx, NK, M, pl.ihist);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL(vnn_inv_scan_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, pl.ihist, IB, M, pl.itmp);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL(vnn_inv_start_kernel, dim3(1), dim3(256), 0, s, pl.itmp, pl.istart, M);
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL(vnn_inv_fill_kernel, dim3((unsigned)IB), dim3(256), 0, s, b.f.idx, NK, M, pl.ihist, pl.istart, pl.inv);
+    GPZ_LAUNCH_OK();
+    b.inv = pl.inv; b.start = pl.istart;
+    const size_t lds = 2 * Mp * sizeof(double);
+    if (lds > 64 * 1024) {
+      static bool set[64] = {};
+      int dev = 0;
+      GPZ_HIP_OK(hipGetDevice(&dev));
+      if (!set[dev & 63]) {
+        GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(vnngp_gather_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        set[dev & 63] = true;
+      }
+    }
+    hipLaunchKernelGGL((vnngp_gather_kernel<T>), dim3((unsigned)M, L32), dim3(64), lds, s, b);
+    GPZ_LAUNCH_OK();
+    if (kgrads) {
+      hipLaunchKernelGGL((vnn_theta_sum_kernel<T>), dim3(L32), dim3(256), 0, s, b);
+      GPZ_LAUNCH_OK();
+    }
+  }
   const dim3 g32((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32);
   const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
   auto dgemm = [&](const double* A, const double* B, double* C, int flags, double alpha) -> int {

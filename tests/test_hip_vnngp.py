@@ -280,3 +280,40 @@ def test_random_vnngp_case(seed):
     close(res[0], leaf["mu"].grad, "grad_mu"); close(res[1], leaf["Lu"].grad, "grad_Lu")
     close(res[2][:, 0], leaf["sigma"].grad, "grad_sigma"); close(res[2][:, 1], leaf["lengthscale"].grad, "grad_lengthscale")
     close(res[3], leaf["Z"].grad, "grad_Z")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_backward_is_bitwise_reproducible(dtype):
+    """The sums over the points that share an inducing point are formed in a fixed order (the neighbour table inverted by a
+    stable counting sort, one wave per inducing point): two evaluations give the same bits for every gradient, with a hub
+    -- an inducing point every datum names -- among the neighbours.  (Rounds 1-3 scattered with fp64 atomics: equal to
+    rounding only.)"""
+    from gpzoo_amd import _lib, ops
+    from gpzoo_amd.ops import KernelSpec
+    N, M, K, L = 5000, 150, 8, 3
+    g = torch.Generator().manual_seed(2024)
+    X = (torch.rand(N, 2, generator=g, dtype=dtype) - 0.5) * 30
+    Z = (torch.rand(M, 2, generator=g, dtype=dtype) - 0.5) * 30
+    sig = 0.5 + 0.2 * torch.rand(L, generator=g, dtype=dtype)
+    ell = 2.0 + 3 * torch.rand(L, generator=g, dtype=dtype)
+    mu = torch.randn(L, M, generator=g, dtype=dtype)
+    Lu = 0.05 * torch.randn(L, M, M, generator=g, dtype=dtype) - 1.5 * torch.eye(M, dtype=dtype)
+    a = torch.randn(L, N, generator=g, dtype=dtype)
+    b = torch.randn(L, N, generator=g, dtype=dtype)
+    spec = KernelSpec(_lib.KERNEL_RBF, sig.cuda(), ell.cuda(), True)
+    idx = ops.knn(X.cuda(), Z.cuda(), K)
+    idx[:, K - 1] = 7                              # a hub: one group of the inverted table holds N entries
+    dup = (idx[:, : K - 1] == 7).any(1)
+    idx[dup, K - 1] = 8                            # (keep a datum's neighbours distinct)
+    dup8 = dup & (idx[:, : K - 1] == 8).any(1)
+    idx[dup8, K - 1] = 9
+    keep = torch.ones(N, dtype=torch.bool, device="cuda")
+    for r in torch.nonzero(dup8).flatten().tolist():
+        keep[r] = len(set(idx[r].tolist())) == K
+    assert bool(keep.all())
+    runs = [ops.vnngp_backward(spec, X.cuda(), Z.cuda(), mu.cuda(), Lu.cuda(), 1e-2, K, idx, a.cuda(), b.cuda(),
+                               kernel_grads=True) for _ in range(3)]
+    for r in runs[1:]:
+        for x, y in zip(runs[0], r):
+            assert torch.equal(x, y)
+    assert all(bool(torch.isfinite(t).all()) for t in runs[0])
