@@ -308,3 +308,19 @@ def test_one_latent_beyond_the_32_bit_panel_keeps_the_wide_tile_kernels():
     wide_off = hip_eval(c, chunk=280_000, want_Lu=False)
     assert not (wide_off["path"] & 1)
     assert float(wide_off["elbo"]) == pytest.approx(float(out["elbo"]), rel=1e-6)
+
+
+@pytest.mark.parametrize("N,M,coop", [(5000, 4700, 1), (5200, 5000, 0)])
+def test_factor_paths_on_both_sides_of_the_task_list_limit(N, M, coop):
+    """The one-launch factorisation carries its tile order as a kernel argument: 1536 entries, i.e. orders up to M = 4864
+    with the inverse.  M = 4700 (37 blocks: 703 Cholesky + 666 inverse tiles) still takes it, M = 5000 falls back to the
+    launch-per-step chain; both against the oracle in fp64, whitened and un-whitened (the latter reads the explicit inverse
+    in fp64 too)."""
+    from gpzoo_amd import _lib
+    from gpzoo_amd.synthetic import make_config
+    assert _lib.load().gpz_factor_path(M, 1) == coop
+    c = make_config(2, N=N, M=M, L=1, dtype=torch.float64)
+    c["jitter"] = 1e-1
+    check(c, 1e-5)
+    c["whitened"] = False
+    check(c, 1e-5)
