@@ -17,9 +17,17 @@
 
 namespace gpz {
 
-constexpr int KF_TX = 64;       // lanes along columns
-constexpr int KF_TY = 4;        // rows in flight per block
-constexpr int KF_ROWS = 8;      // rows per thread
+#ifndef GPZ_KF_TX                // (overridable for timing variants: tools/kfill_variants.sh)
+#define GPZ_KF_TX 64
+#define GPZ_KF_TY 4
+#define GPZ_KF_ROWS 1
+#endif
+constexpr int KF_TX = GPZ_KF_TX;     // lanes along columns
+constexpr int KF_TY = GPZ_KF_TY;     // rows in flight per block
+constexpr int KF_ROWS = GPZ_KF_ROWS; // rows per thread.  (Round 4, config-3 chunks: 8 rows 5.58 TB/s, 2 rows 5.77, 1 row 5.83; 256 threads
+                                     // along the columns instead of 64 x 4: 5.60-5.65; a "flat" form -- one latent per workgroup, one
+                                     // store per thread, the pattern a plain store loop sustains best (tools/write_probe.hip: 6.9 TB/s) --
+                                     // recomputes coordinates and distance per store and drops to 1.9-3.1 TB/s: the fill is not a memset.)
 constexpr int KF_MAXL = 256;    // latents per launch
 constexpr int KF_MAXTAB = 2048; // MGGP (latent, group pair) table entries per launch
 
