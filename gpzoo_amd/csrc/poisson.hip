@@ -29,7 +29,8 @@ struct PoissonArgs {
   const float* mean; const float* scale; const float* eps;   // (Lt,N), (Lt,N), (E,Lt,N)
   const float* W; const float* V; const float* y;            // (D,Lt) positive, (N,) positive, (D,N)
   float* expF;                                               // (E,Lt,N) scratch
-  float* dexp_slab; float* dV_slab; double* ll_slab;          // [SD][E][Lt][N], [SV][N], [2][S][nblk]
+  float* dexp_slab; float* dV_slab; double* ll_slab;          // [SD][E][Lt][N], [SV][N], [S][nblk * E]
+  double* lg_slab; int nlg;                                   // partial sums of lgamma(y + 1), one per workgroup of lgamma_sum_kernel
   float* dW_slab;                                             // [SN][D][Lt]
   float* dW; float* dmean; float* dscale; float* dV; double* loglik;
   int64_t N, D;
@@ -80,13 +81,6 @@ template <int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void spot_mfma_kernel(PoissonArgs a, int GS) {
   constexpr int LT16 = (KS + 3) / 4;          // 16-row tiles of the factor axis
   __shared__ double sh[8];
-  // lgamma(y + 1) = log(y!) for the counts a Poisson model is fed: a table for integer y < 256 (lgammaf is ~100
-  // instructions per element: 1.2 ms of a 1.9 ms pass at Slide-seq size), the library function for anything else
-  __shared__ float lfact[256];
-  if (a.with_lgamma) {
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) lfact[i] = lgammaf((float)i + 1.f);
-    __syncthreads();
-  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int e = blockIdx.x % a.E, gs = wave;
@@ -119,7 +113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int c = 0; c < 4; ++c) dacc[lt][c] = f32x4{0, 0, 0, 0};
   float dv[4] = {0.f, 0.f, 0.f, 0.f};
-  double ll = 0.0, lg = 0.0;
+  double ll = 0.0;
   // One 16-gene group's operands: W as the A operand of the rate product (rows = genes r), y rows 4q + g (four
   // consecutive spots per lane), and W again as the A operand of dexpF (k slot q <-> gene 4q + g, rows = factors).
   // The next group's loads are issued before the current group is computed (the loop is otherwise bound by the
@@ -167,7 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // element-wise: the Poisson terms, and G (gene rows on the register axis) in place of Z.  The common factor 1 / E
     // of G and dV is applied once at the end (to dexpF and dV).  Interior tiles take the branch-free, mask-free form.
-    float llf = 0.f, llg = 0.f;
+    float llf = 0.f;
     if (d0 + 16 <= d_hi && tile_full) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -178,10 +172,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           llf += __builtin_fmaf(y1 * 0.69314718055994530942f, __builtin_amdgcn_logf(rate), -rate);
           dv[c] += __builtin_fmaf(y1, invv[c], -zz);
           z[c][g] = __builtin_fmaf(y1, __builtin_amdgcn_rcpf(zz), -vn[c]);
-          if (a.with_lgamma && e == 0) {
-            const int yi = (int)y1;
-            llg += (y1 == (float)yi && yi >= 0 && yi < 256) ? lfact[yi] : lgammaf(y1 + 1.f);
-          }
         }
     } else {
 #pragma unroll
@@ -195,15 +185,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           llf += ok ? __builtin_fmaf(y1 * 0.69314718055994530942f, __builtin_amdgcn_logf(rate), -rate) : 0.f;
           dv[c] += ok ? __builtin_fmaf(y1, invv[c], -zz) : 0.f;
           z[c][g] = ok ? __builtin_fmaf(y1, __builtin_amdgcn_rcpf(zz), -vn[c]) : 0.f;
-          if (a.with_lgamma && e == 0 && ok) {
-            const int yi = (int)y1;
-            llg += (y1 == (float)yi && yi >= 0 && yi < 256) ? lfact[yi] : lgammaf(y1 + 1.f);
-          }
         }
       }
     }
     ll += (double)llf;
-    lg += (double)llg;
     // dexpF[factor][spot] += sum over the group's genes: k-step g pairs G's register g (gene 4q + g) with
     // A[row = factor 16 lt + r][k slot q] = W[gene 4q + g][factor 16 lt + r]
 #pragma unroll
@@ -239,11 +224,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (q == 0 && nok[c]) a.dV_slab[((int64_t)s * nw + e * GS + gs) * a.N + n0 + 4 * r + c] = v;
   }
   const double t = block_sum_d(ll * (double)inv_e, sh);
-  const double tg = block_sum_d(lg, sh);
-  if (threadIdx.x == 0) {
-    a.ll_slab[(int64_t)s * gridDim.x + blockIdx.x] = t;
-    a.ll_slab[((int64_t)a.S + s) * gridDim.x + blockIdx.x] = tg;
+  if (threadIdx.x == 0) a.ll_slab[(int64_t)s * gridDim.x + blockIdx.x] = t;
+}
+
+// sum over (gene, spot) of lgamma(y + 1) = log(y!), the parameter-free term of the Poisson log-density: its own pass
+// over y (one more read of the counts: 0.1 ms at Slide-seq size) instead of a branch per element inside pass A, where the
+// library function's inlined code (the non-table case) made the loop seven vector instructions per MFMA (rocprofv3 PMC,
+// round 4: pass A 0.755 -> 0.646 ms without it; summed in pass B instead, where a y tile serves all samples, it cost
+// 0.18 ms).  A table for integer y < 256, lgammaf for anything else; one partial sum per workgroup.
+__global__ __launch_bounds__(256) void lgamma_sum_kernel(PoissonArgs a) {
+  __shared__ double sh[8];
+  __shared__ float lfact[256];
+  for (int i = threadIdx.x; i < 256; i += 256) lfact[i] = lgammaf((float)i + 1.f);
+  __syncthreads();
+  const int64_t tot = a.D * a.N;
+  auto term = [&](float y1) {
+    const int yi = (int)y1;
+    return (y1 == (float)yi && yi >= 0 && yi < 256) ? lfact[yi] : lgammaf(y1 + 1.f);
+  };
+  double lg = 0.0;
+  float part = 0.f;
+  int cnt = 0;
+  const int64_t tot4 = ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) ? tot / 4 : 0;     // 16-byte loads when aligned
+  const f32x4* y4 = reinterpret_cast<const f32x4*>(a.y);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot4; i += (int64_t)a.nlg * 256) {
+    const f32x4 v = y4[i];
+    part += (term(v[0]) + term(v[1])) + (term(v[2]) + term(v[3]));
+    if (++cnt == 16) { lg += (double)part; part = 0.f; cnt = 0; }      // fp32 partial sums of at most 64 terms
   }
+  for (int64_t i = 4 * tot4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)a.nlg * 256) part += term(a.y[i]);
+  lg += (double)part;
+  const double tg = block_sum_d(lg, sh);
+  if (threadIdx.x == 0) a.lg_slab[blockIdx.x] = tg;
 }
 
 // Pass B  grid (ceil(D/64), SN), 4 waves: wave w owns the 16 genes 64 b + 16 w and sweeps spot slice sn in tiles of 64
@@ -419,14 +431,15 @@ __global__ __launch_bounds__(256) void poisson_finish_kernel(PoissonArgs a, int 
   }
   if (blockIdx.x == 0) {
     double v = 0.0, vg = 0.0;
-    for (int j = threadIdx.x; j < a.S * nblk_spot; j += 256) { v += a.ll_slab[j]; vg += a.ll_slab[a.S * nblk_spot + j]; }
+    for (int j = threadIdx.x; j < a.S * nblk_spot; j += 256) v += a.ll_slab[j];
+    for (int j = threadIdx.x; j < a.nlg; j += 256) vg += a.lg_slab[j];
     const double t = block_sum_d(v, sh);
     const double tg = block_sum_d(vg, sh);
     if (threadIdx.x == 0) { a.loglik[0] = t; a.loglik[1] = tg; }
   }
 }
 
-struct PoissonPlan { int S, GS, SN; int64_t nblk; size_t bytes; float *expF, *dexp, *dVs, *dWs; double* ll; };
+struct PoissonPlan { int S, GS, SN; int64_t nblk; size_t bytes; float *expF, *dexp, *dVs, *dWs; double *ll, *lg; int nlg; };
 
 static PoissonPlan poisson_plan(int64_t N, int64_t D, int Lt, int E, void* ws) {
   PoissonPlan pl;
@@ -451,7 +464,9 @@ static PoissonPlan poisson_plan(int64_t N, int64_t D, int Lt, int E, void* ws) {
   pl.dexp = c.take<float>((int64_t)pl.S * pl.GS * E * Lt * N);
   pl.dVs = c.take<float>((int64_t)pl.S * E * pl.GS * N);
   pl.dWs = c.take<float>((int64_t)pl.SN * D * Lt);
-  pl.ll = c.take<double>((int64_t)2 * pl.S * pl.nblk * E);
+  pl.ll = c.take<double>((int64_t)pl.S * pl.nblk * E);
+  pl.nlg = 4096;
+  pl.lg = c.take<double>(pl.nlg);
   pl.bytes = c.used();
   return pl;
 }
@@ -485,6 +500,9 @@ static int poisson_passes(const PoissonArgs& a, const PoissonPlan& pl, hipStream
   }
   hipLaunchKernelGGL((spot_mfma_kernel<KS>), dim3((unsigned)(pl.nblk * a.E), (unsigned)pl.S), dim3(64 * pl.GS), 0, s, a, pl.GS);
   GPZ_LAUNCH_OK();
+  if (a.with_lgamma) hipLaunchKernelGGL(lgamma_sum_kernel, dim3((unsigned)a.nlg), dim3(256), 0, s, a);
+  else GPZ_HIP_OK(hipMemsetAsync(a.lg_slab, 0, sizeof(double) * a.nlg, s));
+  GPZ_LAUNCH_OK();
   hipLaunchKernelGGL((gene_mfma_kernel<KS>), dim3((unsigned)((a.D + 63) / 64), (unsigned)pl.SN), dim3(256), lds, s, a, pl.SN);
   GPZ_LAUNCH_OK();
   return 0;
@@ -509,6 +527,7 @@ extern "C" int gpz_poisson_nsf(const float* mean, const float* scale, const floa
   PoissonArgs a;
   a.mean = mean; a.scale = scale; a.eps = eps; a.W = W; a.V = V; a.y = y;
   a.expF = pl.expF; a.dexp_slab = pl.dexp; a.dV_slab = pl.dVs; a.ll_slab = pl.ll; a.dW_slab = pl.dWs;
+  a.lg_slab = pl.lg; a.nlg = pl.nlg;
   a.dW = dW; a.dmean = dmean; a.dscale = dscale; a.dV = dV; a.loglik = loglik;
   a.N = N; a.D = D; a.Lt = Lt; a.E = E; a.S = pl.S; a.with_lgamma = with_lgamma;
   a.SD = pl.S * pl.GS; a.SV = pl.S * E * pl.GS; a.SN = pl.SN;
