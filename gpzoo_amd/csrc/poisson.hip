@@ -119,7 +119,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // The next group's loads are issued before the current group is computed (the loop is otherwise bound by the
   // latency of these L2 reads: two waves per SIMD cannot cover it).
   struct Group { float wa[KS]; f32x4 yv[4]; float wt[4][LT16]; };
+  // Interior groups (all 16 genes and all 64 spots exist, rows 16-byte aligned) load without a branch: every address is
+  // valid, only the padded factor slots (l >= Lt) are zeroed by a select on a clamped index.  The general form guards
+  // every access (each guard is an exec-mask branch: they were a third of the loop's scalar instructions).
   auto load_group = [&](int64_t d0, Group& G) __attribute__((always_inline)) {
+    if (d0 + 16 <= d_hi && tile_full && vec) {
+      const float* wr = a.W + (d0 + r) * a.Lt;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int l = 4 * ks + q;
+        const float v = wr[l < a.Lt ? l : a.Lt - 1];
+        G.wa[ks] = l < a.Lt ? v : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t dg = d0 + 4 * q + g;
+        G.yv[g] = *reinterpret_cast<const f32x4*>(a.y + dg * a.N + n0 + 4 * r);
+        const float* wg = a.W + dg * a.Lt;
+#pragma unroll
+        for (int lt = 0; lt < LT16; ++lt) {
+          const int l = 16 * lt + r;
+          const float v = wg[l < a.Lt ? l : a.Lt - 1];
+          G.wt[g][lt] = l < a.Lt ? v : 0.f;
+        }
+      }
+      return;
+    }
     const int64_t d = d0 + r;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
