@@ -336,11 +336,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #if defined(__HIP_DEVICE_COMPILE__)
     const int64_t n0 = tt * 64;
     const int e0 = gi * EG, ne = (a.E - e0 < EG) ? a.E - e0 : EG;
-    for (int i = wave; i < ne * a.Lt; i += 4) {
-      const int el = i / a.Lt, l = i - el * a.Lt;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rsrc, (lds_void*)(sF + buf * FB + (el * LP + l) * PF), 4, lane * 4,
-                                               (int)(((e0 + el) * per + (int64_t)l * a.N + n0) * 4), 0, 0);
-    }
+    // (rows dealt to the waves per sample: a flat index over (sample, factor) needs an integer division per row, and
+    // scalar division is ~40 instructions: they were most of this kernel's 3.4 scalar instructions per MFMA)
+    for (int el = 0; el < ne; ++el)
+      for (int l = wave; l < a.Lt; l += 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rsrc, (lds_void*)(sF + buf * FB + (el * LP + l) * PF), 4, lane * 4,
+                                                 (int)(((e0 + el) * per + (int64_t)l * a.N + n0) * 4), 0, 0);
     if (wave == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(sV + buf * 64), 4, lane * 4, (int)(n0 * 4), 0, 0);
 #endif
