@@ -30,6 +30,7 @@
 #include "diag128.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -60,6 +61,7 @@ struct CoopParams {
   int nblk, batch, ntasks, gmax;
   unsigned long long timeout_ticks;    // of the 100 MHz s_memrealtime clock
   unsigned long long* trace;           // diagnostics (gpz_debug_coop_trace): 8 words per (matrix, ticket), or null
+  const uint32_t* debug_mute;          // diagnostics (gpz_debug_coop_mute): a flag that is never stored, or null
 };
 
 namespace {
@@ -106,7 +108,8 @@ __device__ __forceinline__ lds_vint* lds_scalars() {
 __device__ __forceinline__ void publish(const Ctx& c, guint* flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (c.tid == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (debug_mute: tests/test_hip_linalg.py withholds one flag to see the launch give up cleanly instead of hanging)
+  if (c.tid == 0 && (const uint32_t*)flag != c.p->debug_mute) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Number of leading k-blocks of [kb0, kb1) whose inputs are published (>= 1 after spinning), or -1: abort.  Wave 0
@@ -745,6 +748,7 @@ static const CoopOrder& cached_order(int nblk, int G, bool inv, int* ntasks) {
 }  // namespace
 
 static unsigned long long* g_coop_trace = nullptr;
+static int g_coop_mute_i = -1, g_coop_mute_j = -1;      // diagnostics: the Cholesky tile of matrix 0 whose flag is withheld
 
 bool coop_supported(int64_t Mp, bool inverse) {
   const int64_t nblk = Mp / 128;
@@ -778,8 +782,17 @@ int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batc
   p.sync = sync + 32; p.abort_word = sync;
   p.nblk = nblk; p.batch = (int)batch;
   p.gmax = std::max(1, std::min(32, 3 * nblk / 2));
-  p.timeout_ticks = 500000000ull;   // 5 s of the 100 MHz clock: far beyond any wait a healthy launch sees, even beside another process's kernels
+  // 5 s of the 100 MHz clock: far beyond any wait a healthy launch sees, even beside another process's kernels
+  // (GPZ_COOP_TIMEOUT_MS: the tests' give-up case does not want to wait that long)
+  static const unsigned long long timeout_ticks = [] {
+    const char* e = std::getenv("GPZ_COOP_TIMEOUT_MS");
+    const long ms = e ? atol(e) : 5000;
+    return (unsigned long long)(ms > 0 ? ms : 5000) * 100000ull;
+  }();
+  p.timeout_ticks = timeout_ticks;
   p.trace = g_coop_trace;
+  p.debug_mute = (g_coop_mute_i >= 0 && g_coop_mute_i < nblk && g_coop_mute_j >= 0 && g_coop_mute_j <= g_coop_mute_i)
+                     ? p.sync + CO_SYNC_HEAD + g_coop_mute_i * nblk + g_coop_mute_j : nullptr;
   const int nclus = (int)std::min<int64_t>(batch, 256);
   const int nwg = std::min(256, (nclus * p.gmax + 7) / 8 * 8);
   const int G = std::max(1, nwg / nclus);
@@ -802,6 +815,14 @@ int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batc
 
 // Diagnostics: a device buffer of 8 * batch * ntasks words that the following factor_coop launches fill with, per
 // (matrix, ticket): task code, workgroup, claim time, end time, time spent polling (100 MHz ticks).  null: off.
+// Diagnostics: the following factor_coop launches never publish Cholesky tile (i, j) of matrix 0, so everything that
+// needs it waits until the launch's timeout, raises the abort word and leaves with info = -7.  (-1, -1): off.
+extern "C" int gpz_debug_coop_mute(int i, int j) {
+  gpz::g_coop_mute_i = i;
+  gpz::g_coop_mute_j = j;
+  return 0;
+}
+
 extern "C" int gpz_debug_coop_trace(void* buf) {
   gpz::g_coop_trace = static_cast<unsigned long long*>(buf);
   return 0;

@@ -68,3 +68,49 @@ def test_not_positive_definite_raises():
         ops.cholesky(A.cuda())
     with pytest.raises(torch.linalg.LinAlgError):
         torch.linalg.cholesky(A)
+
+
+_GIVE_UP_CHILD = r"""
+import ctypes as C, json, sys, time
+sys.path.insert(0, {root!r})
+import torch
+from gpzoo_amd import ops, _lib
+lib = _lib.load()
+lib.gpz_debug_coop_mute.restype = C.c_int
+lib.gpz_debug_coop_mute.argtypes = [C.c_int, C.c_int]
+g = torch.Generator().manual_seed(0)
+B = torch.randn(2, 512, 512, generator=g, dtype=torch.float64)
+A = (B @ B.transpose(-1, -2) / 512 + torch.eye(512, dtype=torch.float64)).cuda()
+ref = ops.cholesky(A)
+lib.gpz_debug_coop_mute(1, 0)                     # tile (1, 0) of matrix 0 is computed but its flag never stored
+t0 = time.perf_counter()
+try:
+    ops.cholesky(A)
+    msg = None
+except RuntimeError as e:
+    msg = str(e)
+dt = time.perf_counter() - t0
+lib.gpz_debug_coop_mute(-1, -1)
+again = ops.cholesky(A)
+print(json.dumps(dict(msg=msg, seconds=dt, healthy=bool(torch.equal(again, ref)))))
+"""
+
+
+def test_one_launch_factorisation_gives_up_instead_of_hanging():
+    """The exit condition every wave of the one-launch factorisation reaches: with one tile's flag withheld (a debug hook)
+    everything that depends on it polls until the launch's timeout (50 ms here, 5 s by default), the first poller to time
+    out raises the abort word, every other poll loop reads it, all workgroups leave and info = -7 becomes a RuntimeError --
+    and the next call on the same device is bitwise what it was before."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPZ_COOP_TIMEOUT_MS="50")
+    env.pop("GPZ_FACTOR_PATH", None)
+    p = subprocess.run([sys.executable, "-c", _GIVE_UP_CHILD.format(root=root)], capture_output=True, text=True, timeout=300,
+                       env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["msg"] is not None and "timed out" in out["msg"] and "-7" in out["msg"]
+    assert out["seconds"] < 5.0 and out["healthy"]
