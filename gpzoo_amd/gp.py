@@ -88,10 +88,40 @@ class _PrecomputedMoments(torch.autograd.Function):
 
 
 class _FusedQU(distributions.MultivariateNormal):
-    """q(U) as returned by the un-whitened modules while training: a MultivariateNormal that remembers the
-    per-latent KL(qU || pU) the fused pass already evaluated (differentiable through gpz_svgp_backward)."""
+    """q(U) as returned by the modules while training: a MultivariateNormal that remembers the per-latent KL the fused pass
+    already evaluated (differentiable through gpz_svgp_backward) and builds its ``scale_tril`` only when somebody asks.
+
+    The reference forms ``Lu = tril(raw, -1) + diag(exp(diag raw))`` in every forward (gp.py:278, torch's
+    LowerCholeskyTransform); its training loops then only use q(U) inside the KL term, which the fused pass has already.
+    Built eagerly through torch that matrix is three passes over (L, M, M) per step -- 0.8 ms of a 55 ms minibatch step at
+    L = 20, M = 3000 -- for a tensor nobody reads; here ``raw`` is kept and the same torch expression runs on first access
+    (``scale_tril``, ``rsample``, ``log_prob``, ``covariance_matrix``, a KL against another distribution ...), so every other
+    use still differentiates w.r.t. the raw parameter exactly as before."""
     _gpz_kl = None
     _gpz_pair = None
+
+    def __init__(self, loc, scale_tril=None, raw=None, validate_args=False):
+        if raw is None:
+            super().__init__(loc, scale_tril=scale_tril, validate_args=validate_args)
+            return
+        # what MultivariateNormal.__init__ derives from (loc, scale_tril), without the matrix
+        batch_shape = torch.broadcast_shapes(raw.shape[:-2], loc.shape[:-1])
+        self.loc = loc.expand(batch_shape + (-1,))
+        self._gpz_raw, self._gpz_tril = raw, None
+        distributions.Distribution.__init__(self, batch_shape, self.loc.shape[-1:], validate_args=False)
+
+    @property
+    def _unbroadcasted_scale_tril(self):
+        t = self.__dict__.get("_gpz_tril")
+        if t is None:
+            raw = self._gpz_raw
+            t = raw.tril(-1) + torch.diag_embed(torch.diagonal(raw, dim1=-2, dim2=-1).exp())
+            self.__dict__["_gpz_tril"] = t
+        return t
+
+    @_unbroadcasted_scale_tril.setter
+    def _unbroadcasted_scale_tril(self, value):      # (the eager constructor path and Distribution.expand assign it)
+        self.__dict__["_gpz_tril"] = value
 
 
 class _FusedPU(distributions.MultivariateNormal):
@@ -220,13 +250,12 @@ class _FusedGP(nn.Module):
             call["group_chain"] = self.kernel._group_a_chain()
         mean, scale, _, chol, kl = _QFMoments.apply(self.mu, self.Lu, self.Z, self.kernel.sigma,
                                                     self.kernel.lengthscale, gparam, call)
-        # q(U)'s scale_tril through torch so that other uses of it differentiate w.r.t. the raw parameter
-        Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
         single = self.mu.dim() == 1
         pick = (lambda t: t[0]) if single else (lambda t: t)
         qF = distributions.Normal(pick(mean), pick(scale))
-        # the matrices are valid by construction, so the O(L M^2) argument validation of scale_tril is skipped
-        qU = _FusedQU(self.mu, scale_tril=Lu, validate_args=False)
+        # q(U)'s scale_tril is the torch expression of the raw parameter (so that other uses of it differentiate w.r.t.
+        # it), evaluated when first asked for: the training loops never do (_FusedQU)
+        qU = _FusedQU(self.mu, raw=self.Lu)
         qU._gpz_kl = pick(kl)          # whitened: read by the training loops' KL term (utilities._kl_u)
         if self._whitened:
             return qF, qU, None
