@@ -350,10 +350,13 @@ struct Buffers {
 
 // The factor cache holds what depends only on (Z, kernel hyper-parameters, jitter): the Cholesky
 // factor of Kzz, its inverse in fp64 and in GEMM precision, and sum(log diag L) per latent.
+// Behind it, in the same buffer, what the two products need of q(U) -- LuE^T, muE and (un-whitened) LuE = Linv Lu in
+// fp64 -- as the last call prepared them from (mu, Lu_raw): the backward pass of that very call takes them from here
+// (bit 1 of factor_cache_valid) instead of preparing them a second time.
 template <typename T>
-struct FactorCache { double *Kzz, *Linv, *logdiag; T* LinvG; size_t bytes; };
+struct FactorCache { double *Kzz, *Linv, *logdiag, *LuW; T *LinvG, *LuT, *muE; size_t bytes; };
 template <typename T>
-static FactorCache<T> carve_cache(const Plan& pl, void* mem) {
+static FactorCache<T> carve_cache(const Plan& pl, bool whitened, void* mem) {
   FactorCache<T> f;
   Carver c(mem);
   const int64_t mm = pl.L * pl.Mp * pl.Mp;
@@ -361,6 +364,9 @@ static FactorCache<T> carve_cache(const Plan& pl, void* mem) {
   f.Linv = c.take<double>(mm);
   f.LinvG = sizeof(T) == 8 ? reinterpret_cast<T*>(f.Linv) : c.take<T>(mm);
   f.logdiag = c.take<double>(pl.L);
+  f.LuT = c.take<T>(mm);
+  f.muE = c.take<T>(pl.L * pl.Mp);
+  f.LuW = whitened ? nullptr : c.take<double>(mm);
   f.bytes = c.used();
   return f;
 }
@@ -422,10 +428,15 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
   GPZ_HIP_OK(hipMemsetAsync(p->info, 0, sizeof(int32_t) * L, s));
   // 1. Kzz + jitter I (fp64, identity padded), Cholesky, inverse -- or the caller's cached copy
   if (p->factor_cache) {
-    FactorCache<T> f = carve_cache<T>(pl, p->factor_cache);
+    FactorCache<T> f = carve_cache<T>(pl, wh, p->factor_cache);
     b.Kzz = f.Kzz; b.Linv = f.Linv; b.LinvG = f.LinvG; b.chol_logdiag = f.logdiag;
+    b.LuT = f.LuT; b.muE = f.muE;
+    if (!wh) b.LuW = f.LuW;
   }
-  if (!(p->factor_cache && p->factor_cache_valid)) {
+  // factor_cache_valid: bit 0 the factor, bit 1 the q(U) operands behind it (set by the backward pass of the call that
+  // wrote them: same mu / Lu_raw, same factor)
+  const bool qu_cached = p->factor_cache && (p->factor_cache_valid & 3) == 3;
+  if (!(p->factor_cache && (p->factor_cache_valid & 1))) {
     if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, p->gZ, p->gZ, b.Kzz, Mp, mm, p->jitter, 1,
                               GPZ_F64, s, p->info))
       return rc;
@@ -450,6 +461,7 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
 
   // 2. q(U) parameters in the form the two products need
   const dim3 g32((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32);
+  if (qu_cached) return 0;
   if (wh) {
     hipLaunchKernelGGL((lu_prepare_kernel<T>), g32, dim3(256), 0, s, static_cast<const T*>(p->Lu_raw), M, Mp, b.LuT,
                        (double*)nullptr, static_cast<T*>(p->Lu), b.lu_part);
@@ -1486,5 +1498,6 @@ extern "C" size_t gpz_svgp_wt_cache_bytes(const gpz_svgp_problem* p, int64_t chu
 extern "C" size_t gpz_svgp_factor_cache_bytes(const gpz_svgp_problem* p) {
   if (check_problem(p)) return 0;
   const Plan pl = make_plan(p, 0);
-  return p->dtype == GPZ_F32 ? carve_cache<float>(pl, nullptr).bytes : carve_cache<double>(pl, nullptr).bytes;
+  const bool wh = p->whitened != 0;
+  return p->dtype == GPZ_F32 ? carve_cache<float>(pl, wh, nullptr).bytes : carve_cache<double>(pl, wh, nullptr).bytes;
 }

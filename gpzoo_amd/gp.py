@@ -234,6 +234,7 @@ class _FusedGP(nn.Module):
                                    want_chol=not self._whitened, retain_wt=getattr(self, "retain_wt", 1.0 / 3), **common)
             kept["wt"] = out.pop("wt_cache", None)
             kept["gen"] = out.get("factor_generation")     # which factorisation the shared buffer holds now
+            kept["qu"] = out.get("qu_generation")          # ... and whose q(U) operands
             return out
 
         def bwd(mu, Lu_raw, g_mean, g_scale, scale, need_kernel, g_chol, g_kl):
@@ -241,9 +242,11 @@ class _FusedGP(nn.Module):
             # forward of other inputs in between refactors into the shared buffer and bumps its generation -- the
             # check then fails on content and the backward refactors from its own copies
             trust = kept.get("gen") is not None and common["cache"].generation == kept["gen"]
+            # the q(U) operands behind the factor are this call's only while no other forward has run on the buffer
+            trust_qu = trust and kept.get("qu") is not None and common["cache"].qu_generation == kept["qu"]
             return ops.svgp_backward(*args, mu, Lu_raw, float(self.jitter), self._whitened, g_mean, g_scale, scale,
                                      kernel_grads=need_kernel, g_chol=g_chol, wt_cache=kept.pop("wt", None),
-                                     g_kl=g_kl, trust_cache=trust, **common)
+                                     g_kl=g_kl, trust_cache=trust, trust_qu=trust_qu, **common)
 
         call = dict(forward=fwd, backward=bwd)
         if gparam is not None:

@@ -295,17 +295,22 @@ class FactorCache:
         # committed; its backward pass may skip the content check only while the counter still has that value, i.e.
         # while no other call has refactored into the shared buffer in between.
         self.generation = 0
+        # Counts the calls that wrote their q(U) operands (LuE^T, muE, un-whitened LuE) behind the factor -- every call
+        # on the buffer but a backward that took them from it.  A backward pass may do that (factor_cache_valid = 3)
+        # only while this is still the value its forward left.
+        self.qu_generation = 0
         self._rebuilds = False
 
     @staticmethod
     def fingerprint(tensors) -> torch.Tensor:
         return torch.cat([t.reshape(-1).view(torch.uint8) for t in tensors if t is not None])
 
-    def attach(self, lib, p: "SvgpProblem", key, device, deps, trust: bool = False):
+    def attach(self, lib, p: "SvgpProblem", key, device, deps, trust: bool = False, trust_qu: bool = False):
         """``trust``: the caller vouches that the buffer still holds the factor of exactly these ``deps`` -- the
         backward pass of the call whose forward committed it, holding private copies of the inputs and having checked
         that ``generation`` is still the value that forward saw -- so the content comparison (a device reduction and a
-        host sync) is skipped."""
+        host sync) is skipped.  ``trust_qu`` (with ``trust``): no other forward has written its q(U) operands into the
+        buffer since, so the backward takes them from there too."""
         nbytes = lib.gpz_svgp_factor_cache_bytes(C.byref(p))
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -313,7 +318,9 @@ class FactorCache:
             self.generation += 1
         if trust and self.key == key and self.snap is not None:
             p.factor_cache = self.buf.data_ptr()
-            p.factor_cache_valid = 1
+            p.factor_cache_valid = 3 if trust_qu else 1
+            if not trust_qu:
+                self.qu_generation += 1
             self._pending = (key, self.snap)
             self._rebuilds = False
             return True
@@ -322,6 +329,7 @@ class FactorCache:
                  and bool(torch.equal(self.snap, fp)))
         p.factor_cache = self.buf.data_ptr()
         p.factor_cache_valid = int(valid)
+        self.qu_generation += 1
         self._pending = (key, fp)
         self._rebuilds = not valid
         return valid
@@ -431,6 +439,7 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     p.info = info.data_ptr()
     if cache is not None:
         cache.attach(lib, p, factor_key(spec, Z, jitter, dt), dev, deps)
+        out["qu_generation"] = cache.qu_generation   # this call writes its q(U) operands behind the factor
     if retain_wt > 0:
         need = lib.gpz_svgp_wt_cache_bytes(C.byref(p), int(chunk))
         if 0 < need <= retain_wt * torch.cuda.mem_get_info(dev)[0]:
@@ -462,7 +471,7 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
 def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
                   gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0, cache: Optional[FactorCache] = None,
                   kernel_grads: bool = False, g_chol=None, wt_cache=None, g_kl=None, trust_cache: bool = False,
-                  narrow_tiles: bool = False):
+                  trust_qu: bool = False, narrow_tiles: bool = False):
     """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) (gpz_svgp_backward); with ``kernel_grads`` also
     dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64.
     ``wt_cache``: the buffer a forward pass on the same inputs and ``chunk`` returned under "wt_cache".
@@ -503,7 +512,7 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
         keep.append(gk)
         g.g_kl = gk.data_ptr()
     if cache is not None:
-        cache.attach(lib, p, factor_key(spec, Z, jitter, dt), dev, deps, trust=trust_cache)
+        cache.attach(lib, p, factor_key(spec, Z, jitter, dt), dev, deps, trust=trust_cache, trust_qu=trust_cache and trust_qu)
     if wt_cache is not None:
         if wt_cache.numel() != lib.gpz_svgp_wt_cache_bytes(C.byref(p), int(chunk)):
             raise ValueError("wt_cache does not belong to this problem / chunking")
@@ -514,7 +523,7 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     ws = _workspace(dev, nbytes)
     rc = lib.gpz_svgp_backward(C.byref(p), C.byref(g), int(chunk), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_svgp_backward")
-    if cache is not None and not p.factor_cache_valid:
+    if cache is not None and not (p.factor_cache_valid & 1):
         # the backward refactored (cache miss): keep the result only if the factorisation succeeded
         if bool(info.any()):
             cache.invalidate()

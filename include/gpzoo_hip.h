@@ -163,8 +163,11 @@ typedef struct gpz_svgp_problem {
   /* optional cache of everything that depends only on (Z, kernel hyper-parameters, jitter):
    * chol(Kzz), its inverse and sum(log diag).  NULL: recompute every call like the reference
    * (SURVEY §3.3).  Non-NULL (gpz_svgp_factor_cache_bytes bytes, caller owned): filled when
-   * factor_cache_valid == 0, reused when 1 -- the caller flips the flag and invalidates it when
-   * Z / sigma / lengthscale / group parameters / jitter change (SURVEY §8f "next" #3). */
+   * bit 0 of factor_cache_valid is 0, reused when it is 1 -- the caller flips the flag and invalidates it when
+   * Z / sigma / lengthscale / group parameters / jitter change (SURVEY §8f "next" #3).  Behind the factor the
+   * buffer keeps what the two products need of q(U) (LuE^T, muE, un-whitened LuE) as the LAST call prepared it from
+   * (mu, Lu_raw); bit 1 (factor_cache_valid == 3) tells gpz_svgp_backward that this is the very (mu, Lu_raw) it is
+   * called with -- the backward pass of the forward that wrote the buffer -- so it is not prepared a second time. */
   void* factor_cache;
   int64_t factor_cache_valid;
   /* Optional retained Wt = Linv Kzx of every N-chunk plus its column-sum partials, for training:
