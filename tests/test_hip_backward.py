@@ -91,6 +91,54 @@ def test_backward_of_an_earlier_forward_after_data_edit_and_second_forward(name,
                                if X.dtype == torch.float64 else 1e-4 * max(sc_Lu, 1.0))
 
 
+@pytest.mark.parametrize("order", ["a_then_b", "b_then_a"])
+@pytest.mark.parametrize("name", ["svgp_nsf_rbf_f64", "wsvgp_matern32_f64", "svgp_matern32_f32"])
+def test_two_forwards_with_other_variational_parameters_before_either_backward(name, order):
+    """forward A (mu, Lu) -> forward B (other mu, Lu; SAME frozen Z / kernel, so the shared cache keeps its factor and B
+    overwrites the q(U) operands kept behind it) -> the two backward passes in either order: each must differentiate
+    ITS problem.  The backward takes LuE^T / muE / LuE from the buffer only while no other call has written them since
+    its own forward (FactorCache.qu_generation); otherwise it prepares them again from its saved (mu, Lu)."""
+    from gpzoo.utilities import whitened_KL_batched
+    c = load_case(name)
+    model = build(name, c)
+    gp = model.gp
+    for t in [gp.Z, *gp.kernel.parameters()]:
+        t.requires_grad_(False)
+    X, y = c["X"].cuda(), c["y"].cuda()
+    kw = {"groupsX": c["gX"].cuda()} if "gX" in c else {}
+
+    def loss_of():
+        pY, qF, qU, pU = model(X=X, E=1, **kw)
+        s = torch.nn.functional.softplus(model.noise)
+        kl = whitened_KL_batched(qU.mean, qU.scale_tril).sum() if c["whitened"] else \
+            torch.distributions.kl_divergence(qU, pU).sum()
+        return -(pY.log_prob(y).sum() - (qF.scale ** 2).sum() / (2 * s ** 2) - kl)
+
+    mu_a, Lu_a = gp.mu, gp.Lu
+    g = torch.Generator().manual_seed(5)
+    mu_b = nn.Parameter((mu_a.detach().cpu() + 0.3 * torch.randn(mu_a.shape, generator=g, dtype=mu_a.dtype)).cuda())
+    Lu_b = nn.Parameter((Lu_a.detach().cpu() * 0.7 + 0.05 * torch.randn(Lu_a.shape, generator=g, dtype=Lu_a.dtype)).cuda())
+    loss_a = loss_of()
+    gen = gp._factor_cache.generation
+    gp.mu, gp.Lu = mu_b, Lu_b
+    loss_b = loss_of()
+    assert gp._factor_cache.generation == gen        # same factor: only the q(U) operands were replaced
+    for which in (("a", "b") if order == "a_then_b" else ("b", "a")):
+        (loss_a if which == "a" else loss_b).backward()
+    rt = rtol_for(X.dtype)
+    sc_mu, sc_Lu = float(c["grad_mu"].abs().max()), float(c["grad_Lu"].abs().max())
+    torch.testing.assert_close(mu_a.grad.cpu(), c["grad_mu"], rtol=rt, atol=rt * sc_mu)
+    torch.testing.assert_close(Lu_a.grad.cpu(), c["grad_Lu"], rtol=rt, atol=rt * sc_Lu)
+    # B against a cache-less evaluation of B alone
+    g_mu, g_Lu = mu_b.grad.clone(), Lu_b.grad.clone()
+    mu_b.grad = Lu_b.grad = None
+    gp.cache_factor = False
+    loss_of().backward()
+    tol = 1e-9 if X.dtype == torch.float64 else 1e-4
+    torch.testing.assert_close(g_mu, mu_b.grad, rtol=tol, atol=tol * max(float(g_mu.abs().max()), 1.0))
+    torch.testing.assert_close(g_Lu, Lu_b.grad, rtol=tol, atol=tol * max(float(g_Lu.abs().max()), 1.0))
+
+
 def test_backward_multi_chunk_matches_single_chunk():
     """Chunked accumulation of the (M x n)(n x M) gradient product: 3 chunks == 1 chunk."""
     from gpzoo_amd import ops
