@@ -85,6 +85,9 @@ def parse():
     ap.add_argument("--generate-kzx", action="store_true",
                     help="stage 1 generates its covariance operand inside the product (GPZ_SVGP_GENERATE_KZX) instead of "
                          "reading a materialised Kzx: the selectable path of DESIGN.md section 5, not the default")
+    ap.add_argument("--panel-products", action="store_true",
+                    help="fp32, M <= 512: both products in one launch on 64-column panels held in LDS (GPZ_SVGP_PANEL_PRODUCTS, "
+                         "csrc/gemmp.hip): the selectable path of DESIGN.md section 5, not the default")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="spots in the CPU-baseline sample (SURVEY §8d: 8192)")
     ap.add_argument("--with-backward", action="store_true",
                     help="also time one forward + backward (mu, Lu gradients) pass, outside the timed region")
@@ -347,7 +350,7 @@ def main():
     def step():
         out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
                                y=g["y"], noise_sd=c["noise_sd"], chunk=a.chunk, want_Lu=False,
-                               materialize_kzx=False if a.generate_kzx else None, **extra)
+                               materialize_kzx=False if a.generate_kzx else None, panel_products=a.panel_products, **extra)
         path["bits"] = out["path"]
         e = out["elbo"]
         if grouped:
@@ -405,12 +408,14 @@ def main():
         # dominant kernel: Wt = Linv * Kzx, one launch per N-chunk -- fp32: gemmw_kernel (128 x 256 tiles, csrc/gemmw.hip),
         # fp64: gemm128_kernel<T,NN,store+colstats>.  algorithmic flops = L * M^2 * N per evaluation (SURVEY §8d TRSM count).
         flops1 = Lper * float(M) * M * N * a.steps
-        ach1 = flops1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
-        mp = measured_peaks()
-        traffic, traffic_src = pmc_traffic(cfg_id, N, M, Lper, a.chunk)
         # the kernel that ran, from the predicate the library itself dispatches on (gpz_svgp_forward_path)
         bits = path.get("bits", 0)
-        kname = ("gemmw_gen_kernel<512,128,generated Kzx,lower,store+colstats> (Wt = Linv*k(Z,X), csrc/gemmw.hip)" if bits & 2
+        panel = bool(bits & 4)      # fp32, M <= 512: ONE launch runs both products panel by panel (csrc/gemmp.hip): 2 x the flops
+        ach1 = (2.0 if panel else 1.0) * flops1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
+        mp = measured_peaks()
+        traffic, traffic_src = pmc_traffic(cfg_id, N, M, Lper, a.chunk)
+        kname = ("panel_kernel<Mp/64 row blocks> (Wt = Linv*Kzx and colsum((LuE^T Wt)^2) on one 64-column panel in LDS, csrc/gemmp.hip)" if panel
+                 else "gemmw_gen_kernel<512,128,generated Kzx,lower,store+colstats> (Wt = Linv*k(Z,X), csrc/gemmw.hip)" if bits & 2
                  else "gemmw_kernel<128,256,mem,lower,store+colstats> (Wt = Linv*Kzx, csrc/gemmw.hip)" if bits & 1
                  else "gemm128_kernel<%s,NN,store+colstats> (Wt = Linv*Kzx, csrc/gemm.hip)" % ("float" if dname == "f32" else "double"))
         roof = {"bound": "mfma",

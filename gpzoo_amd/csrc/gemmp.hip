@@ -1,0 +1,401 @@
+// gemmp.hip -- both forward products on ONE column panel held in LDS, for few inducing points (Mp <= 512, fp32).
+//
+//   stage 1  Wt = Linv * Kzx      (gp.py:255 + :276)                      A lower triangular, B = the Kzx panel
+//   stage 2  colsum((LuE^T Wt)^2) (gp.py:280-296 / utilities.py:382-397)  A upper triangular, B = the Wt panel
+//
+// At M = 512 a row tile of the wide-tile kernels (gemmw.hip) has 8 .. 32 steps: its epilogue (store of the Wt tile, 9 %),
+// the operand traffic of a B panel that every row tile reads again (6 %) and the barrier of every step are first-order
+// terms there (configs[1] stage 1 at 0.74 of the fp32 MFMA peak).  Here a workgroup owns a whole
+// panel -- all Mp rows of 64 columns of one latent -- from the covariance to the column statistics:
+//   * the Kzx panel is read ONCE into LDS, transposed to [column][k] (k contiguous: one ds_read_b128 is a lane's four k
+//     values of a 16-deep chunk; pitch Mp + 4 floats keeps the 16 lanes of a read group on distinct 16-byte bank slots);
+//   * wave w owns the 64 rows of one row block for both stages: its A fragments come straight from L2 into registers
+//     (no other wave needs them: nothing is staged, and there is NO barrier inside a stage -- the panel is read-only);
+//   * stage 1's result stays in the accumulators (64 rows x 64 columns per wave), gives colsum(Wt^2) and muE^T Wt from
+//     there, and overwrites the Kzx panel in LDS (all waves are through stage 1 by then) as stage 2's B operand; Wt
+//     reaches memory only when the caller retains it for the backward pass;
+//   * row block r has r + 1 k-blocks in stage 1 and nrb - r in stage 2: every wave runs nrb + 1 of them per panel; the
+//     two waves a SIMD holds (w, w + 4) take blocks r and nrb - 1 - r, so that the SIMDs are level inside each stage too;
+//   * the latents of a launch are dealt to the XCDs (blocks b, b + 8, ... share one): an XCD's workgroups stream the same
+//     Linv / LuE^T (1 MB each at Mp = 512) out of its 4 MB L2.
+// k order, MFMA order and the values of Wt are those of gemmw.hip / gemm.hip (lane group q owns k = 4q .. 4q+3 of a 16-deep
+// chunk, chunks ascending from k = 0, zero sub-tiles of the diagonal block skipped): the retained Wt is bitwise the same.
+#include "gemmp.h"
+
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+
+// Timing-only diagnostics (WRONG results): -DGPZ_P_ABL=4 builds the kernel without its A-fragment loads, 8 without its B-fragment reads; at run time
+// GPZ_PANEL_DBG=1 loads the Kzx panel once per workgroup, =2 deals the row blocks to the waves in order (no SIMD pairing),
+// =8 gives every wave the k range of the middle row block (equal durations), =16 swaps the A operands of the two stages.
+#ifndef GPZ_P_ABL
+#define GPZ_P_ABL 0
+#endif
+
+namespace gpz {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct PanelParams {
+  const float* Linv; const float* LuT;      // (L, Mp, Mp)
+  const float* Kzx;                         // (L, Mp, ncp)
+  float* Wt;                                // (L, Mp, ncp) or null
+  const float* muE;                         // (L, Mp)
+  float* ps1; float* pm1; float* ps2;       // [L][Mp / 128][ncp]
+  int Mp, ncp, L, npan, units;              // panels per latent, units = L * npan
+  unsigned long long* stamps;               // debug (gpz_debug_panel_stamps): workgroup 0's phase times, [panel][wave][8]
+  int dbg;                                  // timing diagnostics (GPZ_PANEL_DBG; wrong results): 1 panel loaded once, 2 no SIMD pairing
+};
+
+constexpr int P_TN = 64;                    // columns of a panel
+
+// which 32-row block wave w takes: a workgroup's waves go to the SIMDs in a cyclic order of period 4, so waves w, w + 4,
+// w + 8, w + 12 share one; block r has r + 1 k-chunks-pairs in stage 1 and nb - r in stage 2
+template <int NB> __device__ __forceinline__ int row_block_of(int w) {
+  if constexpr (NB == 16) return w < 4 ? w : w < 8 ? 11 - w : w < 12 ? w : 27 - w;     // SIMD s: blocks s, 7 - s, 8 + s, 15 - s
+  else if constexpr (NB == 12) return w < 4 ? w : w < 8 ? 11 - w : w;                   //         s, 7 - s, 8 + s
+  else if constexpr (NB == 8) return w < 4 ? w : 11 - w;                                //         s, 7 - s
+  else return w;
+}
+
+template <int NB, bool STORE>
+__global__ __launch_bounds__(64 * NB) void panel_kernel(const PanelParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // Panel image: column c at c * PK, k contiguous, the four 16-byte slots of every 16-deep chunk XOR-permuted by column
+  // (slot s of column c sits at s ^ g(c), g = [0, 2, 3, 1][(c >> 2) & 3]).  PK = 16 * odd puts columns c .. c + 3 on the
+  // four quarters of the 256-byte bank row; with the permutation every lane group of a ds_read_b128 -- lanes {0-3, 12-15,
+  // 20-27} etc.: columns r and k slots q mixed -- covers sixteen distinct 16-byte bank slots (no conflict).
+  constexpr int Mp = 32 * NB, PK = Mp + 16;
+  constexpr int MI = 2;                          // 16-row sub-tiles of a wave's 32 rows
+  float* const P = smem;                         // [64][PK]: Kzx panel, then Wt panel
+  float* const red = smem + P_TN * PK;           // [3][NB][64]: per-wave column statistics
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int rb = (p.dbg & 2) ? wave : row_block_of<NB>(wave);
+  constexpr int NT = 64 * NB;
+  auto gperm = [](int c) { const int t = (c >> 2) & 3; return (((t >> 1) ^ t) & 1) << 1 | (t >> 1); };
+
+  // units (latent, panel) in latent-major order; XCD x takes the contiguous range [x U / 8, (x + 1) U / 8)
+  const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int u_lo = (int)((int64_t)x * p.units / 8), u_hi = (int)((int64_t)(x + 1) * p.units / 8);
+  if (u_lo + j >= u_hi) return;
+
+  // this lane's A rows: row block rb, sub-tile mi, row r; its k offset 4q inside a chunk
+  int a_voff[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) a_voff[mi] = ((rb * 32 + mi * 16 + r) * Mp + 4 * q) * 4;
+  // B fragment: column ni * 16 + r, k = k0 + 4q .. 4q + 3 (slot q of the chunk)
+  const float* const bfrag = P + r * PK + ((q ^ gperm(r)) << 2);
+  const int kd = ((p.dbg & 8) ? NB / 2 - 1 : rb) * 32;        // first k of the wave's diagonal block
+
+  int n_it = 0;
+  auto stamp = [&](int ph) __attribute__((always_inline)) {
+    if (p.stamps && blockIdx.x == 0 && n_it < 16 && wave < 8 && lane == 0)
+      p.stamps[(n_it * 8 + wave) * 8 + ph] = __builtin_readcyclecounter();
+  };
+
+  using std::integral_constant;
+  using i0 = integral_constant<int, 0>;
+  using i1 = integral_constant<int, 1>;
+
+  // The Kzx panel travels memory -> registers -> LDS (transposed).  It is fetched by the waves of the upper half of the row
+  // blocks: their stage 2 is the short one, so they are through with it (accumulators and fragments dead: 64 free
+  // registers) in the first half of the workgroup's stage 2 and would only wait at its barrier -- the next panel's HBM
+  // latency passes there.  Fetching thread ft takes columns 4 c4 .. 4 c4 + 3 of the k rows k_of, k_of + 2 NB, ...: one
+  // per-lane offset, the row step in the scalar offset.
+  constexpr int NR = 16;                         // float4 per fetching thread: Mp * 64 * 4 bytes / (NT / 2 threads)
+  constexpr int RP = 2 * NB;                     // k rows per pass of the NT / 2 fetching threads
+  f32x4 pv[NR];
+  const bool fetcher = rb >= NB / 2;
+  const int ft = (rb - NB / 2) * 64 + lane;
+  const int pc4 = ft & 15, pk_of = ft >> 4;
+  auto panel_fetch = [&](int l, int64_t col0) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.Kzx + (int64_t)l * Mp * p.ncp + col0), 0, (Mp - 1) * p.ncp * 4 + P_TN * 4, 0x00020000);
+    const int voff = (pk_of * p.ncp + 4 * pc4) * 4, sstep = RP * p.ncp * 4;
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kr, voff, i * sstep, 0));
+#endif
+  };
+  auto panel_write = [&]() __attribute__((always_inline)) {
+    int kof = pk_of;
+    asm volatile("" : "+v"(kof));                // per panel: keeps the store addresses from being hoisted out of the unit loop (and spilled)
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int k = i * RP + kof;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * pc4 + e;
+        P[c * PK + (k & ~15) + ((((k >> 2) & 3) ^ gperm(c)) << 2) + (k & 3)] = pv[i][e];
+      }
+    }
+  };
+
+  f32x4 acc[MI][4];
+  f32x4 fa0[MI], fb0[4], fa1[MI], fb1[4];
+  // One 16-deep chunk: MFMAs over the sub-tiles LO .. HI of the wave's 32 rows with the fragments in (fa, fb)
+  auto mma = [&](const f32x4 (&fa)[MI], const f32x4 (&fb)[4], auto lo_c, auto hi_c) __attribute__((always_inline)) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int mi = LO; mi <= HI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi][jj], fb[ni][jj], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // A fragments straight from L2: WHICH = 1 Linv, 2 LuE^T of latent l
+  auto load_a = [&](auto which_c, int l, f32x4 (&fa)[MI], int k0, auto lo_c, auto hi_c) __attribute__((always_inline)) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (GPZ_P_ABL & 4) return;
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(((decltype(which_c)::value == 1) != ((p.dbg & 16) != 0) ? p.Linv : p.LuT) + (int64_t)l * Mp * Mp), 0, Mp * Mp * 4, 0x00020000);
+#pragma unroll
+    for (int mi = LO; mi <= HI; ++mi)
+      fa[mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, a_voff[mi], k0 * 4, 0));
+#endif
+  };
+  auto load_b = [&](f32x4 (&fb)[4], int k0) __attribute__((always_inline)) {
+    if (GPZ_P_ABL & 8) return;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) fb[ni] = *reinterpret_cast<const f32x4*>(bfrag + ni * 16 * PK + k0);
+  };
+  // the fragments of the NEXT chunk are requested before this chunk's MFMAs and stay there (hipcc otherwise sinks the
+  // loads to their first use and the wave waits out their latency with the matrix pipe empty)
+  auto load = [&](auto which_c, int l, f32x4 (&fa)[MI], f32x4 (&fb)[4], int k0, auto lo_c, auto hi_c) __attribute__((always_inline)) {
+    load_a(which_c, l, fa, k0, lo_c, hi_c);
+    load_b(fb, k0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const i1 a1s{};
+  const integral_constant<int, 2> a2s{};
+
+  int u = u_lo + j;
+  int l = u / p.npan, pn = u - l * p.npan;
+#pragma unroll 1
+  for (;;) {
+    const int64_t col0 = (int64_t)pn * P_TN;
+    const int un = u + per;
+    stamp(0);
+    if (u == u_lo + j) {                         // the workgroup's first panel; later ones are on their way
+      if (fetcher) panel_fetch(l, col0);
+      else {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) pv[i] = f32x4{0, 0, 0, 0};
+      }
+    }
+    load_a(a1s, l, fa0, 0, i0{}, i1{});          // stage 1's first A chunk
+    __builtin_amdgcn_sched_barrier(0);
+    if (fetcher && (!(p.dbg & 1) || u == u_lo + j)) panel_write();
+    stamp(1);
+    __syncthreads();
+    stamp(2);
+
+    // ---------------- stage 1: rows of block rb, k = 0 .. kd + 31 (the last 32: the diagonal block) ----------------
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
+    load_b(fb0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int k = 0; k < kd; k += 32) {           // full chunks, two per trip (kd is a multiple of 32)
+      load(a1s, l, fa1, fb1, k + 16, i0{}, i1{});
+      mma(fa0, fb0, i0{}, i1{});
+      load(a1s, l, fa0, fb0, k + 32, i0{}, i1{});   // k + 32 <= kd: at most the diagonal block's first chunk
+      mma(fa1, fb1, i0{}, i1{});
+    }
+    // diagonal block: chunk v holds k = kd + 16 v ..: rows of sub-tiles mi < v are zero there
+    load(a1s, l, fa1, fb1, kd + 16, i1{}, i1{});
+    mma(fa0, fb0, i0{}, i1{});
+    load_a(a2s, l, fa0, kd, i0{}, i0{});         // stage 2's first A chunk sets out
+    __builtin_amdgcn_sched_barrier(0);
+    mma(fa1, fb1, i1{}, i1{});
+    stamp(3);
+
+    // column statistics of this wave's 32 rows, from the accumulators
+    {
+      float ssq[4] = {0.f, 0.f, 0.f, 0.f}, smu[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.muE + (int64_t)l * Mp + rb * 32 + mi * 16 + 4 * q);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const float v = acc[mi][ni][g];
+            ssq[ni] = __builtin_fmaf(v, v, ssq[ni]);
+            smu[ni] = __builtin_fmaf(m4[g], v, smu[ni]);
+          }
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        ssq[ni] += __shfl_xor(ssq[ni], 16); ssq[ni] += __shfl_xor(ssq[ni], 32);
+        smu[ni] += __shfl_xor(smu[ni], 16); smu[ni] += __shfl_xor(smu[ni], 32);
+        if (q == 0) {
+          red[(0 * NB + rb) * 64 + ni * 16 + r] = ssq[ni];
+          red[(1 * NB + rb) * 64 + ni * 16 + r] = smu[ni];
+        }
+      }
+    }
+    __syncthreads();                             // every wave is through with the Kzx panel
+    // Wt block -> LDS (stage 2's B operand): lane (r, q) holds rows 4q .. 4q+3 of column ni * 16 + r: one 16-byte write
+    {
+      int wbase = r * PK + rb * 32 + ((q ^ gperm(r)) << 2);
+      asm volatile("" : "+v"(wbase));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(P + wbase + ni * 16 * PK + mi * 16) = acc[mi][ni];
+    }
+    if constexpr (STORE) {                       // retained for the backward pass: 64-byte row segments straight from the registers
+      float* const Wg = p.Wt + ((int64_t)l * Mp + rb * 32) * p.ncp + col0 + r;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) Wg[(int64_t)(mi * 16 + 4 * q + g) * p.ncp + ni * 16] = acc[mi][ni][g];
+    }
+    __syncthreads();
+    if (tid < 64) {                              // per 128-row block, as the tile kernels write them (finalize_kernel sums the blocks)
+#pragma unroll
+      for (int b = 0; b < NB / 4; ++b) {
+        const int64_t o = ((int64_t)l * (NB / 4) + b) * p.ncp + col0 + tid;
+        float s1 = 0.f, m1 = 0.f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { s1 += red[(0 * NB + 4 * b + h) * 64 + tid]; m1 += red[(1 * NB + 4 * b + h) * 64 + tid]; }
+        p.ps1[o] = s1;
+        p.pm1[o] = m1;
+      }
+    }
+
+    stamp(4);
+    // ---------------- stage 2: rows of block rb of LuE^T Wt, k = kd .. Mp - 1 (the first 32: the diagonal block) ----------------
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
+    // diagonal block: chunk v holds k = kd + 16 v ..: rows of sub-tiles mi > v are zero there
+    load_b(fb0, kd);
+    __builtin_amdgcn_sched_barrier(0);
+    load(a2s, l, fa1, fb1, kd + 16, i0{}, i1{});
+    mma(fa0, fb0, i0{}, i0{});
+    if (kd + 32 < Mp) {
+      load(a2s, l, fa0, fb0, kd + 32, i0{}, i1{});
+      mma(fa1, fb1, i0{}, i1{});
+#pragma unroll 1
+      for (int k = kd + 32; k < Mp; k += 32) {
+        load(a2s, l, fa1, fb1, k + 16, i0{}, i1{});
+        mma(fa0, fb0, i0{}, i1{});
+        if (k + 32 < Mp) load(a2s, l, fa0, fb0, k + 32, i0{}, i1{});
+        mma(fa1, fb1, i0{}, i1{});
+      }
+    } else {
+      mma(fa1, fb1, i0{}, i1{});
+    }
+    stamp(5);
+    {
+      float ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) ssq[ni] = __builtin_fmaf(acc[mi][ni][g], acc[mi][ni][g], ssq[ni]);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        ssq[ni] += __shfl_xor(ssq[ni], 16); ssq[ni] += __shfl_xor(ssq[ni], 32);
+        if (q == 0) red[(2 * NB + rb) * 64 + ni * 16 + r] = ssq[ni];
+      }
+    }
+    stamp(6);
+    if (fetcher && un < u_hi && !(p.dbg & 1)) {  // this wave's accumulators are dead: the next panel sets out
+      const int ln = un / p.npan;
+      panel_fetch(ln, (int64_t)(un - ln * p.npan) * P_TN);
+    } else {                                     // (tells the register allocator that nothing of pv lives through the stages)
+#pragma unroll
+      for (int i = 0; i < NR; ++i) pv[i] = f32x4{0, 0, 0, 0};
+    }
+    __syncthreads();                             // ... and every wave is through with the Wt panel
+    stamp(7);
+    ++n_it;
+    if (tid < 64) {
+#pragma unroll
+      for (int b = 0; b < NB / 4; ++b) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) s2 += red[(2 * NB + 4 * b + h) * 64 + tid];
+        p.ps2[((int64_t)l * (NB / 4) + b) * p.ncp + col0 + tid] = s2;
+      }
+    }
+    if (un >= u_hi) break;
+    u = un; l = un / p.npan; pn = un - l * p.npan;
+  }
+}
+
+static unsigned long long* g_panel_stamps = nullptr;
+
+bool panel_supported(int64_t Mp, int64_t ncp) {
+  return Mp >= 128 && Mp <= 512 && Mp % 128 == 0 && ncp % P_TN == 0 && Mp * ncp * 4 < (1ll << 31);
+}
+
+template <int NB>
+static int launch_t(const PanelParams& p, bool store, hipStream_t s) {
+  const size_t lds = sizeof(float) * ((size_t)P_TN * (p.Mp + 16) + 3 * NB * 64);
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [&] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr_rc == hipSuccess)
+      attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  GPZ_HIP_OK(attr_rc);
+  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+      n = 256;
+    cus = n;
+  }
+  int wgs = cus * (per_cu > 2 ? 2 : per_cu);
+  wgs -= wgs % 8;
+  if (store) hipLaunchKernelGGL((panel_kernel<NB, true>), dim3(wgs), dim3(64 * NB), lds, s, p);
+  else hipLaunchKernelGGL((panel_kernel<NB, false>), dim3(wgs), dim3(64 * NB), lds, s, p);
+  GPZ_LAUNCH_OK();
+  return 0;
+}
+
+int panel_launch(const PanelArgs& a, hipStream_t s) {
+  GPZ_REQUIRE(panel_supported(a.Mp, a.ncp), "panel_launch: unsupported shape Mp=%lld ncp=%lld", (long long)a.Mp, (long long)a.ncp);
+  PanelParams p;
+  p.Linv = a.Linv; p.LuT = a.LuT; p.Kzx = a.Kzx; p.Wt = a.Wt; p.muE = a.muE;
+  p.ps1 = a.ps1; p.pm1 = a.pm1; p.ps2 = a.ps2;
+  p.stamps = g_panel_stamps;
+  static const int dbg = [] { const char* e = getenv("GPZ_PANEL_DBG"); return e ? atoi(e) : 0; }();
+  p.dbg = dbg;
+  p.Mp = (int)a.Mp; p.ncp = (int)a.ncp; p.L = a.L; p.npan = (int)(a.ncp / P_TN); p.units = a.L * p.npan;
+  const bool store = a.Wt != nullptr;
+  switch (a.Mp / 32) {
+    case 4: return launch_t<4>(p, store, s);
+    case 8: return launch_t<8>(p, store, s);
+    case 12: return launch_t<12>(p, store, s);
+    default: return launch_t<16>(p, store, s);
+  }
+}
+
+}  // namespace gpz
+
+// Debug: device buffer of 16 * 8 * 8 uint64 that workgroup 0 of the next panel launches fills with its phase times
+// (shader clock; tools/panel_trace.py), or null to stop.
+extern "C" void gpz_debug_panel_stamps(unsigned long long* buf) { gpz::g_panel_stamps = buf; }

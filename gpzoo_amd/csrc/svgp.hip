@@ -17,11 +17,13 @@
 // never stored.  All reductions are slab-based (no atomics): bitwise reproducible.
 #include "common.h"
 #include "gemmw.h"
+#include "gemmp.h"
 #include "factor.h"
 #include "gemm.h"
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace gpz {
 
@@ -490,6 +492,15 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
   return 0;
 }
 
+// The panel kernel (gemmp.hip) takes both products of an fp32 chunk with Mp <= 512 when the caller asks for it (flags) or
+// the environment does (GPZ_SVGP_PRODUCTS=panel: A/B timing without rebuilding).  Built, bitwise the same Wt, and as fast
+// as the tile kernels at configs[1] -- not faster, so the tile kernels stay the default.
+static bool panel_path(const gpz_svgp_problem* p, bool f32, int64_t Mp, int64_t ncp) {
+  static const bool env_panel = [] { const char* e = getenv("GPZ_SVGP_PRODUCTS"); return e && !strcmp(e, "panel"); }();
+  return f32 && (env_panel || (p->flags & GPZ_SVGP_PANEL_PRODUCTS)) && !(p->flags & GPZ_SVGP_NARROW_TILES) &&
+         panel_supported(Mp, ncp);
+}
+
 template <typename T>
 static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes, hipStream_t s) {
   const Plan pl = make_plan(p, chunk);
@@ -516,6 +527,8 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     const int nt = (int)(ncp / NB);
     const ProductSchedule sched = product_schedule<T>(true, nt);
     const bool wide = !narrow && pl.f32 && wide_product_supported(Mp, ncp);    // fp32: 128 x 256 tiles (gemmw.hip)
+    // fp32, Mp <= 512, on request: both products on one column panel held in LDS (gemmp.hip)
+    const bool panel = panel_path(p, pl.f32, Mp, ncp) && !fused;
     T* const Wc = p->wt_cache ? wtc.wt(ci) : b.Wc;      // retained for the backward pass when asked for
     T* const ps1 = p->wt_cache ? wtc.ps1(ci) : b.ps1;
     if (fused) {
@@ -540,7 +553,16 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
       prof_begin(PROF_STAGE1, s);
       bool done = false;
       if constexpr (sizeof(T) == 4) {
-        if (wide) {      // Wt = Linv * Kzx on the 128 x 256 tile, with colsum(Wt^2) and muE^T Wt
+        if (panel) {     // Wt = Linv * Kzx, its column statistics AND stage 2's, panel by panel; Wt stored only when retained
+          PanelArgs pa;
+          pa.Linv = b.LinvG; pa.LuT = b.LuT; pa.Kzx = b.Kc; pa.Wt = p->wt_cache ? Wc : nullptr; pa.muE = b.muE;
+          pa.ps1 = ps1; pa.pm1 = b.pm1; pa.ps2 = b.ps2; pa.Mp = Mp; pa.ncp = ncp; pa.L = L32;
+          if (int rc = panel_launch(pa, s)) return rc;
+          done = true;
+        }
+      }
+      if constexpr (sizeof(T) == 4) {
+        if (wide && !done) {      // Wt = Linv * Kzx on the 128 x 256 tile, with colsum(Wt^2) and muE^T Wt
           WideArgs wa = {};
           wa.A = b.LinvG; wa.B = b.Kc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 0; wa.epilogue = WIDE_STORE_STATS;
           wa.C = Wc; wa.mu = b.muE; wa.ps_sq = ps1; wa.ps_mu = b.pm1;
@@ -560,7 +582,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
       prof_end(PROF_STAGE1, s);
     }
     prof_begin(PROF_STAGE2, s);
-    {
+    if (!panel) {
       bool done = false;
       if constexpr (sizeof(T) == 4) {
         if (wide) {      // colsum((LuE^T Wt)^2) on the 128 x 256 tile
@@ -1396,7 +1418,7 @@ static int check_problem(const gpz_svgp_problem* p) {
   GPZ_REQUIRE(p->X && p->Z && p->mu && p->Lu_raw && p->info, "gpz_svgp: null input pointer");
   GPZ_REQUIRE(p->d >= 1 && p->d <= 4, "gpz_svgp: input dimension %d unsupported", p->d);
   if (p->y) GPZ_REQUIRE(p->noise_sd > 0.0, "gpz_svgp: noise_sd must be positive");
-  GPZ_REQUIRE((p->flags & ~(GPZ_SVGP_MATERIALIZE_KZX | GPZ_SVGP_NARROW_TILES | GPZ_SVGP_GENERATE_KZX)) == 0,
+  GPZ_REQUIRE((p->flags & ~(GPZ_SVGP_MATERIALIZE_KZX | GPZ_SVGP_NARROW_TILES | GPZ_SVGP_GENERATE_KZX | GPZ_SVGP_PANEL_PRODUCTS)) == 0,
               "gpz_svgp: unknown bits in flags (0x%x): the field was `reserved` before ABI 210 -- zero it", p->flags);
   return 0;
 }
@@ -1413,7 +1435,8 @@ extern "C" size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t ch
 }
 
 // Which kernels gpz_svgp_forward takes for the two big products of this problem and chunk: bit 0 the wide-tile fp32
-// kernels (gemmw.hip), bit 1 the generated-Kzx stage 1; 0: the 128 x 128-tile kernels (gemm.hip).  -1: bad problem.
+// kernels (gemmw.hip), bit 1 the generated-Kzx stage 1; 4: the panel kernel (gemmp.hip: both products in one launch,
+// fp32, Mp <= 512); 0: the 128 x 128-tile kernels (gemm.hip).  -1: bad problem.
 extern "C" int gpz_svgp_forward_path(const gpz_svgp_problem* p, int64_t chunk) {
   if (check_problem(p)) return -1;
   const Plan pl = make_plan(p, chunk);
@@ -1421,7 +1444,8 @@ extern "C" int gpz_svgp_forward_path(const gpz_svgp_problem* p, int64_t chunk) {
   const bool wide = !narrow && pl.f32 && wide_product_supported(pl.Mp, pl.nc);
   const bool fused = !narrow && (p->flags & GPZ_SVGP_GENERATE_KZX) && !(p->flags & GPZ_SVGP_MATERIALIZE_KZX) &&
                      fused1_supported(p->dtype, p->k.kind, p->d);
-  return (wide ? 1 : 0) | (fused ? 2 : 0);
+  const bool panel = !fused && panel_path(p, pl.f32, pl.Mp, pl.nc);
+  return panel ? 4 : (wide ? 1 : 0) | (fused ? 2 : 0);
 }
 
 extern "C" int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes, void* stream) {

@@ -390,7 +390,8 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
                  y=None, noise_sd: Optional[float] = None, clamp_min: float = 1e-6, chunk: int = 0,
                  want_moments: bool = True, want_Lu: bool = True, want_chol: bool = False,
                  check_info: bool = True, cache: Optional[FactorCache] = None,
-                 retain_wt: float = 0.0, materialize_kzx: Optional[bool] = None, narrow_tiles: bool = False) -> dict:
+                 retain_wt: float = 0.0, materialize_kzx: Optional[bool] = None, narrow_tiles: bool = False,
+                 panel_products: bool = False) -> dict:
     """One fused forward pass (gpz_svgp_forward).  Returns a dict with mean, scale
     (L,N), Lu (L,M,M), chol (L,M,M), kl (L,), loglik (L,), elbo () -- fp64 scalars.
     ``retain_wt`` > 0: keep Wt of every chunk for ``svgp_backward(wt_cache=out["wt_cache"])`` when it fits
@@ -398,7 +399,8 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     ``materialize_kzx``: True = write every Kzx chunk to HBM and run the triangular product on it (the reference's
     structure), False = the product that generates its covariance operand itself (fp32 RBF / Matern-3/2, d <= 2), None =
     the library's choice; ``narrow_tiles``: the 128 x 128-tile kernel of the other precisions for the two big fp32
-    products.  Same Wt bits on every path."""
+    products; ``panel_products`` (fp32, M <= 512): both products in one launch on 64-column panels held in LDS.  Same Wt
+    bits on every path."""
     _need_cuda(X, Z, mu, Lu_raw)
     if X.dim() == 2 and X.shape[0] == 0 and Z.dim() == 2 and Z.shape[0] > 0:
         # No data points: q(F) is empty and the ELBO is -sum(KL), as the reference's torch code gives for an (0,d) X.
@@ -420,6 +422,8 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
         p.flags |= _lib.SVGP_MATERIALIZE_KZX if materialize_kzx else _lib.SVGP_GENERATE_KZX
     if narrow_tiles:
         p.flags |= _lib.SVGP_NARROW_TILES
+    if panel_products:               # fp32, M <= 512: both products in one launch, panel by panel (csrc/gemmp.hip)
+        p.flags |= _lib.SVGP_PANEL_PRODUCTS
     if y is not None:
         y = y.detach().to(dt).reshape(L, N).contiguous()
         p.y, p.noise_sd = y.data_ptr(), float(noise_sd)
@@ -451,7 +455,7 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     ws = _workspace(dev, nbytes)
     rc = lib.gpz_svgp_forward(C.byref(p), int(chunk), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_svgp_forward")
-    out["path"] = lib.gpz_svgp_forward_path(C.byref(p), int(chunk))    # bit 0: wide tiles, bit 1: generated Kzx
+    out["path"] = lib.gpz_svgp_forward_path(C.byref(p), int(chunk))    # bit 0: wide tiles, bit 1: generated Kzx, 4: panel kernel
     bad = check_info and bool(info.any())       # one device-to-host sync, shared by the cache decision and the raise
     if cache is not None:
         # a factor that failed must not be reused; without the host check the cache stays uncommitted

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPZ_VERSION 210
+#define GPZ_VERSION 211
 
 enum { GPZ_F32 = 0, GPZ_F64 = 1 };
 
@@ -132,6 +132,10 @@ int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_l, void* B,
                                      * the wide-tile one (csrc/gemmw.hip); implies a materialised Kzx */
 #define GPZ_SVGP_GENERATE_KZX 4     /* fp32 RBF / Matern-3/2, d <= 2: stage 1 generates its covariance operand inside the
                                      * product (csrc/gemmw.hip) and Kzx is never written */
+#define GPZ_SVGP_PANEL_PRODUCTS 8   /* fp32, M <= 512: both products panel by panel in ONE launch (csrc/gemmp.hip): a workgroup
+                                     * holds 64 columns x all rows in LDS from Kzx to the column statistics; Wt reaches
+                                     * memory only when retained.  Same Wt bits; mean / scale differ from the tile path
+                                     * by fp32 rounding (other summation order of the statistics).  Ignored elsewhere. */
 
 typedef struct gpz_svgp_problem {
   gpz_kernel_desc k;
@@ -183,7 +187,8 @@ size_t gpz_svgp_wt_cache_bytes(const gpz_svgp_problem* p, int64_t chunk);
 
 size_t gpz_svgp_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
 /* Which kernels gpz_svgp_forward takes for the two big products of this problem and chunk (0 = automatic chunk):
- * bit 0 the wide-tile fp32 kernels, bit 1 the generated-Kzx stage 1; 0: the 128 x 128-tile kernels; -1: bad problem.
+ * bit 0 the wide-tile fp32 kernels, bit 1 the generated-Kzx stage 1; 4: the panel kernel (both products in one launch);
+ * 0: the 128 x 128-tile kernels; -1: bad problem.
  * Unknown bits in `flags` are an error since ABI 210 (the word was `reserved` before 200: zero it). */
 int gpz_svgp_forward_path(const gpz_svgp_problem* p, int64_t chunk);
 int gpz_svgp_forward(const gpz_svgp_problem* p, int64_t chunk, void* ws, size_t ws_bytes,

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_string():
     from gpzoo_amd import _lib
     lib = _lib.load()
-    assert lib.gpz_version() == 210          # 210: unknown gpz_svgp_problem.flags bits rejected, gpz_svgp_forward_path
+    assert lib.gpz_version() == 211          # 210: unknown gpz_svgp_problem.flags bits rejected, gpz_svgp_forward_path; 211: GPZ_SVGP_PANEL_PRODUCTS
     assert isinstance(lib.gpz_last_error(), bytes)
 
 
@@ -103,7 +103,7 @@ def test_flag_constants_match_the_header():
     hdr = open(os.path.join(ROOT, "include", "gpzoo_hip.h")).read()
     vals = {n: int(v) for n, v in re.findall(r"#define\s+(GPZ_SVGP_[A-Z_]+)\s+(\d+)", hdr)}
     assert vals == {"GPZ_SVGP_MATERIALIZE_KZX": _lib.SVGP_MATERIALIZE_KZX, "GPZ_SVGP_NARROW_TILES": _lib.SVGP_NARROW_TILES,
-                    "GPZ_SVGP_GENERATE_KZX": _lib.SVGP_GENERATE_KZX}
-    assert len(set(vals.values())) == 3 and all(v & (v - 1) == 0 for v in vals.values())     # distinct single bits
+                    "GPZ_SVGP_GENERATE_KZX": _lib.SVGP_GENERATE_KZX, "GPZ_SVGP_PANEL_PRODUCTS": _lib.SVGP_PANEL_PRODUCTS}
+    assert len(set(vals.values())) == 4 and all(v & (v - 1) == 0 for v in vals.values())     # distinct single bits
     fields = dict(_lib.SvgpProblem._fields_)
     assert "flags" in fields and ctypes.sizeof(fields["flags"]) == 4

@@ -3,6 +3,8 @@
   narrow + kfill   kfill_kernel, then gemm128_kernel for both products (the path of round 2 and of every other precision)
   wide + kfill     kfill_kernel, then gemmw_kernel<128,256,mem> for both products (the default)
   generated        gemmw_kernel<512,128,gen> (16 waves): stage 1 computes its covariance operand itself, Kzx is never written
+  panel            kfill_kernel, then panel_kernel (csrc/gemmp.hip; fp32, M <= 512, on request): BOTH products in one launch, a
+                   workgroup holding 64 columns x all rows in LDS; Wt is stored only when retained
 
 cov.h is shared by the fill and the generator and all three kernels give lane group q the k = 4q..4q+3 slots of a
 16-deep chunk, so Wt must agree BIT FOR BIT; the column statistics are summed in different orders, so mean / scale /
@@ -87,6 +89,68 @@ def test_wide_tiles_agree_with_narrow_tiles_on_random_shapes(N, M, L):
     assert torch.equal(out["wt_cache"].view(torch.int32)[:nwt], ref["wt_cache"].view(torch.int32)[:nwt])
     torch.testing.assert_close(out["scale"], ref["scale"], rtol=1e-5, atol=0)
     assert float(out["elbo"]) == pytest.approx(float(ref["elbo"]), rel=1e-7)
+
+
+PANEL_SHAPES = [
+    # cfg, N, M, L, whitened
+    (2, 50000, 512, 8, True),        # configs[1] itself: 16 waves, one latent per XCD
+    (2, 20000, 512, 3, True),        # fewer latents than XCDs: an XCD's range of panels spans two latents
+    (3, 5000, 500, 5, True),         # Mp = 512 with padded rows; Matern-3/2; ragged last panel (N not a multiple of 64)
+    (3, 2000, 384, 3, True),         # 12 row blocks (three waves per SIMD)
+    (2, 9000, 256, 11, True),        # 8 row blocks, two workgroups per CU
+    (3, 777, 100, 2, True),          # 4 row blocks: a single 128-block
+    (3, 3000, 300, 4, False),        # un-whitened SVGP: LuE = Linv Lu, clamp
+    (2, 64, 40, 1, True),            # one panel in all
+]
+
+
+@pytest.mark.parametrize("cfg,N,M,L,whitened", PANEL_SHAPES)
+def test_panel_kernel_agrees_with_the_tile_kernels(cfg, N, M, L, whitened):
+    """The one-launch panel path (GPZ_SVGP_PANEL_PRODUCTS): the library reports it took it, the retained Wt is bit for bit
+    the tile kernels', mean / scale / ELBO agree to fp32 rounding (its column statistics are summed wave by wave), and
+    without retention (the evaluation path: Wt never reaches memory) the moments are the same bits as with it."""
+    from gpzoo_amd import ops
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(cfg, N=N, M=M, L=L)
+    c["whitened"] = whitened
+    g = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
+    spec, extra = spec_for_config(g, torch.device("cuda", 0))
+    Mp, ncp = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    nwt = L * Mp * ncp
+    ref = _run(c, g, spec, extra)
+    out = _run(c, g, spec, extra, panel_products=True)
+    assert ref["path"] in (0, 1) and out["path"] == 4
+    assert torch.equal(out["wt_cache"].view(torch.int32)[:nwt], ref["wt_cache"].view(torch.int32)[:nwt])
+    torch.testing.assert_close(out["mean"], ref["mean"], rtol=1e-5, atol=1e-5 * float(ref["mean"].abs().max()))
+    torch.testing.assert_close(out["scale"], ref["scale"], rtol=1e-5, atol=0)
+    assert float(out["elbo"]) == pytest.approx(float(ref["elbo"]), rel=1e-7)
+    assert torch.equal(out["kl"], ref["kl"])
+    bare = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
+                            noise_sd=c["noise_sd"], want_Lu=False, panel_products=True, **extra)
+    assert bare["path"] == 4 and "wt_cache" not in bare
+    assert torch.equal(bare["mean"], out["mean"]) and torch.equal(bare["scale"], out["scale"])
+    assert float(bare["elbo"]) == float(out["elbo"])
+
+
+def test_panel_kernel_in_chunks_and_against_the_oracle():
+    """N=3000, M=300, L=3 Matern-3/2 fp32 on the panel path, whole and in three chunks of columns, against the CPU oracle;
+    and the request is ignored where the kernel does not apply (M > 512, fp64): the tile kernels run."""
+    from oracle import svgp_oracle as O
+    from gpzoo_amd import ops
+    c, g, spec, extra = _problem(3, 3000, 300, 3, 2)
+    e, mean, scale = O.elbo_eval(c["kind"], c["whitened"], c["X"], c["y"], c["Z"], c["sigma"], c["lengthscale"], c["mu"],
+                                 c["Lu_raw"], c["jitter"], c["noise_sd"])
+    rt = rtol_for(torch.float32)
+    for chunk in (0, 1024):
+        out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
+                               noise_sd=c["noise_sd"], want_Lu=False, panel_products=True, chunk=chunk, **extra)
+        assert out["path"] == 4
+        torch.testing.assert_close(out["mean"].cpu(), mean, rtol=rt, atol=rt * float(mean.abs().max()))
+        torch.testing.assert_close(out["scale"].cpu(), scale, rtol=rt, atol=0)
+        assert float(out["elbo"]) == pytest.approx(float(e), rel=rt)
+    c, g, spec, extra = _problem(3, 2000, 640, 2, 2)
+    assert _run(c, g, spec, extra, panel_products=True)["path"] == 1
 
 
 @pytest.mark.parametrize("materialize", [None, True, False])
