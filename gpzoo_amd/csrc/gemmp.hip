@@ -255,15 +255,6 @@ __global__ __launch_bounds__(64 * NB) void panel_kernel(const PanelParams p) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(P + wbase + ni * 16 * PK + mi * 16) = acc[mi][ni];
     }
-    if constexpr (STORE) {                       // retained for the backward pass: 64-byte row segments straight from the registers
-      float* const Wg = p.Wt + ((int64_t)l * Mp + rb * 32) * p.ncp + col0 + r;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) Wg[(int64_t)(mi * 16 + 4 * q + g) * p.ncp + ni * 16] = acc[mi][ni][g];
-    }
     __syncthreads();
     if (tid < 64) {                              // per 128-row block, as the tile kernels write them (finalize_kernel sums the blocks)
 #pragma unroll
@@ -323,6 +314,23 @@ __global__ __launch_bounds__(64 * NB) void panel_kernel(const PanelParams p) {
     } else {                                     // (tells the register allocator that nothing of pv lives through the stages)
 #pragma unroll
       for (int i = 0; i < NR; ++i) pv[i] = f32x4{0, 0, 0, 0};
+    }
+    if constexpr (STORE) {
+      // Wt retained for the backward pass: the same early finishers copy the Wt panel from LDS to memory while the
+      // fetch is in flight -- lane = column (whole 256-byte row segments per store), wave = 64 rows; the 16-byte reads
+      // down a column of the permuted image are conflict-free too
+      if (fetcher) {
+        const int fw = rb - NB / 2;
+        const float* const src = P + lane * PK + fw * 64;
+        const int gs = gperm(lane);
+        float* const dst = p.Wt + ((int64_t)l * Mp + fw * 64) * p.ncp + col0 + lane;
+#pragma unroll 4
+        for (int kk = 0; kk < 64; kk += 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + (kk & ~15) + ((((kk >> 2) & 3) ^ gs) << 2));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[(int64_t)(kk + e) * p.ncp] = v[e];
+        }
+      }
     }
     __syncthreads();                             // ... and every wave is through with the Wt panel
     stamp(7);

@@ -492,13 +492,22 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
   return 0;
 }
 
-// The panel kernel (gemmp.hip) takes both products of an fp32 chunk with Mp <= 512 when the caller asks for it (flags) or
-// the environment does (GPZ_SVGP_PRODUCTS=panel: A/B timing without rebuilding).  Built, bitwise the same Wt, and as fast
-// as the tile kernels at configs[1] -- not faster, so the tile kernels stay the default.
+// The panel kernel (gemmp.hip: both products of an fp32 chunk with Mp <= 512 in one launch) is the library's choice
+// where it is the faster one -- Mp = 256 and 384: -10 % and -15 % against the two tile launches in an evaluation (N=200k,
+// M=256, L=32: 7.93 -> 7.14 ms; N=100k, M=384, L=16: 5.03 -> 4.29 ms), -1 % ... +7 % when Wt has to be written for the
+// backward pass anyway (the choice does not depend on that: a forward pass gives the same bits with and without
+// retention); a tie at Mp = 512, slower at 128 -- and runs wherever it applies when the caller asks
+// for it (GPZ_SVGP_PANEL_PRODUCTS).  Any of the other three flags names a
+// tile path and gets it.  GPZ_SVGP_PRODUCTS=panel|tiles overrides the library's choice (A/B timing without rebuilding).
 static bool panel_path(const gpz_svgp_problem* p, bool f32, int64_t Mp, int64_t ncp) {
-  static const bool env_panel = [] { const char* e = getenv("GPZ_SVGP_PRODUCTS"); return e && !strcmp(e, "panel"); }();
-  return f32 && (env_panel || (p->flags & GPZ_SVGP_PANEL_PRODUCTS)) && !(p->flags & GPZ_SVGP_NARROW_TILES) &&
-         panel_supported(Mp, ncp);
+  static const int env = [] {
+    const char* e = getenv("GPZ_SVGP_PRODUCTS");
+    return !e ? 0 : !strcmp(e, "panel") ? 1 : !strcmp(e, "tiles") ? 2 : 0;
+  }();
+  if (!f32 || !panel_supported(Mp, ncp)) return false;
+  if (p->flags & (GPZ_SVGP_NARROW_TILES | GPZ_SVGP_MATERIALIZE_KZX | GPZ_SVGP_GENERATE_KZX)) return false;
+  if (p->flags & GPZ_SVGP_PANEL_PRODUCTS) return true;
+  return env == 1 || (env == 0 && (Mp == 256 || Mp == 384));
 }
 
 template <typename T>
@@ -527,7 +536,7 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
     const int nt = (int)(ncp / NB);
     const ProductSchedule sched = product_schedule<T>(true, nt);
     const bool wide = !narrow && pl.f32 && wide_product_supported(Mp, ncp);    // fp32: 128 x 256 tiles (gemmw.hip)
-    // fp32, Mp <= 512, on request: both products on one column panel held in LDS (gemmp.hip)
+    // fp32, Mp <= 512, where faster or on request: both products on one column panel held in LDS (gemmp.hip)
     const bool panel = panel_path(p, pl.f32, Mp, ncp) && !fused;
     T* const Wc = p->wt_cache ? wtc.wt(ci) : b.Wc;      // retained for the backward pass when asked for
     T* const ps1 = p->wt_cache ? wtc.ps1(ci) : b.ps1;

@@ -118,9 +118,11 @@ def test_panel_kernel_agrees_with_the_tile_kernels(cfg, N, M, L, whitened):
     spec, extra = spec_for_config(g, torch.device("cuda", 0))
     Mp, ncp = (M + 127) // 128 * 128, (N + 127) // 128 * 128
     nwt = L * Mp * ncp
-    ref = _run(c, g, spec, extra)
+    ref = _run(c, g, spec, extra, materialize_kzx=True)          # names the fill + tile-product path
     out = _run(c, g, spec, extra, panel_products=True)
     assert ref["path"] in (0, 1) and out["path"] == 4
+    # left to itself the library takes the panel kernel where it measured faster: 128 < M <= 384, retained Wt or not
+    assert (_run(c, g, spec, extra)["path"] == 4) == (Mp in (256, 384))
     assert torch.equal(out["wt_cache"].view(torch.int32)[:nwt], ref["wt_cache"].view(torch.int32)[:nwt])
     torch.testing.assert_close(out["mean"], ref["mean"], rtol=1e-5, atol=1e-5 * float(ref["mean"].abs().max()))
     torch.testing.assert_close(out["scale"], ref["scale"], rtol=1e-5, atol=0)
@@ -129,6 +131,9 @@ def test_panel_kernel_agrees_with_the_tile_kernels(cfg, N, M, L, whitened):
     bare = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
                             noise_sd=c["noise_sd"], want_Lu=False, panel_products=True, **extra)
     assert bare["path"] == 4 and "wt_cache" not in bare
+    auto = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
+                            noise_sd=c["noise_sd"], want_Lu=False, **extra)
+    assert (auto["path"] == 4) == (Mp in (256, 384))
     assert torch.equal(bare["mean"], out["mean"]) and torch.equal(bare["scale"], out["scale"])
     assert float(bare["elbo"]) == float(out["elbo"])
 
