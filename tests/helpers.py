@@ -84,3 +84,33 @@ def load_multiblock(name):
     if c["kind"] in ("nsf_rbf", "mggp_nsf_rbf"):     # the NSF kernels keep (L,1,1) parameters
         c["sigma"], c["lengthscale"] = c["sigma"].reshape(-1, 1, 1), c["lengthscale"].reshape(-1, 1, 1)
     return c
+
+
+def to_wire(obj):
+    """Tensors -> numpy arrays (recursively through tuples / lists / dicts) before a multiprocessing queue: a torch CPU
+    tensor is pickled as a file descriptor the SENDER has to serve, and a worker that has exited by the time the parent
+    unpickles its result (it has nothing left to do after its last collective) makes the parent's q.get() raise EOFError
+    now and then.  Arrays travel by value."""
+    import torch
+    if isinstance(obj, torch.Tensor):
+        return ("__tensor__", obj.detach().cpu().numpy().copy())
+    if isinstance(obj, tuple):
+        return tuple(to_wire(o) for o in obj)
+    if isinstance(obj, list):
+        return [to_wire(o) for o in obj]
+    if isinstance(obj, dict):
+        return {k: to_wire(v) for k, v in obj.items()}
+    return obj
+
+
+def from_wire(obj):
+    import torch
+    if isinstance(obj, tuple) and len(obj) == 2 and isinstance(obj[0], str) and obj[0] == "__tensor__":
+        return torch.from_numpy(obj[1])
+    if isinstance(obj, tuple):
+        return tuple(from_wire(o) for o in obj)
+    if isinstance(obj, list):
+        return [from_wire(o) for o in obj]
+    if isinstance(obj, dict):
+        return {k: from_wire(v) for k, v in obj.items()}
+    return obj

@@ -7,6 +7,8 @@ import socket
 import pytest
 import torch
 import torch.distributed as dist
+
+from helpers import from_wire, to_wire
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
@@ -79,7 +81,7 @@ def _train_worker(rank, world, port, L, q):
     m = _model(c, lat, dev)
     _loss(m, c["X"].to(dev), c["y"][lat.start:lat.stop].to(dev)).backward()
     allreduce_shared_grads([m.Z])
-    q.put((lat.start, lat.stop, m.Z.grad.cpu(), m.mu.grad.cpu(), m.kernel.lengthscale.grad.cpu()))
+    q.put(to_wire((lat.start, lat.stop, m.Z.grad.cpu(), m.mu.grad.cpu(), m.kernel.lengthscale.grad.cpu())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -97,7 +99,7 @@ def test_two_rank_training_step_gradients_match_single_process():
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_train_worker, args=(r, 2, port, L, q)) for r in range(2)]
     [p.start() for p in procs]
-    got = [q.get() for _ in range(2)]
+    got = [from_wire(q.get()) for _ in range(2)]
     [p.join(300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     c = make_config(2, N=2000, M=150, L=L, dtype=torch.float64)

@@ -13,6 +13,8 @@ import sys
 import pytest
 import torch
 import torch.distributed as dist
+
+from helpers import from_wire, to_wire
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
@@ -69,7 +71,7 @@ def _worker(rank, world, port, q):
         p = _problem()
         lat, genes = shard_latents(p["L"], world, rank), shard_latents(p["D"], world, rank)
         loss, grads = _step(p, lat, genes, dev)
-        q.put((rank, (lat.start, lat.stop), (genes.start, genes.stop), loss, grads))
+        q.put(to_wire((rank, (lat.start, lat.stop), (genes.start, genes.stop), loss, grads)))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
@@ -98,7 +100,7 @@ def test_two_rank_hip_step_matches_single_process():
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
-    got = [q.get() for _ in range(2)]
+    got = [from_wire(q.get()) for _ in range(2)]
     [p.join(300) for p in procs]
     assert all(g[4] is not None for g in got), [g[3] for g in got if g[4] is None]
     assert all(p.exitcode == 0 for p in procs)

@@ -8,6 +8,8 @@ import sys
 import pytest
 import torch
 import torch.distributed as dist
+
+from helpers import from_wire, to_wire
 import torch.multiprocessing as mp
 
 from gpzoo_amd.synthetic import make_config
@@ -103,7 +105,7 @@ def _grad_worker(rank, world, port, L, q):
     loss = -_oracle_eval(q_)
     loss.backward()
     allreduce_shared_grads([Z])
-    q.put((rank, p["latents"].start, p["latents"].stop, Z.grad.clone(), mu.grad.clone()))
+    q.put(to_wire((rank, p["latents"].start, p["latents"].stop, Z.grad.clone(), mu.grad.clone())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -119,7 +121,7 @@ def test_shared_parameter_gradients_sum_over_latent_shards():
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, L, q)) for r in range(2)]
     [p.start() for p in procs]
-    got = [q.get() for _ in range(2)]
+    got = [from_wire(q.get()) for _ in range(2)]
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     full = make_config(2, N=300, M=40, L=L, dtype=torch.float64)
@@ -141,7 +143,7 @@ def _missing_grad_worker(rank, world, port, q):
     loss = (a * (rank + 1.0)).sum() + ((b * 3.0).sum() if rank == 0 else 0.0)
     loss.backward()
     allreduce_shared_grads([a, None, b])
-    q.put((rank, a.grad.clone(), b.grad.clone()))
+    q.put(to_wire((rank, a.grad.clone(), b.grad.clone())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -157,7 +159,7 @@ def test_shared_gradient_exchange_with_a_parameter_unused_on_one_rank():
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_missing_grad_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
-    got = [q.get() for _ in range(2)]
+    got = [from_wire(q.get()) for _ in range(2)]
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     for rank, ga, gb in got:
@@ -234,8 +236,8 @@ def _nsf_worker_body(rank, world, port, q):
     V = torch.nn.Parameter(p["V"].clone())
     loss = sharded_nsf_step(gp, p["X"], W, V, p["y"][genes.start:genes.stop], p["eps"], p["L"],
                             local=_torch_local_poisson, shared_params=[gp.Z])
-    q.put((rank, (lat.start, lat.stop), (genes.start, genes.stop), float(loss),
-           {k: v.grad.clone() for k, v in dict(Z=gp.Z, lengthscale=gp.lengthscale, mu=gp.mu, Lu=gp.Lu, W=W, V=V).items()}))
+    q.put(to_wire((rank, (lat.start, lat.stop), (genes.start, genes.stop), float(loss),
+                   {k: v.grad.clone() for k, v in dict(Z=gp.Z, lengthscale=gp.lengthscale, mu=gp.mu, Lu=gp.Lu, W=W, V=V).items()})))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -251,7 +253,7 @@ def test_latent_sharded_poisson_nsf_step_matches_single_process():
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_nsf_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
-    got = [q.get() for _ in range(2)]
+    got = [from_wire(q.get()) for _ in range(2)]
     [p.join(180) for p in procs]
     assert all(g[4] is not None for g in got), [g[3] for g in got if g[4] is None]
     assert all(p.exitcode == 0 for p in procs)
