@@ -10,9 +10,11 @@ clk = r.get("clocks") or {}
 fac = ("factor (Cholesky + inverse, one launch) %.3f ms = %.1f TF fp64" % (k["factor"]["ms_per_eval"], k["factor"]["achieved_TFLOPs"])
        if "factor" in k else "potrf %.2f ms (trailing %.1f TF) | trtri %.2f ms" % (
            k["potrf_ms_per_eval"], k["potrf_trailing"]["achieved_TFLOPs"], k["trtri_ms_per_eval"]))
-print("  value %.4f %s | %.2f ms/step | stage1 %.1f TF (frac %.3f; sclk %.0f MHz: frac at that clock %.3f) | stage2 %.1f TF | kfill %.0f GB/s | %s%s" % (
-    r["value"], r["unit"], r["ms_per_step"], r["roofline"]["achieved"], r["roofline"]["frac"], clk.get("sclk_MHz_mean", 0.0),
-    r["roofline"].get("frac_at_sampled_clock", 0.0), k["stage2_LuT_Wt"]["achieved_TFLOPs"],
+panel = r["roofline"]["kernel"].startswith("panel_kernel")
+print("  value %.4f %s | %.2f ms/step | %s %.1f TF (frac %.3f; sclk %.0f MHz: frac at that clock %.3f) | %s %.1f TF | kfill %.0f GB/s | %s%s" % (
+    r["value"], r["unit"], r["ms_per_step"], "both products (one launch)" if panel else "stage1", r["roofline"]["achieved"], r["roofline"]["frac"],
+    clk.get("sclk_MHz_mean", 0.0), r["roofline"].get("frac_at_sampled_clock", 0.0), "(stage2: same launch)" if panel else "stage2",
+    k["stage2_LuT_Wt"]["achieved_TFLOPs"],
     k["kuf_fill"]["achieved_GBps"], fac,
     (" | fwd+bwd %s ms" % {a: round(b, 1) for a, b in r["forward_backward_ms"].items()}) if "forward_backward_ms" in r else ""))
 PY
@@ -21,6 +23,11 @@ echo "== config 3 (default): N=200k M=2048 L=32 Matern-3/2 fp32, with forward+ba
 python3 bench.py --no-cpu-baseline --with-backward > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 2: N=50k M=512 L=8 RBF fp32"
 python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== config 2 with the panel kernel (--panel-products: both products in one launch, reported as stage 1 over 2x the flops)"
+python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline --panel-products > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== N=200k M=256 L=32 Matern-3/2 fp32: the panel kernel is the library's choice (128 < M <= 384); then the tile kernels (GPZ_SVGP_PRODUCTS=tiles)"
+python3 bench.py --N 200000 --M 256 --L 32 --steps 8 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+GPZ_SVGP_PRODUCTS=tiles python3 bench.py --N 200000 --M 256 --L 32 --steps 8 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 5: MGGP 4 groups, N=200k M=2048 fp64, L=32 on one GPU"
 python3 bench.py --config 5 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 5 as sharded over 8 GPUs: 4 latents per GPU"

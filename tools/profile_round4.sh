@@ -2,7 +2,8 @@
 # Round-4 profile run on the GPU box (through gpurun):  bash tools/profile_round4.sh r04
 #   * default bench command (config 3): kernel-trace stats + the separate PMC passes (as tools/profile_round.sh)
 #   * kernel-trace stats of the other measured paths: forward + backward at config 3, the Poisson NSF step,
-#     configs[4] as one rank of eight holds it (fp64, L = 4), configs[1]
+#     configs[4] as one rank of eight holds it (fp64, L = 4), configs[1]; the panel kernel (csrc/gemmp.hip) at M = 256
+#     (where the library takes it) and at configs[1] (on request)
 # Under rocprofv3 the program itself follows `--` (python3 ...): no env / bash -c hop.
 set -e
 tag=${1:-r04}
@@ -26,5 +27,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_poisson20 -- 
 echo "poisson traces done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg5 -- python3 bench.py --config 5 --L 4 --steps 2 --warmup 1 --no-cpu-baseline > $out/trace_cfg5.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2 -- python3 bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline > $out/trace_cfg2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_m256 -- python3 bench.py --N 200000 --M 256 --L 32 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_m256.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2panel -- python3 bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline --panel-products > $out/trace_cfg2panel.log 2>&1
 echo "config traces done"
 ls $out

@@ -80,5 +80,25 @@ for tag, what in (("cfg5", "configs[4] as one of eight ranks holds it: MGGP, N=2
           f"factor {k['potrf_ms_per_eval']:.3f} ms ({k.get('factor', {}).get('achieved_TFLOPs', 0):.1f} TF fp64)")
     for name, calls, avg, tot in sorted(rows(st, lambda n: "gpz::" in n), key=lambda r: -r[3])[:8]:
         P(f"  {name[:78]:78s} {calls:5d} calls  avg {avg:8.3f} ms  total {tot:9.1f} ms")
+# ---- the panel kernel: both products in one launch ----
+for tag, what, Lp, Mq, Nq in (("m256", "N=200000, M=256, L=32, Matern-3/2, fp32: the library's own choice", 32, 256, 200000),
+                              ("cfg2panel", "configs[1] with --panel-products: N=50000, M=512, L=8, RBF, fp32", 8, 512, 50000)):
+    if not glob.glob(f"{src}/trace_{tag}/*/*_kernel_stats.csv"):
+        continue
+    st = stats(tag)
+    b = jline(tag)
+    P(f"== panel kernel (csrc/gemmp.hip), {what}")
+    if b:
+        P(f"  {b['ms_per_step']:.2f} ms per evaluation | {b['roofline']['kernel'][:60]}: {b['roofline']['achieved']:.1f} TF over BOTH products "
+          f"= {b['roofline']['frac']:.3f} of {b['roofline']['peak']} | fill {b['kernels']['kuf_fill']['achieved_GBps']:.0f} GB/s")
+    for name, calls, avg, tot in sorted(rows(st, lambda n: "gpz::" in n), key=lambda r: -r[3])[:5]:
+        P(f"  {name[:78]:78s} {calls:5d} calls  avg {avg:8.3f} ms  total {tot:9.1f} ms")
+    pk = rows(st, lambda n: "panel_kernel" in n)
+    ev = rows(st, lambda n: "coop_factor_kernel" in n)          # one factorisation per evaluation
+    if pk and ev:
+        fl = 2.0 * Lp * float(Mq) * Mq * Nq     # two triangular products of L M^2 N flops per evaluation
+        per_eval = pk[0][3] / ev[0][1]          # ms of panel_kernel launches per evaluation (one launch per chunk of columns)
+        P(f"  panel_kernel: {pk[0][1] // ev[0][1]} launch(es) = {per_eval:.3f} ms per evaluation for {fl / 1e9:.1f} Gflop -> "
+          f"{fl / per_eval / 1e9:.1f} TF = {fl / per_eval / 1e9 / PEAK32:.3f}  (the wall time per evaluation above is under the profiler)")
 open(f"{dst}/other_paths.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
