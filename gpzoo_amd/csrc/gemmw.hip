@@ -46,8 +46,7 @@
 
 // Timing-only diagnostics (WRONG results by construction; tools/ablate_fused.sh builds them next to the real library):
 // -DGPZ_W_ABL=<bits>  1: no covariance arithmetic (the generated B tile holds a coordinate), 2: no tile loads after the
-// first, 4: no epilogue (statistics, Wt store), 8: no per-step barrier, 16: tile loads issued but never waited for,
-// 32: every column tile reads one of two B panels of its latent (no B traffic beyond L2).
+// first, 4: no epilogue (statistics, Wt store), 8: no per-step barrier, 16: tile loads issued but never waited for.
 #ifndef GPZ_W_ABL
 #define GPZ_W_ABL 0
 #endif
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
       while (row >= Mp) row -= 128;             // rows past the matrix: re-read valid ones (their waves are inactive)
       a_soff[h] = (row * (int)p.lda + kb) * (int)sizeof(float);
     }
-    b_soff = ((kb + RPP * wave) * (int)p.ldb + ((GPZ_W_ABL & 32) ? (tj & 1) : tj) * TN) * (int)sizeof(float);   // ABL 32: every column tile reads one of two B panels (L2-resident: what the B traffic costs)
+    b_soff = ((kb + RPP * wave) * (int)p.ldb + tj * TN) * (int)sizeof(float);
     stage_load(0);
   };
 
