@@ -436,8 +436,10 @@ def main():
         tr_tf = (trailing_flops(Mp // 128) * Lper * a.steps / (prof["potrf_trailing"][0] * 1e-3) / 1e12
                  if prof["potrf_trailing"][0] > 0 else 0.0)
         sub = {
-            "kuf_fill": {"bound": "hbm", "achieved_GBps": kgbs, "peak_GBps": HBM_PEAK, "frac": kgbs / HBM_PEAK,
-                         "ms_per_eval": kms / a.steps},
+            "kuf_fill": ({"bound": "hbm", "achieved_GBps": kgbs, "peak_GBps": HBM_PEAK, "frac": kgbs / HBM_PEAK,
+                          "ms_per_eval": kms / a.steps} if kn > 0 else
+                         {"bound": "hbm", "achieved_GBps": None, "peak_GBps": HBM_PEAK, "frac": None, "ms_per_eval": 0.0,
+                          "note": "no fill launch: panel_kernel computes its covariance panel itself and Kzx is never written"}),
             # (panel kernel: the second product runs inside the launch counted as stage 1 -- its rate is that launch's, over both)
             "stage2_LuT_Wt": ({"bound": "mfma", "achieved_TFLOPs": ach1, "peak_TFLOPs": PEAK[dname], "ms_per_eval": 0.0,
                                "note": "inside panel_kernel with the first product: achieved_TFLOPs is the launch's rate over both"}
@@ -473,7 +475,7 @@ def main():
                 sub["potrf_whole_TFLOPs"] = potrf_flops * a.steps / (prof["potrf_all"][0] * 1e-3) / 1e12
         if mp:   # fractions of the rates measured on the box (tools/peaks.sh), next to the spec / datasheet ones
             sub["measured_peaks"] = {k: v for k, v in mp.items() if k != "how"}
-            if mp.get("hbm_write_GBps"):
+            if mp.get("hbm_write_GBps") and kn > 0:
                 sub["kuf_fill"]["frac_of_measured_write_rate"] = kgbs / mp["hbm_write_GBps"]
             if mp.get("mfma_f64_TFLOPs") and "potrf_trailing" in sub:
                 sub["potrf_trailing"]["frac_of_measured_peak"] = tr_tf / mp["mfma_f64_TFLOPs"]

@@ -22,6 +22,8 @@
 // chunk, chunks ascending from k = 0, zero sub-tiles of the diagonal block skipped): the retained Wt is bitwise the same.
 #include "gemmp.h"
 
+#include "cov.h"
+
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -40,7 +42,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct PanelParams {
   const float* Linv; const float* LuT;      // (L, Mp, Mp)
-  const float* Kzx;                         // (L, Mp, ncp)
+  const float* Kzx;                         // (L, Mp, ncp); GEN: unused
+  const float* Z; const float* X;           // GEN: (M, D) inducing points, (nreal, D) this chunk's spots
+  const float* sigma; const float* ell;     // GEN: (L,)
+  int M, nreal;                             // GEN: real rows / columns (the rest of the panel is zero, as the fill writes it)
   float* Wt;                                // (L, Mp, ncp) or null
   const float* muE;                         // (L, Mp)
   float* ps1; float* pm1; float* ps2;       // [L][Mp / 128][ncp]
@@ -60,7 +65,10 @@ template <int NB> __device__ __forceinline__ int row_block_of(int w) {
   else return w;
 }
 
-template <int NB, bool STORE>
+// GEN: 0 the Kzx panel is read from memory (the stand-alone fill wrote it); 1 + 2 * KIND + (D - 1): the fetching waves
+// compute it themselves (cov.h: the fill's own arithmetic, same bits) -- fp32 RBF (KIND 0) / Matern-3/2 (KIND 1) on 1-D / 2-D
+// inputs -- and Kzx never exists.
+template <int NB, bool STORE, int GEN>
 __global__ __launch_bounds__(64 * NB) void panel_kernel(const PanelParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // Panel image: column c at c * PK, k contiguous, the four 16-byte slots of every 16-deep chunk XOR-permuted by column
@@ -113,14 +121,45 @@ __global__ __launch_bounds__(64 * NB) void panel_kernel(const PanelParams p) {
   const int ft = (rb - NB / 2) * 64 + lane;
   const int pc4 = ft & 15, pk_of = ft >> 4;
   auto panel_fetch = [&](int l, int64_t col0) __attribute__((always_inline)) {
+    if constexpr (GEN == 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.Kzx + (int64_t)l * Mp * p.ncp + col0), 0, (Mp - 1) * p.ncp * 4 + P_TN * 4, 0x00020000);
-    const int voff = (pk_of * p.ncp + 4 * pc4) * 4, sstep = RP * p.ncp * 4;
+      const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.Kzx + (int64_t)l * Mp * p.ncp + col0), 0, (Mp - 1) * p.ncp * 4 + P_TN * 4, 0x00020000);
+      const int voff = (pk_of * p.ncp + 4 * pc4) * 4, sstep = RP * p.ncp * 4;
 #pragma unroll
-    for (int i = 0; i < NR; ++i)
-      pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kr, voff, i * sstep, 0));
+      for (int i = 0; i < NR; ++i)
+        pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kr, voff, i * sstep, 0));
 #endif
+    } else {
+      // the thread's four columns (spots) stay in registers for its sixteen k rows (inducing points); padded rows and
+      // columns are exactly zero, as the stand-alone fill writes them
+      constexpr int KIND = (GEN - 1) >> 1, D = ((GEN - 1) & 1) + 1;
+      const CovConst cc = cov_const<KIND>(p.sigma[l], p.ell[l]);
+      float xc[4][D];
+      bool real[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t n = col0 + 4 * pc4 + e;
+        real[e] = n < p.nreal;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xc[e][k] = real[e] ? p.X[n * D + k] : 0.f;
+      }
+      int kof = pk_of;
+      asm volatile("" : "+v"(kof));              // per panel: the sixteen inducing points are NOT to be kept in registers across panels
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int k = i * RP + kof;
+        const bool row = k < p.M;
+        float z[D];
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) z[kk] = row ? p.Z[k * D + kk] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = cov_value<KIND>(cov_radial<KIND>(cov_d2<D>(z, xc[e])), cc.amp, cc.c0, cc.c1);
+          pv[i][e] = (row && real[e]) ? v : 0.f;
+        }
+      }
+    }
   };
   auto panel_write = [&]() __attribute__((always_inline)) {
     int kof = pk_of;
@@ -351,20 +390,24 @@ __global__ __launch_bounds__(64 * NB) void panel_kernel(const PanelParams p) {
 
 static unsigned long long* g_panel_stamps = nullptr;
 
+bool panel_generates(int kind, int d) {
+  return (kind == GPZ_KERNEL_RBF || kind == GPZ_KERNEL_MATERN32) && (d == 1 || d == 2);
+}
+
 bool panel_supported(int64_t Mp, int64_t ncp) {
   return Mp >= 128 && Mp <= 512 && Mp % 128 == 0 && ncp % P_TN == 0 && Mp * ncp * 4 < (1ll << 31);
 }
 
-template <int NB>
+template <int NB, int GEN>
 static int launch_t(const PanelParams& p, bool store, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)P_TN * (p.Mp + 16) + 3 * NB * 64);
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [&] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, false>),
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, false, GEN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr_rc == hipSuccess)
-      attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, true>),
+      attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, true, GEN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   GPZ_HIP_OK(attr_rc);
@@ -378,15 +421,15 @@ static int launch_t(const PanelParams& p, bool store, hipStream_t s) {
   }
   int wgs = cus * (per_cu > 2 ? 2 : per_cu);
   wgs -= wgs % 8;
-  if (store) hipLaunchKernelGGL((panel_kernel<NB, true>), dim3(wgs), dim3(64 * NB), lds, s, p);
-  else hipLaunchKernelGGL((panel_kernel<NB, false>), dim3(wgs), dim3(64 * NB), lds, s, p);
+  if (store) hipLaunchKernelGGL((panel_kernel<NB, true, GEN>), dim3(wgs), dim3(64 * NB), lds, s, p);
+  else hipLaunchKernelGGL((panel_kernel<NB, false, GEN>), dim3(wgs), dim3(64 * NB), lds, s, p);
   GPZ_LAUNCH_OK();
   return 0;
 }
 
 int panel_launch(const PanelArgs& a, hipStream_t s) {
   GPZ_REQUIRE(panel_supported(a.Mp, a.ncp), "panel_launch: unsupported shape Mp=%lld ncp=%lld", (long long)a.Mp, (long long)a.ncp);
-  PanelParams p;
+  PanelParams p = {};
   p.Linv = a.Linv; p.LuT = a.LuT; p.Kzx = a.Kzx; p.Wt = a.Wt; p.muE = a.muE;
   p.ps1 = a.ps1; p.pm1 = a.pm1; p.ps2 = a.ps2;
   p.stamps = g_panel_stamps;
@@ -394,12 +437,32 @@ int panel_launch(const PanelArgs& a, hipStream_t s) {
   p.dbg = dbg;
   p.Mp = (int)a.Mp; p.ncp = (int)a.ncp; p.L = a.L; p.npan = (int)(a.ncp / P_TN); p.units = a.L * p.npan;
   const bool store = a.Wt != nullptr;
-  switch (a.Mp / 32) {
-    case 4: return launch_t<4>(p, store, s);
-    case 8: return launch_t<8>(p, store, s);
-    case 12: return launch_t<12>(p, store, s);
-    default: return launch_t<16>(p, store, s);
+  int gen = 0;
+  if (a.Z) {       // generated operand
+    GPZ_REQUIRE(panel_generates(a.kind, a.d) && a.X && a.sigma && a.ell && a.M >= 1 && a.M <= a.Mp && a.nreal >= 1 && a.nreal <= a.ncp,
+                "panel_launch: bad generator arguments (kind=%d d=%d)", a.kind, a.d);
+    gen = 1 + 2 * (a.kind == GPZ_KERNEL_MATERN32 ? 1 : 0) + (a.d - 1);
+    p.Z = a.Z; p.X = a.X; p.sigma = a.sigma; p.ell = a.ell; p.M = (int)a.M; p.nreal = (int)a.nreal;
+  } else {
+    GPZ_REQUIRE(a.Kzx, "panel_launch: neither a Kzx buffer nor generator arguments");
   }
+#define GPZ_PANEL_CASE(NBV)                                  \
+  case NBV:                                                  \
+    switch (gen) {                                           \
+      case 1: return launch_t<NBV, 1>(p, store, s);          \
+      case 2: return launch_t<NBV, 2>(p, store, s);          \
+      case 3: return launch_t<NBV, 3>(p, store, s);          \
+      case 4: return launch_t<NBV, 4>(p, store, s);          \
+      default: return launch_t<NBV, 0>(p, store, s);         \
+    }
+  switch (a.Mp / 32) {
+    GPZ_PANEL_CASE(4)
+    GPZ_PANEL_CASE(8)
+    GPZ_PANEL_CASE(12)
+    default:
+    GPZ_PANEL_CASE(16)
+  }
+#undef GPZ_PANEL_CASE
 }
 
 }  // namespace gpz

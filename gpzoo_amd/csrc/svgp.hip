@@ -493,12 +493,15 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
 }
 
 // The panel kernel (gemmp.hip: both products of an fp32 chunk with Mp <= 512 in one launch) is the library's choice
-// where it is the faster one -- Mp = 256 and 384: -10 % and -15 % against the two tile launches in an evaluation (N=200k,
-// M=256, L=32: 7.93 -> 7.14 ms; N=100k, M=384, L=16: 5.03 -> 4.29 ms), -1 % ... +7 % when Wt has to be written for the
-// backward pass anyway (the choice does not depend on that: a forward pass gives the same bits with and without
-// retention); a tie at Mp = 512, slower at 128 -- and runs wherever it applies when the caller asks
-// for it (GPZ_SVGP_PANEL_PRODUCTS).  Any of the other three flags names a
-// tile path and gets it.  GPZ_SVGP_PRODUCTS=panel|tiles overrides the library's choice (A/B timing without rebuilding).
+// where it is the faster one (evaluations, same box, two tile launches + fill -> panel kernel):
+//   * wherever it computes its covariance panel itself (cov.h: RBF / Matern-3/2 on 1-D / 2-D inputs) -- no fill launch, no
+//     Kzx: configs[1] (M=512) 2.36 -> 2.27 ms, N=200k M=256 L=32 9.47 -> 8.11 ms, N=100k M=384 L=16 5.71 -> 4.80 ms,
+//     N=60k M=128 L=32 1.28 -> 1.22 ms; with Wt retained for the backward pass 2.36 -> 2.26, 9.48 -> 8.63, 5.69 -> 5.13 ms;
+//   * with the fill's Kzx as its operand (the other kernel families) for Mp = 256 and 384 only (-10 % / -15 %; a tie at 512,
+//     slower at 128).
+// The choice does not depend on whether Wt is retained: a forward pass gives the same bits either way.  Any of the other
+// three flags names a tile path and gets it; GPZ_SVGP_PANEL_PRODUCTS runs the panel kernel wherever it applies;
+// GPZ_SVGP_PRODUCTS=panel|tiles overrides the library's choice (A/B timing without rebuilding).
 static bool panel_path(const gpz_svgp_problem* p, bool f32, int64_t Mp, int64_t ncp) {
   static const int env = [] {
     const char* e = getenv("GPZ_SVGP_PRODUCTS");
@@ -507,7 +510,7 @@ static bool panel_path(const gpz_svgp_problem* p, bool f32, int64_t Mp, int64_t 
   if (!f32 || !panel_supported(Mp, ncp)) return false;
   if (p->flags & (GPZ_SVGP_NARROW_TILES | GPZ_SVGP_MATERIALIZE_KZX | GPZ_SVGP_GENERATE_KZX)) return false;
   if (p->flags & GPZ_SVGP_PANEL_PRODUCTS) return true;
-  return env == 1 || (env == 0 && (Mp == 256 || Mp == 384));
+  return env == 1 || (env == 0 && (panel_generates(p->k.kind, p->d) || Mp == 256 || Mp == 384));
 }
 
 template <typename T>
@@ -553,18 +556,30 @@ static int svgp_forward_t(const gpz_svgp_problem* p, int64_t chunk, void* ws, si
         prof_end(PROF_STAGE1, s);
       }
     } else {
-      prof_begin(PROF_KFILL, s);
-      if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
-                                p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
-                                pl.f32 ? GPZ_F32 : GPZ_F64, s, p->info))
-        return rc;
-      prof_end(PROF_KFILL, s);
+      // (the panel kernel computes its covariance panel itself where cov.h covers the kernel: no fill, no Kzx)
+      static const bool env_panel_fill = [] { const char* e = getenv("GPZ_PANEL_FILL"); return e && !strcmp(e, "1"); }();
+      const bool panel_gen = panel && pl.f32 && panel_generates(p->k.kind, p->d) && !env_panel_fill;
+      if (!panel_gen) {
+        prof_begin(PROF_KFILL, s);
+        if (int rc = kfill_padded(&p->k, p->Z, M, Mp, static_cast<const char*>(p->X) + n0 * p->d * esz, nreal, ncp, p->d,
+                                  p->gZ, p->gX ? p->gX + n0 : nullptr, b.Kc, ncp, Mp * ncp, 0.0, 0,
+                                  pl.f32 ? GPZ_F32 : GPZ_F64, s, p->info))
+          return rc;
+        prof_end(PROF_KFILL, s);
+      }
       prof_begin(PROF_STAGE1, s);
       bool done = false;
       if constexpr (sizeof(T) == 4) {
         if (panel) {     // Wt = Linv * Kzx, its column statistics AND stage 2's, panel by panel; Wt stored only when retained
-          PanelArgs pa;
-          pa.Linv = b.LinvG; pa.LuT = b.LuT; pa.Kzx = b.Kc; pa.Wt = p->wt_cache ? Wc : nullptr; pa.muE = b.muE;
+          PanelArgs pa = {};
+          pa.Linv = b.LinvG; pa.LuT = b.LuT; pa.Wt = p->wt_cache ? Wc : nullptr; pa.muE = b.muE;
+          if (panel_gen) {
+            pa.Z = static_cast<const float*>(p->Z); pa.X = static_cast<const float*>(p->X) + n0 * p->d;
+            pa.sigma = static_cast<const float*>(p->k.sigma); pa.ell = static_cast<const float*>(p->k.lengthscale);
+            pa.M = M; pa.nreal = nreal; pa.kind = p->k.kind; pa.d = p->d;
+          } else {
+            pa.Kzx = b.Kc;
+          }
           pa.ps1 = ps1; pa.pm1 = b.pm1; pa.ps2 = b.ps2; pa.Mp = Mp; pa.ncp = ncp; pa.L = L32;
           if (int rc = panel_launch(pa, s)) return rc;
           done = true;

@@ -125,8 +125,8 @@ int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_l, void* B,
  * match).  Kzz, its Cholesky factor and inverse are carried in fp64 in both modes.
  */
 /* gpz_svgp_problem.flags: which kernels the forward pass takes for its two big fp32 products (results agree bit for
- * bit in Wt on every path; 0 = the library's choice: the fill + wide-tile products, except 128 < M <= 384, where the panel
- * kernel is the faster one) */
+ * bit in Wt on every path; 0 = the library's choice: the fill + wide-tile products for M > 512, the panel kernel for
+ * M <= 512 where it is the faster one -- see GPZ_SVGP_PANEL_PRODUCTS) */
 #define GPZ_SVGP_MATERIALIZE_KZX 1  /* write every Kzx chunk to HBM with the stand-alone fill and run the triangular
                                      * product on it -- the reference's structure, gp.py:255 + :276 */
 #define GPZ_SVGP_NARROW_TILES 2     /* the 128 x 128-tile kernel every other precision uses (csrc/gemm.hip) instead of
@@ -134,10 +134,13 @@ int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_l, void* B,
 #define GPZ_SVGP_GENERATE_KZX 4     /* fp32 RBF / Matern-3/2, d <= 2: stage 1 generates its covariance operand inside the
                                      * product (csrc/gemmw.hip) and Kzx is never written */
 #define GPZ_SVGP_PANEL_PRODUCTS 8   /* fp32, M <= 512: both products panel by panel in ONE launch (csrc/gemmp.hip): a workgroup
-                                     * holds 64 columns x all rows in LDS from Kzx to the column statistics; Wt reaches
-                                     * memory only when retained.  Same Wt bits; mean / scale differ from the tile path
-                                     * by fp32 rounding (other summation order of the statistics).  The library's own
-                                     * choice for 128 < M <= 384; with this flag wherever it applies, ignored elsewhere
+                                     * holds 64 columns x all rows in LDS from the covariance to the column statistics.
+                                     * RBF / Matern-3/2 on <= 2-D inputs: the panel is computed inside the kernel and Kzx
+                                     * never exists; other kernel families: it is read from the stand-alone fill's Kzx.
+                                     * Wt reaches memory only when retained.  Same Wt bits; mean / scale differ from the
+                                     * tile path by fp32 rounding (other summation order of the statistics).  The
+                                     * library's own choice (flags == 0) in the first case for every M <= 512 and in the
+                                     * second for 128 < M <= 384; with this flag wherever it applies; ignored elsewhere
                                      * and next to any of the three flags above. */
 
 typedef struct gpz_svgp_problem {

@@ -92,28 +92,35 @@ def test_wide_tiles_agree_with_narrow_tiles_on_random_shapes(N, M, L):
 
 
 PANEL_SHAPES = [
-    # cfg, N, M, L, whitened
-    (2, 50000, 512, 8, True),        # configs[1] itself: 16 waves, one latent per XCD
-    (2, 20000, 512, 3, True),        # fewer latents than XCDs: an XCD's range of panels spans two latents
-    (3, 5000, 500, 5, True),         # Mp = 512 with padded rows; Matern-3/2; ragged last panel (N not a multiple of 64)
-    (3, 2000, 384, 3, True),         # 12 row blocks (three waves per SIMD)
-    (2, 9000, 256, 11, True),        # 8 row blocks, two workgroups per CU
-    (3, 777, 100, 2, True),          # 4 row blocks: a single 128-block
-    (3, 3000, 300, 4, False),        # un-whitened SVGP: LuE = Linv Lu, clamp
-    (2, 64, 40, 1, True),            # one panel in all
+    # cfg, N, M, L, whitened, d
+    (2, 50000, 512, 8, True, 2),        # configs[1] itself: 16 waves, one latent per XCD
+    (2, 20000, 512, 3, True, 2),        # fewer latents than XCDs: an XCD's range of panels spans two latents
+    (3, 5000, 500, 5, True, 2),         # Mp = 512 with padded rows; Matern-3/2; ragged last panel (N not a multiple of 64)
+    (3, 2000, 384, 3, True, 2),         # 12 row blocks (three waves per SIMD)
+    (2, 9000, 256, 11, True, 2),        # 8 row blocks, two workgroups per CU
+    (3, 777, 100, 2, True, 2),          # 4 row blocks: a single 128-block
+    (3, 3000, 300, 4, False, 2),        # un-whitened SVGP: LuE = Linv Lu, clamp
+    (2, 64, 40, 1, True, 2),            # one panel in all
+    (2, 4000, 200, 3, True, 1),         # 1-D inputs (RBF)
+    (3, 4000, 333, 3, True, 1),         # 1-D inputs (Matern-3/2)
+    (5, 6000, 300, 3, True, 2),         # multi-group RBF in fp32: cov.h does not cover it, the panel is read from the fill's Kzx
 ]
 
 
-@pytest.mark.parametrize("cfg,N,M,L,whitened", PANEL_SHAPES)
-def test_panel_kernel_agrees_with_the_tile_kernels(cfg, N, M, L, whitened):
-    """The one-launch panel path (GPZ_SVGP_PANEL_PRODUCTS): the library reports it took it, the retained Wt is bit for bit
-    the tile kernels', mean / scale / ELBO agree to fp32 rounding (its column statistics are summed wave by wave), and
-    without retention (the evaluation path: Wt never reaches memory) the moments are the same bits as with it."""
+@pytest.mark.parametrize("cfg,N,M,L,whitened,d", PANEL_SHAPES)
+def test_panel_kernel_agrees_with_the_tile_kernels(cfg, N, M, L, whitened, d):
+    """The one-launch panel path (GPZ_SVGP_PANEL_PRODUCTS; its covariance panel computed inside the kernel where cov.h
+    covers the kernel family, read from the stand-alone fill's Kzx otherwise): the library reports it took it, the
+    retained Wt is bit for bit the tile kernels', mean / scale / ELBO agree to fp32 rounding (its column statistics are
+    summed wave by wave), and without retention (the evaluation path: Wt never reaches memory) the moments are the same
+    bits as with it."""
     from gpzoo_amd import ops
     from gpzoo_amd.configs import spec_for_config
     from gpzoo_amd.synthetic import make_config
-    c = make_config(cfg, N=N, M=M, L=L)
+    c = make_config(cfg, N=N, M=M, L=L, dtype=torch.float32)
     c["whitened"] = whitened
+    if d == 1:
+        c["X"], c["Z"] = c["X"][:, :1].contiguous(), c["Z"][:, :1].contiguous()
     g = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
     spec, extra = spec_for_config(g, torch.device("cuda", 0))
     Mp, ncp = (M + 127) // 128 * 128, (N + 127) // 128 * 128
@@ -121,8 +128,10 @@ def test_panel_kernel_agrees_with_the_tile_kernels(cfg, N, M, L, whitened):
     ref = _run(c, g, spec, extra, materialize_kzx=True)          # names the fill + tile-product path
     out = _run(c, g, spec, extra, panel_products=True)
     assert ref["path"] in (0, 1) and out["path"] == 4
-    # left to itself the library takes the panel kernel where it measured faster: 128 < M <= 384, retained Wt or not
-    assert (_run(c, g, spec, extra)["path"] == 4) == (Mp in (256, 384))
+    # left to itself the library takes the panel kernel where it measured faster -- wherever it computes the covariance
+    # itself (RBF / Matern-3/2), else for 128 < M <= 384 -- retained Wt or not
+    own_choice = cfg in (2, 3) or Mp in (256, 384)
+    assert (_run(c, g, spec, extra)["path"] == 4) == own_choice
     assert torch.equal(out["wt_cache"].view(torch.int32)[:nwt], ref["wt_cache"].view(torch.int32)[:nwt])
     torch.testing.assert_close(out["mean"], ref["mean"], rtol=1e-5, atol=1e-5 * float(ref["mean"].abs().max()))
     torch.testing.assert_close(out["scale"], ref["scale"], rtol=1e-5, atol=0)
@@ -133,7 +142,7 @@ def test_panel_kernel_agrees_with_the_tile_kernels(cfg, N, M, L, whitened):
     assert bare["path"] == 4 and "wt_cache" not in bare
     auto = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
                             noise_sd=c["noise_sd"], want_Lu=False, **extra)
-    assert (auto["path"] == 4) == (Mp in (256, 384))
+    assert (auto["path"] == 4) == own_choice
     assert torch.equal(bare["mean"], out["mean"]) and torch.equal(bare["scale"], out["scale"])
     assert float(bare["elbo"]) == float(out["elbo"])
 

@@ -15,7 +15,7 @@ print("  value %.4f %s | %.2f ms/step | %s %.1f TF (frac %.3f; sclk %.0f MHz: fr
     r["value"], r["unit"], r["ms_per_step"], "both products (one launch)" if panel else "stage1", r["roofline"]["achieved"], r["roofline"]["frac"],
     clk.get("sclk_MHz_mean", 0.0), r["roofline"].get("frac_at_sampled_clock", 0.0), "(stage2: same launch)" if panel else "stage2",
     k["stage2_LuT_Wt"]["achieved_TFLOPs"],
-    k["kuf_fill"]["achieved_GBps"], fac,
+    k["kuf_fill"]["achieved_GBps"] or 0.0, fac,
     (" | fwd+bwd %s ms" % {a: round(b, 1) for a, b in r["forward_backward_ms"].items()}) if "forward_backward_ms" in r else ""))
 PY
 }
@@ -23,9 +23,9 @@ echo "== config 3 (default): N=200k M=2048 L=32 Matern-3/2 fp32, with forward+ba
 python3 bench.py --no-cpu-baseline --with-backward > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 2: N=50k M=512 L=8 RBF fp32"
 python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
-echo "== config 2 with the panel kernel (--panel-products: both products in one launch, reported as stage 1 over 2x the flops)"
-python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline --panel-products > /tmp/b.log 2>/dev/null; one /tmp/b.log
-echo "== N=200k M=256 L=32 Matern-3/2 fp32: the panel kernel is the library's choice (128 < M <= 384); then the tile kernels (GPZ_SVGP_PRODUCTS=tiles)"
+echo "== config 2 on the fill + tile kernels (GPZ_SVGP_PRODUCTS=tiles; the line above is the panel kernel: fill and both products in one launch, kfill 0)"
+GPZ_SVGP_PRODUCTS=tiles python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== N=200k M=256 L=32 Matern-3/2 fp32: the panel kernel (the library's choice for M <= 512); then the tile kernels (GPZ_SVGP_PRODUCTS=tiles)"
 python3 bench.py --N 200000 --M 256 --L 32 --steps 8 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
 GPZ_SVGP_PRODUCTS=tiles python3 bench.py --N 200000 --M 256 --L 32 --steps 8 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 5: MGGP 4 groups, N=200k M=2048 fp64, L=32 on one GPU"

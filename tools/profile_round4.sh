@@ -28,6 +28,6 @@ echo "poisson traces done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg5 -- python3 bench.py --config 5 --L 4 --steps 2 --warmup 1 --no-cpu-baseline > $out/trace_cfg5.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2 -- python3 bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline > $out/trace_cfg2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_m256 -- python3 bench.py --N 200000 --M 256 --L 32 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_m256.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2panel -- python3 bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline --panel-products > $out/trace_cfg2panel.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_cfg2panel -- python3 bench.py --config 2 --steps 10 --warmup 2 --no-cpu-baseline --panel-products > $out/trace_cfg2panel.log 2>&1   # (= trace_cfg2 since the panel kernel became the default there)
 echo "config traces done"
 ls $out

@@ -76,7 +76,7 @@ for tag, what in (("cfg5", "configs[4] as one of eight ranks holds it: MGGP, N=2
     if b:
         k = b["kernels"]
         P(f"  {b['ms_per_step']:.2f} ms per evaluation | stage 1 {b['roofline']['achieved']:.1f} TF = {b['roofline']['frac']:.3f} of "
-          f"{b['roofline']['peak']} | stage 2 {k['stage2_LuT_Wt']['achieved_TFLOPs']:.1f} TF | fill {k['kuf_fill']['achieved_GBps']:.0f} GB/s | "
+          f"{b['roofline']['peak']} | stage 2 {k['stage2_LuT_Wt']['achieved_TFLOPs']:.1f} TF | fill {(k['kuf_fill']['achieved_GBps'] or 0):.0f} GB/s | "
           f"factor {k['potrf_ms_per_eval']:.3f} ms ({k.get('factor', {}).get('achieved_TFLOPs', 0):.1f} TF fp64)")
     for name, calls, avg, tot in sorted(rows(st, lambda n: "gpz::" in n), key=lambda r: -r[3])[:8]:
         P(f"  {name[:78]:78s} {calls:5d} calls  avg {avg:8.3f} ms  total {tot:9.1f} ms")
@@ -90,7 +90,7 @@ for tag, what, Lp, Mq, Nq in (("m256", "N=200000, M=256, L=32, Matern-3/2, fp32:
     P(f"== panel kernel (csrc/gemmp.hip), {what}")
     if b:
         P(f"  {b['ms_per_step']:.2f} ms per evaluation | {b['roofline']['kernel'][:60]}: {b['roofline']['achieved']:.1f} TF over BOTH products "
-          f"= {b['roofline']['frac']:.3f} of {b['roofline']['peak']} | fill {b['kernels']['kuf_fill']['achieved_GBps']:.0f} GB/s")
+          f"= {b['roofline']['frac']:.3f} of {b['roofline']['peak']} | fill {(b['kernels']['kuf_fill']['achieved_GBps'] or 0):.0f} GB/s (0: computed inside the kernel)")
     for name, calls, avg, tot in sorted(rows(st, lambda n: "gpz::" in n), key=lambda r: -r[3])[:5]:
         P(f"  {name[:78]:78s} {calls:5d} calls  avg {avg:8.3f} ms  total {tot:9.1f} ms")
     pk = rows(st, lambda n: "panel_kernel" in n)
