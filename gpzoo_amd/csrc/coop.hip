@@ -766,7 +766,7 @@ size_t coop_sync_words(int64_t Mp, int64_t batch) {
 // diagonal blocks in Dinv and -- when Linv is given -- the inverse of the factor in Linv (pitch Mp; its blocks above
 // the diagonal are NOT written) with XT (batch, Mp, Mp) as scratch.  info as potrf_padded; -7: a hand-off timed out.
 int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                double* Linv, double* XT, uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32) {
+                double* Linv, double* XT, uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32, bool sync_cleared) {
   GPZ_REQUIRE(coop_supported(Mp, Linv != nullptr), "factor_coop: order %lld not supported", (long long)Mp);
   GPZ_REQUIRE(!Linv || XT, "factor_coop: the inverse needs its transposed scratch");
   GPZ_REQUIRE(lda * 128 * 8 < (1ll << 31), "factor_coop: leading dimension too large for 32-bit lane offsets");
@@ -805,7 +805,7 @@ int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batc
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)CO_LDS_BYTES));
     attr_set[dev & 63] = true;
   }
-  GPZ_HIP_OK(hipMemsetAsync(sync, 0, sizeof(uint32_t) * coop_sync_words(Mp, batch), s));
+  if (!sync_cleared) GPZ_HIP_OK(hipMemsetAsync(sync, 0, sizeof(uint32_t) * coop_sync_words(Mp, batch), s));
   hipLaunchKernelGGL(coop_factor_kernel, dim3(nwg), dim3(CO_THREADS), CO_LDS_BYTES, s, p, ord);
   GPZ_LAUNCH_OK();
   return 0;

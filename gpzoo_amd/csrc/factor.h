@@ -8,7 +8,8 @@ namespace gpz {
 bool coop_supported(int64_t Mp, bool inverse);
 size_t coop_sync_words(int64_t Mp, int64_t batch);
 int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batch, int64_t m_real, double* Dinv,
-                double* Linv, double* XT, uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32 = nullptr);
+                double* Linv, double* XT, uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32 = nullptr,
+                bool sync_cleared = false);
 
 // Which path the entries below take: the one-launch dataflow unless GPZ_FACTOR_PATH=launches (the launch-per-step
 // chain of rounds 1-3, kept for comparison and for orders the dataflow's task list cannot hold).
@@ -27,6 +28,10 @@ int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* 
 // T: batch * Mp * Mp doubles of scratch; sync as above (null: launch-per-step path).  Linv32 (nullable): an fp32 copy
 // of Linv, written by the one-launch path itself; *wrote32 tells whether it was (the caller casts otherwise).
 int factor_invert_padded(double* A, int64_t Mp, int64_t batch, int64_t m_real, double* Dinv, double* Linv, double* T,
-                         uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32 = nullptr, bool* wrote32 = nullptr);
+                         uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32 = nullptr, bool* wrote32 = nullptr,
+                         bool sync_cleared = false);
+// Words of `sync` a one-launch factorisation of this shape wants zeroed before it starts (0: the launch chain runs).  A caller
+// that zeroes them together with its own flags passes sync_cleared = true and saves the launch.
+size_t factor_sync_clear_words(int64_t Mp, int64_t batch, bool with_inverse);
 
 }  // namespace gpz

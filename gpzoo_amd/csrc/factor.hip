@@ -182,8 +182,12 @@ int trtri_padded(const double* Lc, int64_t ldl, int64_t stride_l, const double* 
   return 0;
 }
 
+size_t factor_sync_clear_words(int64_t Mp, int64_t batch, bool with_inverse) {
+  return factor_use_coop(Mp, with_inverse) ? coop_sync_words(Mp, batch) : 0;
+}
+
 int factor_invert_padded(double* A, int64_t Mp, int64_t batch, int64_t m_real, double* Dinv, double* Linv, double* T,
-                         uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32, bool* wrote32) {
+                         uint32_t* sync, int32_t* info, hipStream_t s, float* Linv32, bool* wrote32, bool sync_cleared) {
   if (wrote32) *wrote32 = false;
   if (sync && factor_use_coop(Mp, true)) {
     static const bool no32 = std::getenv("GPZ_COOP_NO_CAST32") != nullptr;     // A/B measurements only
@@ -192,7 +196,7 @@ int factor_invert_padded(double* A, int64_t Mp, int64_t batch, int64_t m_real, d
     // one launch for both; the two profile slots then bracket the same interval
     prof_begin(PROF_POTRF_ALL, s);
     prof_begin(PROF_TRTRI, s);
-    if (int rc = factor_coop(A, Mp, Mp, Mp * Mp, batch, m_real, Dinv, Linv, T, sync, info, s, Linv32)) return rc;
+    if (int rc = factor_coop(A, Mp, Mp, Mp * Mp, batch, m_real, Dinv, Linv, T, sync, info, s, Linv32, sync_cleared)) return rc;
     prof_end(PROF_TRTRI, s);
     prof_end(PROF_POTRF_ALL, s);
     return 0;

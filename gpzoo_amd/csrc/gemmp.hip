@@ -30,7 +30,8 @@
 
 // Timing-only diagnostics (WRONG results): -DGPZ_P_ABL=4 builds the kernel without its A-fragment loads, 8 without its B-fragment reads; at run time
 // GPZ_PANEL_DBG=1 loads the Kzx panel once per workgroup, =2 deals the row blocks to the waves in order (no SIMD pairing),
-// =8 gives every wave the k range of the middle row block (equal durations), =16 swaps the A operands of the two stages.
+// =8 gives every wave the k range of the middle row block (equal durations), =16 swaps the A operands of the two stages,
+// =32 deals the row blocks as the first version did (s, 7 - s, 8 + s, 15 - s).
 #ifndef GPZ_P_ABL
 #define GPZ_P_ABL 0
 #endif
@@ -56,12 +57,18 @@ struct PanelParams {
 
 constexpr int P_TN = 64;                    // columns of a panel
 
-// which 32-row block wave w takes: a workgroup's waves go to the SIMDs in a cyclic order of period 4, so waves w, w + 4,
-// w + 8, w + 12 share one; block r has r + 1 k-chunks-pairs in stage 1 and nb - r in stage 2
+// which 32-row block wave w takes.  A workgroup's waves go to the SIMDs in a cyclic order of period 4, so waves w, w + 4,
+// w + 8, w + 12 share one; block r has r + 1 units of k in stage 1 and nb - r in stage 2.  The blocks are dealt so that every
+// SIMD carries the same sum in both stages AND its two longest waves are of nearly equal length: the longest wave of a SIMD
+// ends the stage alone, and a wave alone does not keep the matrix pipe full (its own loads and waits show).
+//   16 blocks: {0, 3, 12, 15}, {1, 2, 13, 14}, {4, 5, 10, 11}, {6, 7, 8, 9}: 34 units each, at most 3 of them alone
+//              (s, 7 - s, 8 + s, 15 - s, the first dealing, left 7 alone on SIMD 0: configs[1] +1.3 %, M = 384 +4.4 %;
+//              {0, 1, 14, 15}, {2, 3, 12, 13}, ... leaves 1 alone but two waves for 26 of the 34: no better than the first)
+//   12 blocks: {0, 5, 11}, {1, 6, 10}, {3, 4, 9}, {2, 7, 8}: 19 / 20 / 19 / 20 units (s, 7 - s, 8 + s: 18 ... 21)
 template <int NB> __device__ __forceinline__ int row_block_of(int w) {
-  if constexpr (NB == 16) return w < 4 ? w : w < 8 ? 11 - w : w < 12 ? w : 27 - w;     // SIMD s: blocks s, 7 - s, 8 + s, 15 - s
-  else if constexpr (NB == 12) return w < 4 ? w : w < 8 ? 11 - w : w;                   //         s, 7 - s, 8 + s
-  else if constexpr (NB == 8) return w < 4 ? w : 11 - w;                                //         s, 7 - s
+  if constexpr (NB == 16) { constexpr int t[16] = {0, 1, 4, 6, 3, 2, 5, 7, 12, 13, 10, 8, 15, 14, 11, 9}; return t[w]; }
+  else if constexpr (NB == 12) { constexpr int t[12] = {0, 1, 3, 2, 5, 6, 4, 7, 11, 10, 9, 8}; return t[w]; }
+  else if constexpr (NB == 8) return w < 4 ? w : 11 - w;                                //  s, 7 - s (two workgroups per CU)
   else return w;
 }
 
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(64 * NB) void panel_kernel(const PanelParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int rb = (p.dbg & 2) ? wave : row_block_of<NB>(wave);
+  const int rb = (p.dbg & 2) ? wave : (p.dbg & 32) ? (NB == 16 ? (wave < 4 ? wave : wave < 8 ? 11 - wave : wave < 12 ? wave : 27 - wave) : NB == 12 ? (wave < 4 ? wave : wave < 8 ? 11 - wave : wave) : row_block_of<NB>(wave)) : row_block_of<NB>(wave);
   constexpr int NT = 64 * NB;
   auto gperm = [](int c) { const int t = (c >> 2) & 3; return (((t >> 1) ^ t) & 1) << 1 | (t >> 1); };
 

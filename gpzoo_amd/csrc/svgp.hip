@@ -421,13 +421,25 @@ static Buffers<T> carve(const Plan& pl, bool whitened, void* ws) {
 
 // Steps shared by the forward and backward passes: Kzz + jitter I (fp64, identity padded), its
 // Cholesky factor and inverse, and q(U)'s parameters in the form the two big products need.
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ a, size_t na, uint32_t* __restrict__ b, size_t nb) {
+  const size_t t0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+  for (size_t i = t0; i < na; i += step) a[i] = 0u;
+  for (size_t i = t0; i < nb; i += step) b[i] = 0u;
+}
+
 template <typename T>
 static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, hipStream_t s) {
   const bool wh = p->whitened != 0;
   const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, mm = Mp * Mp;
   const int L32 = (int)L;
   // info: 0 = fine, k > 0 = leading minor k not positive-definite (potrf), < 0 = a group id out of range (kfill)
-  GPZ_HIP_OK(hipMemsetAsync(p->info, 0, sizeof(int32_t) * L, s));
+  // ... zeroed in ONE small launch together with the flag words of the one-launch factorisation (each separate memset is a
+  // launch of its own, and on a short evaluation -- whose previous `info` check left the queue empty -- every launch of
+  // this prelude is a host round trip the GPU waits for)
+  const bool will_factor = !(p->factor_cache && (p->factor_cache_valid & 1));
+  const size_t nsync = will_factor ? factor_sync_clear_words(Mp, L, true) : 0;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(64, (nsync + (size_t)L) / 1024 + 1)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p->info), (size_t)L, b.fsync, nsync);
+  GPZ_LAUNCH_OK();
   // 1. Kzz + jitter I (fp64, identity padded), Cholesky, inverse -- or the caller's cached copy
   if (p->factor_cache) {
     FactorCache<T> f = carve_cache<T>(pl, wh, p->factor_cache);
@@ -444,7 +456,7 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
       return rc;
     bool wrote32 = false;     // the one-launch factorisation writes the fp32 copy of the inverse itself
     if (int rc = factor_invert_padded(b.Kzz, Mp, L, M, b.Dinv, b.Linv, b.Tmp, b.fsync, p->info, s,
-                                      sizeof(T) == 4 ? reinterpret_cast<float*>(b.LinvG) : nullptr, &wrote32))
+                                      sizeof(T) == 4 ? reinterpret_cast<float*>(b.LinvG) : nullptr, &wrote32, nsync > 0))
       return rc;
     hipLaunchKernelGGL((chol_out_kernel<T>), dim3(p->chol ? 64 : 1, L32), dim3(256), 0, s, b.Kzz, Mp, M,
                        static_cast<T*>(p->chol), b.chol_logdiag);

@@ -437,7 +437,7 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     if want_chol:
         out["chol"] = torch.empty((L, M, M), dtype=dt, device=dev)
         p.chol = out["chol"].data_ptr()
-    scal = torch.zeros(2 * L + 1, dtype=torch.float64, device=dev)
+    scal = torch.empty(2 * L + 1, dtype=torch.float64, device=dev)     # every entry is written by the pass (reduce / elbo_sum kernels)
     info = torch.empty(L, dtype=torch.int32, device=dev)
     p.kl, p.loglik, p.elbo = scal.data_ptr(), scal.data_ptr() + 8 * L, scal.data_ptr() + 16 * L
     p.info = info.data_ptr()

@@ -31,7 +31,7 @@ def main():
     lib.gpz_debug_panel_stamps(None)
     t = buf.cpu().view(16, 8, 8)
     names = ["panel write", "barrier", "stage 1", "stats+Wt->LDS", "stage 2", "stats", "barrier"]
-    rb = [0, 1, 2, 3, 7, 6, 5, 4]       # 32-row blocks of waves 0 .. 7 (of 16: SIMD s holds blocks s, 7 - s, 8 + s, 15 - s)
+    rb = [0, 1, 4, 6, 3, 2, 5, 7]       # 32-row blocks of waves 0 .. 7 (of 16: row_block_of in csrc/gemmp.hip)
     for it in (2, 3, 4):
         base = int(t[it, :, 0].min())
         print("panel %d (length %d cycles from first top to last end)" % (it, int(t[it, :, 7].max()) - base))
