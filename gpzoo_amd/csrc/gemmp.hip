@@ -138,46 +138,60 @@ __global__ __launch_bounds__(64 * NB) void panel_kernel(const PanelParams p) {
         pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kr, voff, i * sstep, 0));
 #endif
     } else {
-      // the thread's four columns (spots) stay in registers for its sixteen k rows (inducing points); padded rows and
-      // columns are exactly zero, as the stand-alone fill writes them
+      // Computed: a fetching wave takes sixteen groups of four consecutive k (inducing points: wave-uniform)
+      // for all 64 columns (one spot per lane, in registers) -- a lane's four values are one 16-byte LDS write.  Padded rows
+      // and columns are exactly zero, as the stand-alone fill writes them.
       constexpr int KIND = (GEN - 1) >> 1, D = ((GEN - 1) & 1) + 1;
       const CovConst cc = cov_const<KIND>(p.sigma[l], p.ell[l]);
-      float xc[4][D];
-      bool real[4];
+      const int64_t n = col0 + lane;
+      const bool real = n < p.nreal;
+      float xc[D];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int64_t n = col0 + 4 * pc4 + e;
-        real[e] = n < p.nreal;
+      for (int k = 0; k < D; ++k) xc[k] = real ? p.X[n * D + k] : 0.f;
+      // the wave's 64 inducing points: lane 4 i + e holds point k(i, e) (one vector load per coordinate), handed to all lanes
+      // by v_readlane when its turn comes (64 scalar loads would take 128 SGPRs at D = 2: they spill)
+      const int fw = rb - NB / 2;
+      const int kl = 4 * (fw + (NB / 2) * (lane >> 2)) + (lane & 3);
+      float zl[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) xc[e][k] = real[e] ? p.X[n * D + k] : 0.f;
-      }
-      int kof = pk_of;
-      asm volatile("" : "+v"(kof));              // per panel: the sixteen inducing points are NOT to be kept in registers across panels
+      for (int kk = 0; kk < D; ++kk) zl[kk] = kl < p.M ? p.Z[kl * D + kk] : 0.f;
+      // padding as a factor (1 or 0, exact; the values are finite and non-negative: 0 * v = +0 as the fill writes it) rather
+      // than 64 lane-mask predicates, which would live in 128 SGPRs
+      const float rowf = kl < p.M ? 1.f : 0.f, colf = real ? 1.f : 0.f;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
-        const int k = i * RP + kof;
-        const bool row = k < p.M;
-        float z[D];
-#pragma unroll
-        for (int kk = 0; kk < D; ++kk) z[kk] = row ? p.Z[k * D + kk] : 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = cov_value<KIND>(cov_radial<KIND>(cov_d2<D>(z, xc[e])), cc.amp, cc.c0, cc.c1);
-          pv[i][e] = (row && real[e]) ? v : 0.f;
+          float z[D];
+#pragma unroll
+          for (int kk = 0; kk < D; ++kk) z[kk] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zl[kk]), 4 * i + e));
+          const float keep = colf * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rowf), 4 * i + e));
+          pv[i][e] = keep * cov_value<KIND>(cov_radial<KIND>(cov_d2<D>(z, xc)), cc.amp, cc.c0, cc.c1);
         }
       }
     }
   };
   auto panel_write = [&]() __attribute__((always_inline)) {
-    int kof = pk_of;
-    asm volatile("" : "+v"(kof));                // per panel: keeps the store addresses from being hoisted out of the unit loop (and spilled)
+    if constexpr (GEN == 0) {
+      int kof = pk_of;
+      asm volatile("" : "+v"(kof));              // per panel: keeps the store addresses from being hoisted out of the unit loop (and spilled)
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int k = i * RP + kof;
+      for (int i = 0; i < NR; ++i) {
+        const int k = i * RP + kof;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = 4 * pc4 + e;
-        P[c * PK + (k & ~15) + ((((k >> 2) & 3) ^ gperm(c)) << 2) + (k & 3)] = pv[i][e];
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * pc4 + e;
+          P[c * PK + (k & ~15) + ((((k >> 2) & 3) ^ gperm(c)) << 2) + (k & 3)] = pv[i][e];
+        }
+      }
+    } else {
+      int base = lane * PK;
+      asm volatile("" : "+v"(base));
+      const int gs = gperm(lane), fw = rb - NB / 2;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int kq = fw + (NB / 2) * i;        // group of four k: slot kq & 3 of chunk kq >> 2
+        *reinterpret_cast<f32x4*>(P + base + ((kq >> 2) << 4) + (((kq & 3) ^ gs) << 2)) = pv[i];
       }
     }
   };
