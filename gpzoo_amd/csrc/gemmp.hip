@@ -51,7 +51,7 @@ struct PanelParams {
   const float* muE;                         // (L, Mp)
   float* ps1; float* pm1; float* ps2;       // [L][Mp / 128][ncp]
   int Mp, ncp, L, npan, units;              // panels per latent, units = L * npan
-  unsigned long long* stamps;               // debug (gpz_debug_panel_stamps): workgroup 0's phase times, [panel][wave][8]
+  unsigned long long* stamps;               // debug (gpz_debug_panel_stamps): workgroup 0's phase times, [panel][16 waves][8]
   int dbg;                                  // timing diagnostics (GPZ_PANEL_DBG; wrong results): 1 panel loaded once, 2 no SIMD pairing
 };
 
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(64 * NB) void panel_kernel(const PanelParams p) {
 
   int n_it = 0;
   auto stamp = [&](int ph) __attribute__((always_inline)) {
-    if (p.stamps && blockIdx.x == 0 && n_it < 16 && wave < 8 && lane == 0)
-      p.stamps[(n_it * 8 + wave) * 8 + ph] = __builtin_readcyclecounter();
+    if (p.stamps && blockIdx.x == 0 && n_it < 16 && lane == 0)
+      p.stamps[(n_it * 16 + wave) * 8 + ph] = __builtin_readcyclecounter();
   };
 
   using std::integral_constant;
@@ -493,6 +493,6 @@ int panel_launch(const PanelArgs& a, hipStream_t s) {
 
 }  // namespace gpz
 
-// Debug: device buffer of 16 * 8 * 8 uint64 that workgroup 0 of the next panel launches fills with its phase times
+// Debug: device buffer of 16 * 16 * 8 uint64 that workgroup 0 of the next panel launches fills with its phase times
 // (shader clock; tools/panel_trace.py), or null to stop.
 extern "C" void gpz_debug_panel_stamps(unsigned long long* buf) { gpz::g_panel_stamps = buf; }

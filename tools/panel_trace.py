@@ -24,18 +24,18 @@ def main():
     args = (spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], True)
     for _ in range(3):
         ops.svgp_forward(*args, **extra)
-    buf = torch.zeros(16 * 8 * 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(16 * 16 * 8, dtype=torch.int64, device="cuda")
     lib.gpz_debug_panel_stamps(buf.data_ptr())
     ops.svgp_forward(*args, **extra)
     torch.cuda.synchronize()
     lib.gpz_debug_panel_stamps(None)
-    t = buf.cpu().view(16, 8, 8)
+    t = buf.cpu().view(16, 16, 8)
     names = ["panel write", "barrier", "stage 1", "stats+Wt->LDS", "stage 2", "stats", "barrier"]
-    rb = [0, 1, 4, 6, 3, 2, 5, 7]       # 32-row blocks of waves 0 .. 7 (of 16: row_block_of in csrc/gemmp.hip)
-    for it in (2, 3, 4):
+    rb = [0, 1, 4, 6, 3, 2, 5, 7, 12, 13, 10, 8, 15, 14, 11, 9]       # 32-row blocks of the 16 waves (row_block_of in csrc/gemmp.hip)
+    for it in (3,):
         base = int(t[it, :, 0].min())
         print("panel %d (length %d cycles from first top to last end)" % (it, int(t[it, :, 7].max()) - base))
-        for w in range(8):
+        for w in range(16):
             d = [int(t[it, w, i + 1] - t[it, w, i]) for i in range(7)]
             print("  wave %d (row block %d): start +%5d | " % (w, rb[w], int(t[it, w, 0]) - base) +
                   "  ".join("%s %6d" % (n, x) for n, x in zip(names, d)))
