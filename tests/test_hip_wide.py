@@ -196,6 +196,23 @@ def test_generated_operand_does_not_read_the_kzx_buffer():
     assert torch.isfinite(b["mean"]).all() and torch.isfinite(b["scale"]).all()
 
 
+def test_panel_kernel_does_not_read_the_kzx_buffer():
+    """M <= 512, RBF / Matern-3/2: the panel kernel computes its covariance panel itself -- no fill launch, nothing read from
+    the workspace where the other paths keep their Kzx chunk: poison it with NaN bit patterns, evaluate, and compare with
+    the fill + tile-kernel path bit for bit."""
+    from gpzoo_amd import ops
+    c, g, spec, extra = _problem(3, 6000, 500, 2, 2)
+    a = _run(c, g, spec, extra, materialize_kzx=True)
+    assert ops._workspaces
+    for t in ops._workspaces.values():
+        t.fill_(0xFF)
+    b = _run(c, g, spec, extra)
+    assert b["path"] == 4
+    nwt = 2 * 512 * 6016
+    assert torch.equal(a["wt_cache"].view(torch.int32)[:nwt], b["wt_cache"].view(torch.int32)[:nwt])
+    assert torch.isfinite(b["mean"]).all() and torch.isfinite(b["scale"]).all()
+
+
 @pytest.mark.parametrize("whitened", [True, False])
 @pytest.mark.parametrize("N,M,L,retain", [(5000, 640, 2, True), (5000, 640, 2, False), (3000, 1024, 1, True), (2000, 384, 3, False)])
 def test_backward_wide_matches_narrow(N, M, L, retain, whitened):
