@@ -43,6 +43,10 @@ int wide_product_launch(const WideArgs& a, hipStream_t s);
 // C (L, Mp, Mp) += A (L, Mp, K) * B (L, Mp, K)^T, lower 128-tiles only (the tiles on the diagonal are written whole), fp32:
 // the backward pass's gradient accumulations over an N-chunk.
 bool wide_nt_supported(int64_t Mp, int64_t K);
-int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s);
+// With few tiles (small M, few latents) the k extent is cut into pieces that run side by side and are added up in a fixed
+// order; `scratch`: wide_nt_scratch_floats(Mp, K, L) floats (0: never cut), or null: one workgroup per tile walks all of k.
+int wide_nt_pieces(int64_t Mp, int64_t K, int L);
+size_t wide_nt_scratch_floats(int64_t Mp, int64_t K, int L);
+int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s, float* scratch = nullptr);
 
 }  // namespace gpz

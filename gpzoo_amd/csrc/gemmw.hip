@@ -508,6 +508,10 @@ struct NTParams {
   const float* A; const float* B; float* C;
   int64_t ld, sAB, ldc, sC;                 // operand leading dimension (= K) / batch stride, C's
   int K, nblk, mt, L, T;                    // k extent, 128-blocks, 256-row tiles, matrices, tiles per matrix
+  // few tiles (small M, few latents): the k extent is cut into S pieces of Ks (a multiple of 32) and a workgroup takes one
+  // (tile, piece); its result goes to part[piece] (laid out like C, plain store) and nt_reduce_kernel adds the pieces to C
+  int S, Ks;
+  float* part; int64_t sPart;
 };
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_nt_kernel(const NTParams p) {
@@ -518,10 +522,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   auto sA = [&](int buf) -> float* { return smem + buf * STAGE; };
   auto sB = [&](int buf) -> float* { return smem + buf * STAGE + A_ELEMS; };
   // block -> (matrix, tile): XCD x takes the contiguous range [x n / 8, (x + 1) n / 8) of the (matrix-major) tile order
-  int b0, ti, tj;
+  int b0, ti, tj, piece;
   {
     const int nb = (int)gridDim.x, qn = nb >> 3, rem = nb & 7, x = blockIdx.x & 7;
-    const int lid = x * qn + min(x, rem) + (int)(blockIdx.x >> 3);
+    const int lid0 = x * qn + min(x, rem) + (int)(blockIdx.x >> 3);
+    const int lid = lid0 / p.S;
+    piece = lid0 - lid * p.S;
     b0 = lid / p.T;
     const int t = lid - b0 * p.T;
     // row tile ti holds column tiles 0 .. 2 ti + 1 (the last row of an odd block count one fewer): ti (ti + 1) tiles precede it
@@ -551,9 +557,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (int h = 0; h < 2; ++h) {
     int row = ti * TM + (2 * wave + h) * 16;
     while (row >= Mp) row -= 128;
-    a_soff[h] = row * (int)p.ld * (int)sizeof(float);
+    a_soff[h] = (row * (int)p.ld + piece * p.Ks) * (int)sizeof(float);
   }
-  b_soff = (tj * TN + wave * 16) * (int)p.ld * (int)sizeof(float);
+  b_soff = ((tj * TN + wave * 16) * (int)p.ld + piece * p.Ks) * (int)sizeof(float);
   auto stage_load = [&](int buf) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             acc[half * 4 + m][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][j], fb[ni][j], acc[half * 4 + m][ni], 0, 0, 0);
     }
   };
-  const int nk = p.K / BK;                           // even: K is a multiple of 128
+  const int nk = (min(p.K, (piece + 1) * p.Ks) - piece * p.Ks) / BK;      // even: K is a multiple of 128, Ks of 32
   stage_load(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -617,10 +623,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     return;
   }
-  // read-modify-write of the tile: all loads of a pass are issued before its first store
+  // read-modify-write of the tile (all loads of a pass are issued before its first store) -- or, with the k extent cut
+  // into pieces, a plain store of this piece's partial tile
   constexpr int LDE = 36;
   float* strip = smem + wave * (32 * LDE);
-  float* Cg = p.C + b0 * p.sC + (int64_t)db * 128 * p.ldc + (int64_t)tj * TN + wn * 32;
+  const bool split = p.S > 1;
+  float* Cg = (split ? p.part + piece * p.sPart : p.C) + b0 * p.sC + (int64_t)db * 128 * p.ldc + (int64_t)tj * TN + wn * 32;
   const int srow = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
@@ -633,7 +641,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __builtin_amdgcn_wave_barrier();
     f32x4 cin[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) cin[it] = *reinterpret_cast<const f32x4*>(Cg + (int64_t)(pass * 32 + it * 8 + srow) * p.ldc + c4);
+    for (int it = 0; it < 4; ++it)
+      cin[it] = split ? f32x4{0, 0, 0, 0} : *reinterpret_cast<const f32x4*>(Cg + (int64_t)(pass * 32 + it * 8 + srow) * p.ldc + c4);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + srow;
@@ -642,6 +651,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// C += part[0] + part[1] + ... (ascending: reproducible) over the 128-blocks the product computes (column block <= row block)
+__global__ __launch_bounds__(256) void nt_reduce_kernel(float* __restrict__ C, const float* __restrict__ part, int S, int64_t sPart,
+                                                        int Mp, int64_t total4) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= total4) return;
+  const int64_t e = i4 * 4;
+  const int col = (int)(e % Mp), row = (int)((e / Mp) % Mp);
+  if ((col >> 7) > (row >> 7)) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(C + e);
+  for (int s = 0; s < S; ++s) v += *reinterpret_cast<const f32x4*>(part + s * sPart + e);
+  *reinterpret_cast<f32x4*>(C + e) = v;
 }
 
 // ---------------- host side ----------------
@@ -778,17 +800,43 @@ bool wide_nt_supported(int64_t Mp, int64_t K) {
   return Mp % 128 == 0 && K % 128 == 0 && K > 0 && Mp * K * 4 < (1ll << 31);
 }
 
-int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s) {
+// Pieces of the k extent for a launch with few tiles: at Mp = 512, L = 8 (configs[1]) there are 48 tiles for 256 CUs and one
+// workgroup walked all 50 048 columns (6.0 ms per launch: 60 % of a forward + backward there); cut into pieces the launch
+// fills the chip.  1: no cut (enough tiles, or a short k).
+int wide_nt_pieces(int64_t Mp, int64_t K, int L) {
+  const int64_t nblk = Mp / 128, mt = (nblk + 1) / 2, T = mt * (mt + 1) - (nblk & 1), tiles = T * L;
+  if (tiles >= 384) return 1;
+  int64_t S = (512 + tiles - 1) / tiles;
+  S = std::min<int64_t>(S, K / 1024);           // at least 64 steps per piece
+  S = std::min<int64_t>(S, 16);
+  return (int)std::max<int64_t>(S, 1);
+}
+
+size_t wide_nt_scratch_floats(int64_t Mp, int64_t K, int L) {
+  const int S = wide_nt_pieces(Mp, K, L);
+  return S > 1 ? (size_t)S * L * Mp * Mp : 0;
+}
+
+int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s, float* scratch) {
   GPZ_REQUIRE(A && B && C && wide_nt_supported(Mp, K) && L > 0, "wide A B^T: bad arguments");
   NTParams p;
   p.A = A; p.B = B; p.C = C; p.ld = K; p.sAB = Mp * K; p.ldc = Mp; p.sC = Mp * Mp;
   p.K = (int)K; p.nblk = (int)(Mp / 128); p.mt = (p.nblk + 1) / 2; p.L = L;
   p.T = p.mt * (p.mt + 1) - (p.nblk & 1);            // row tile ti holds min(2 ti + 2, nblk) column tiles
-  const int64_t nblocks = (int64_t)p.T * L;
+  int S = scratch ? wide_nt_pieces(Mp, K, L) : 1;
+  p.Ks = (int)(((K + S - 1) / S + 31) / 32 * 32);
+  S = (int)((K + p.Ks - 1) / p.Ks);
+  p.S = S; p.part = scratch; p.sPart = (int64_t)L * Mp * Mp;
+  const int64_t nblocks = (int64_t)p.T * L * S;
   GPZ_REQUIRE(nblocks > 0 && nblocks < (1ll << 31), "wide A B^T: bad grid");
   constexpr size_t lds = sizeof(float) * 2 * (256 + 128) * W_BK;
   hipLaunchKernelGGL(gemmw_nt_kernel, dim3((unsigned)nblocks), dim3(512), lds, s, p);
   GPZ_LAUNCH_OK();
+  if (S > 1) {
+    const int64_t total4 = (int64_t)L * Mp * Mp / 4;
+    hipLaunchKernelGGL(nt_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, C, scratch, S, p.sPart, (int)Mp, total4);
+    GPZ_LAUNCH_OK();
+  }
   return 0;
 }
 

@@ -1058,6 +1058,7 @@ __global__ void kl_add_kernel(T* __restrict__ G, int64_t Mp, const double* __res
 template <typename T>
 struct BwdBuffers {
   T *Pc, *G, *G2, *LinvT, *cs; double *mu_part, *mu_sum;
+  float* nt_part;                            // fp32, few tiles: pieces of the A B^T accumulations (gemmw.hip, wide_nt_pieces)
   // kernel / Z gradients only
   T *LuN, *GL, *csc, *gmc, *PS; double *D1, *D2, *D3, *kacc, *sig_direct;
   size_t bytes;
@@ -1076,6 +1077,8 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* w
   b.cs = c.take<T>(pl.L * pl.nc);
   b.mu_part = c.take<double>(pl.L * pl.nchunks * pl.Mp);
   b.mu_sum = c.take<double>(pl.L * pl.Mp);
+  const size_t ntf = sizeof(T) == 4 && wide_nt_supported(pl.Mp, pl.nc) ? wide_nt_scratch_floats(pl.Mp, pl.nc, (int)pl.L) : 0;
+  b.nt_part = ntf ? c.take<float>((int64_t)ntf) : nullptr;
   b.LuN = b.GL = b.csc = b.gmc = b.PS = nullptr;
   b.D1 = b.D2 = b.D3 = b.kacc = b.sig_direct = nullptr;
   if (full) {
@@ -1201,7 +1204,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     g3.alpha = 1; g3.beta = 1;
     const bool wide_nt = sizeof(T) == 4 && wide && wide_nt_supported(Mp, ncp);
     if (wide_nt) {
-      if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(Wc, w.Pc, w.G, Mp, ncp, L32, s)) return rc; }
+      if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(Wc, w.Pc, w.G, Mp, ncp, L32, s, w.nt_part)) return rc; }
     } else if (int rc = gemm_launch(g3, EPI_STORE, s)) return rc;
     hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, Wc, Mp, ncp,
                        static_cast<const T*>(g->g_mean), N, n0, w.mu_part, pl.nchunks, ci);
@@ -1245,7 +1248,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       GemmParams<T> g6 = g3;
       g6.A = w.Pc; g6.B = Wc; g6.C = w.GL;
       if (wide_nt) {
-        if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(w.Pc, Wc, w.GL, Mp, ncp, L32, s)) return rc; }
+        if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(w.Pc, Wc, w.GL, Mp, ncp, L32, s, w.nt_part)) return rc; }
       } else if (int rc = gemm_launch(g6, EPI_STORE, s)) return rc;
       // kernel hyper-parameter and Z gradients from Kbar_x
       KgradArgs ka;

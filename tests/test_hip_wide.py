@@ -217,8 +217,10 @@ def test_panel_kernel_does_not_read_the_kzx_buffer():
 @pytest.mark.parametrize("N,M,L,retain", [(5000, 640, 2, True), (5000, 640, 2, False), (3000, 1024, 1, True), (2000, 384, 3, False)])
 def test_backward_wide_matches_narrow(N, M, L, retain, whitened):
     """The backward pass's fp32 products on the wide kernels (W = Linv Kzx, Pbar with the column scale, Wbar, Kbar_x and the
-    two A B^T accumulations over the N-chunk) against the 128 x 128-tile kernel: every gradient agrees to fp32 rounding
-    (the k order is the same; only the column statistics of a recomputed W are summed in a different order)."""
+    two A B^T accumulations over the N-chunk) against the 128 x 128-tile kernel: every gradient agrees to fp32 rounding.
+    (The products keep the k order; the column statistics of a recomputed W are summed in a different order, and with few
+    tiles -- these shapes -- the wide A B^T accumulation cuts its k extent into pieces that run side by side and are added
+    up afterwards: another order of the fp32 sums, 5e-5 on the sigma / lengthscale gradients that sum everything.)"""
     from gpzoo_amd import ops
     c, g, spec, extra = _problem(3, N, M, L, 2)
     out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], whitened, want_Lu=False,
@@ -233,7 +235,7 @@ def test_backward_wide_matches_narrow(N, M, L, retain, whitened):
     for a, b, what in zip(res[True], res[False], ("grad_mu", "grad_Lu", "grad_theta", "grad_Z")):
         a, b = a.double(), b.double()
         assert torch.isfinite(b).all(), what
-        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-5 * float(a.abs().max()), msg=lambda m: f"{what}: {m}")
+        torch.testing.assert_close(b, a, rtol=1e-4, atol=1e-4 * float(a.abs().max()), msg=lambda m: f"{what}: {m}")
 
 
 def test_backward_wide_matches_narrow_on_the_paired_schedule():
