@@ -806,7 +806,7 @@ bool wide_nt_supported(int64_t Mp, int64_t K) {
 int wide_nt_pieces(int64_t Mp, int64_t K, int L) {
   const int64_t nblk = Mp / 128, mt = (nblk + 1) / 2, T = mt * (mt + 1) - (nblk & 1), tiles = T * L;
   if (tiles >= 384) return 1;
-  int64_t S = (512 + tiles - 1) / tiles;
+  int64_t S = 512 / tiles;                      // one round of two workgroups per CU, not a second round with a few stragglers
   S = std::min<int64_t>(S, K / 1024);           // at least 64 steps per piece
   S = std::min<int64_t>(S, 16);
   return (int)std::max<int64_t>(S, 1);

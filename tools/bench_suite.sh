@@ -21,8 +21,8 @@ PY
 }
 echo "== config 3 (default): N=200k M=2048 L=32 Matern-3/2 fp32, with forward+backward"
 python3 bench.py --no-cpu-baseline --with-backward > /tmp/b.log 2>/dev/null; one /tmp/b.log
-echo "== config 2: N=50k M=512 L=8 RBF fp32"
-python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+echo "== config 2: N=50k M=512 L=8 RBF fp32, with forward+backward"
+python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline --with-backward > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 2 on the fill + tile kernels (GPZ_SVGP_PRODUCTS=tiles; the line above is the panel kernel: fill and both products in one launch, kfill 0)"
 GPZ_SVGP_PRODUCTS=tiles python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== N=200k M=256 L=32 Matern-3/2 fp32: the panel kernel (the library's choice for M <= 512); then the tile kernels (GPZ_SVGP_PRODUCTS=tiles)"
