@@ -30,7 +30,7 @@ def main():
         for t in gp.kernel.parameters():
             t.requires_grad_(False)
         model = GaussianLikelihood(gp, noise=0.5).to(dev)
-        opt = torch.optim.Adam([gp.mu, gp.Lu], lr=1e-2)
+        opt = torch.optim.Adam([gp.mu, gp.Lu], lr=1e-2, fused=os.environ.get("GPZ_FUSED_ADAM", "0") == "1")
         for cache in (False, True):
             gp.cache_factor = cache
             times = []
