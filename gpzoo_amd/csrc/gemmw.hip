@@ -514,8 +514,12 @@ struct NTParams {
   float* part; int64_t sPart;
 };
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_nt_kernel(const NTParams p) {
-  constexpr int BK = W_BK, TM = 256, TN = 128;
+// TM = 256: 8 waves, two 128-row blocks per tile; TM = 128 (few blocks: at four 128-blocks the 256-row tile computes 12
+// block-slots for the 10 blocks of the lower triangle, at two blocks 4 for 3): 4 waves, one block per tile.
+template <int TM>
+__global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_nt_kernel(const NTParams p) {
+  constexpr int BK = W_BK, TN = 128;
+  constexpr int NW = TM / 32;                    // waves: (TM / 128) row blocks x 4 column strips
   constexpr int A_ELEMS = TM * BK, B_ELEMS = TN * BK, STAGE = A_ELEMS + B_ELEMS;
   extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
   float* const smem = reinterpret_cast<float*>(smem_raw);
@@ -530,18 +534,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     piece = lid0 - lid * p.S;
     b0 = lid / p.T;
     const int t = lid - b0 * p.T;
-    // row tile ti holds column tiles 0 .. 2 ti + 1 (the last row of an odd block count one fewer): ti (ti + 1) tiles precede it
-    int i = (int)((sqrtf(4.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while ((i + 1) * (i + 2) <= t) ++i;
-    while (i * (i + 1) > t) --i;
-    ti = i; tj = t - i * (i + 1);
+    if constexpr (TM == 256) {
+      // row tile ti holds column tiles 0 .. 2 ti + 1 (the last row of an odd block count one fewer): ti (ti + 1) tiles precede it
+      int i = (int)((sqrtf(4.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while ((i + 1) * (i + 2) <= t) ++i;
+      while (i * (i + 1) > t) --i;
+      ti = i; tj = t - i * (i + 1);
+    } else {
+      // row block ti holds column blocks 0 .. ti: ti (ti + 1) / 2 tiles precede it
+      int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while ((i + 1) * (i + 2) / 2 <= t) ++i;
+      while (i * (i + 1) / 2 > t) --i;
+      ti = i; tj = t - i * (i + 1) / 2;
+    }
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 15, q = lane >> 4;
   const int Mp = p.nblk * 128;
-  const int db = 2 * ti + wm;                        // this wave's 128-row block
+  const int db = (TM / 128) * ti + wm;               // this wave's 128-row block
   const bool active = db < p.nblk && tj <= db;       // blocks above the diagonal (and past the matrix) are not computed
   typedef __attribute__((address_space(3))) void lds_void;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -559,7 +571,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     while (row >= Mp) row -= 128;
     a_soff[h] = (row * (int)p.ld + piece * p.Ks) * (int)sizeof(float);
   }
-  b_soff = ((tj * TN + wave * 16) * (int)p.ld + piece * p.Ks) * (int)sizeof(float);
+  constexpr int NPB = 8 / NW;                    // 16-row pieces of the B tile per wave: 1 (8 waves) or 2 (4 waves)
+  b_soff = ((tj * TN + wave * NPB * 16) * (int)p.ld + piece * p.Ks) * (int)sizeof(float);
   auto stage_load = [&](int buf) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -567,7 +580,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(sA(buf) + (2 * wave + h) * 256), 16, voff, a_soff[h], 0, 0);
       a_soff[h] += BK * (int)sizeof(float);
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sB(buf) + wave * 256), 16, voff, b_soff, 0, 0);
+#pragma unroll
+    for (int h = 0; h < NPB; ++h)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sB(buf) + (wave * NPB + h) * 256), 16, voff,
+                                               b_soff + h * 16 * (int)p.ld * (int)sizeof(float), 0, 0);
     b_soff += BK * (int)sizeof(float);
 #endif
   };
@@ -803,8 +819,15 @@ bool wide_nt_supported(int64_t Mp, int64_t K) {
 // Pieces of the k extent for a launch with few tiles: at Mp = 512, L = 8 (configs[1]) there are 48 tiles for 256 CUs and one
 // workgroup walked all 50 048 columns (6.0 ms per launch: 60 % of a forward + backward there); cut into pieces the launch
 // fills the chip.  1: no cut (enough tiles, or a short k).
+static bool nt_small_tiles(int64_t nblk) { return nblk <= 4; }      // one 128-row block per tile (gemmw_nt_kernel<128>)
+static int64_t nt_tiles(int64_t nblk) {
+  if (nt_small_tiles(nblk)) return nblk * (nblk + 1) / 2;
+  const int64_t mt = (nblk + 1) / 2;
+  return mt * (mt + 1) - (nblk & 1);             // row tile ti holds min(2 ti + 2, nblk) column tiles
+}
+
 int wide_nt_pieces(int64_t Mp, int64_t K, int L) {
-  const int64_t nblk = Mp / 128, mt = (nblk + 1) / 2, T = mt * (mt + 1) - (nblk & 1), tiles = T * L;
+  const int64_t tiles = nt_tiles(Mp / 128) * L;
   if (tiles >= 384) return 1;
   int64_t S = 512 / tiles;                      // one round of two workgroups per CU, not a second round with a few stragglers
   S = std::min<int64_t>(S, K / 1024);           // at least 64 steps per piece
@@ -822,15 +845,21 @@ int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t
   NTParams p;
   p.A = A; p.B = B; p.C = C; p.ld = K; p.sAB = Mp * K; p.ldc = Mp; p.sC = Mp * Mp;
   p.K = (int)K; p.nblk = (int)(Mp / 128); p.mt = (p.nblk + 1) / 2; p.L = L;
-  p.T = p.mt * (p.mt + 1) - (p.nblk & 1);            // row tile ti holds min(2 ti + 2, nblk) column tiles
+  const bool small = nt_small_tiles(p.nblk);
+  p.T = (int)nt_tiles(p.nblk);
   int S = scratch ? wide_nt_pieces(Mp, K, L) : 1;
   p.Ks = (int)(((K + S - 1) / S + 31) / 32 * 32);
   S = (int)((K + p.Ks - 1) / p.Ks);
   p.S = S; p.part = scratch; p.sPart = (int64_t)L * Mp * Mp;
   const int64_t nblocks = (int64_t)p.T * L * S;
   GPZ_REQUIRE(nblocks > 0 && nblocks < (1ll << 31), "wide A B^T: bad grid");
-  constexpr size_t lds = sizeof(float) * 2 * (256 + 128) * W_BK;
-  hipLaunchKernelGGL(gemmw_nt_kernel, dim3((unsigned)nblocks), dim3(512), lds, s, p);
+  if (small) {
+    constexpr size_t lds = sizeof(float) * 2 * (128 + 128) * W_BK;
+    hipLaunchKernelGGL(gemmw_nt_kernel<128>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
+  } else {
+    constexpr size_t lds = sizeof(float) * 2 * (256 + 128) * W_BK;
+    hipLaunchKernelGGL(gemmw_nt_kernel<256>, dim3((unsigned)nblocks), dim3(512), lds, s, p);
+  }
   GPZ_LAUNCH_OK();
   if (S > 1) {
     const int64_t total4 = (int64_t)L * Mp * Mp / 4;
