@@ -509,8 +509,8 @@ static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, h
 //   * wherever it computes its covariance panel itself (cov.h: RBF / Matern-3/2 on 1-D / 2-D inputs) -- no fill launch, no
 //     Kzx: configs[1] (M=512) 2.36 -> 2.27 ms, N=200k M=256 L=32 9.47 -> 8.11 ms, N=100k M=384 L=16 5.71 -> 4.80 ms,
 //     N=60k M=128 L=32 1.28 -> 1.22 ms; with Wt retained for the backward pass 2.36 -> 2.26, 9.48 -> 8.63, 5.69 -> 5.13 ms;
-//   * with the fill's Kzx as its operand (the other kernel families) for Mp = 256 and 384 only (-10 % / -15 %; a tie at 512,
-//     slower at 128).
+//   * with the fill's Kzx as its operand (the other kernel families) for Mp = 256 ... 512 (multi-group RBF, fp32: N=50k M=512
+//     L=8 2.38 -> 2.31 ms, N=200k M=256 L=8 2.56 -> 2.41 ms, N=7000 M=500 L=20 1.24 -> 1.17 ms; one 128-block: 0.71 -> 0.76, not taken).
 // The choice does not depend on whether Wt is retained: a forward pass gives the same bits either way.  Any of the other
 // three flags names a tile path and gets it; GPZ_SVGP_PANEL_PRODUCTS runs the panel kernel wherever it applies;
 // GPZ_SVGP_PRODUCTS=panel|tiles overrides the library's choice (A/B timing without rebuilding).
@@ -522,7 +522,7 @@ static bool panel_path(const gpz_svgp_problem* p, bool f32, int64_t Mp, int64_t 
   if (!f32 || !panel_supported(Mp, ncp)) return false;
   if (p->flags & (GPZ_SVGP_NARROW_TILES | GPZ_SVGP_MATERIALIZE_KZX | GPZ_SVGP_GENERATE_KZX)) return false;
   if (p->flags & GPZ_SVGP_PANEL_PRODUCTS) return true;
-  return env == 1 || (env == 0 && (panel_generates(p->k.kind, p->d) || Mp == 256 || Mp == 384));
+  return env == 1 || (env == 0 && (panel_generates(p->k.kind, p->d) || Mp >= 256));
 }
 
 template <typename T>

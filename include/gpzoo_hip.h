@@ -140,7 +140,7 @@ int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_l, void* B,
                                      * Wt reaches memory only when retained.  Same Wt bits; mean / scale differ from the
                                      * tile path by fp32 rounding (other summation order of the statistics).  The
                                      * library's own choice (flags == 0) in the first case for every M <= 512 and in the
-                                     * second for 128 < M <= 384; with this flag wherever it applies; ignored elsewhere
+                                     * second for 128 < M <= 512; with this flag wherever it applies; ignored elsewhere
                                      * and next to any of the three flags above. */
 
 typedef struct gpz_svgp_problem {

@@ -104,6 +104,8 @@ PANEL_SHAPES = [
     (2, 4000, 200, 3, True, 1),         # 1-D inputs (RBF)
     (3, 4000, 333, 3, True, 1),         # 1-D inputs (Matern-3/2)
     (5, 6000, 300, 3, True, 2),         # multi-group RBF in fp32: cov.h does not cover it, the panel is read from the fill's Kzx
+    (5, 3000, 512, 2, True, 2),         # ... at four 128-blocks (16 waves), and at one (not the library's own choice there)
+    (5, 3000, 128, 2, True, 2),
 ]
 
 
@@ -129,8 +131,8 @@ def test_panel_kernel_agrees_with_the_tile_kernels(cfg, N, M, L, whitened, d):
     out = _run(c, g, spec, extra, panel_products=True)
     assert ref["path"] in (0, 1) and out["path"] == 4
     # left to itself the library takes the panel kernel where it measured faster -- wherever it computes the covariance
-    # itself (RBF / Matern-3/2), else for 128 < M <= 384 -- retained Wt or not
-    own_choice = cfg in (2, 3) or Mp in (256, 384)
+    # itself (RBF / Matern-3/2), else for 128 < M <= 512 -- retained Wt or not
+    own_choice = cfg in (2, 3) or Mp in (256, 384, 512)
     assert (_run(c, g, spec, extra)["path"] == 4) == own_choice
     assert torch.equal(out["wt_cache"].view(torch.int32)[:nwt], ref["wt_cache"].view(torch.int32)[:nwt])
     torch.testing.assert_close(out["mean"], ref["mean"], rtol=1e-5, atol=1e-5 * float(ref["mean"].abs().max()))
