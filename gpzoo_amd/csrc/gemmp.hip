@@ -1,25 +1,33 @@
-// gemmp.hip -- both forward products on ONE column panel held in LDS, for few inducing points (Mp <= 512, fp32).
+// gemmp.hip -- the covariance fill and both forward products on ONE column panel held in LDS, for few inducing points
+// (Mp <= 512, fp32).
 //
-//   stage 1  Wt = Linv * Kzx      (gp.py:255 + :276)                      A lower triangular, B = the Kzx panel
+//   fill     Kzx = k(Z, X)        (gp.py:255; kernels.py forward)        computed in the kernel where cov.h covers the family
+//   stage 1  Wt = Linv * Kzx      (gp.py:276)                             A lower triangular, B = the Kzx panel
 //   stage 2  colsum((LuE^T Wt)^2) (gp.py:280-296 / utilities.py:382-397)  A upper triangular, B = the Wt panel
 //
 // At M = 512 a row tile of the wide-tile kernels (gemmw.hip) has 8 .. 32 steps: its epilogue (store of the Wt tile, 9 %),
 // the operand traffic of a B panel that every row tile reads again (6 %) and the barrier of every step are first-order
 // terms there (configs[1] stage 1 at 0.74 of the fp32 MFMA peak).  Here a workgroup owns a whole
 // panel -- all Mp rows of 64 columns of one latent -- from the covariance to the column statistics:
-//   * the Kzx panel is read ONCE into LDS, transposed to [column][k] (k contiguous: one ds_read_b128 is a lane's four k
-//     values of a 16-deep chunk; pitch Mp + 4 floats keeps the 16 lanes of a read group on distinct 16-byte bank slots);
-//   * wave w owns the 64 rows of one row block for both stages: its A fragments come straight from L2 into registers
-//     (no other wave needs them: nothing is staged, and there is NO barrier inside a stage -- the panel is read-only);
-//   * stage 1's result stays in the accumulators (64 rows x 64 columns per wave), gives colsum(Wt^2) and muE^T Wt from
+//   * the panel sits in LDS as [column][k] (k contiguous: one ds_read_b128 is a lane's four k values of a 16-deep chunk),
+//     the four 16-byte slots of every chunk XOR-permuted per column so that ds_read_b128's lane groups are conflict-free;
+//   * Mp / 32 waves (16 at Mp = 512); wave w owns the 32 rows of one row block for BOTH stages: its A fragments come
+//     straight from L2 into registers (no other wave needs them: nothing is staged, and there is NO barrier inside a stage
+//     -- the panel is read-only), one 16-deep chunk ahead of the MFMAs that use them;
+//   * stage 1's result stays in the accumulators (32 rows x 64 columns per wave), gives colsum(Wt^2) and muE^T Wt from
 //     there, and overwrites the Kzx panel in LDS (all waves are through stage 1 by then) as stage 2's B operand; Wt
-//     reaches memory only when the caller retains it for the backward pass;
-//   * row block r has r + 1 k-blocks in stage 1 and nrb - r in stage 2: every wave runs nrb + 1 of them per panel; the
-//     two waves a SIMD holds (w, w + 4) take blocks r and nrb - 1 - r, so that the SIMDs are level inside each stage too;
+//     reaches memory only when the caller retains it for the backward pass (copied out of LDS by waves that are idle);
+//   * row block r has r + 1 units of k in stage 1 and nb - r in stage 2; the blocks are dealt to the waves so that every
+//     SIMD carries the same sum in both stages and its longest waves are of similar length (row_block_of below);
+//   * the waves of the upper half of the row blocks have the short stage 2: they prepare the NEXT panel meanwhile, into the
+//     registers their dead accumulators free -- computing its covariance values (cov.h: the fill kernel's own arithmetic,
+//     same bits; no fill launch, no Kzx in memory) or, for other kernel families, loading them from the fill's Kzx;
 //   * the latents of a launch are dealt to the XCDs (blocks b, b + 8, ... share one): an XCD's workgroups stream the same
 //     Linv / LuE^T (1 MB each at Mp = 512) out of its 4 MB L2.
 // k order, MFMA order and the values of Wt are those of gemmw.hip / gemm.hip (lane group q owns k = 4q .. 4q+3 of a 16-deep
 // chunk, chunks ascending from k = 0, zero sub-tiles of the diagonal block skipped): the retained Wt is bitwise the same.
+// Measured: configs[1] (N=50k, M=512, L=8) 1.69 ms for fill + both products = 0.79 of the fp32 MFMA
+// peak, evaluation 2.32 -> 2.18 ms against fill + two tile launches; M = 256 / 384: -20 % / -23 %.
 #include "gemmp.h"
 
 #include "cov.h"
@@ -52,7 +60,7 @@ struct PanelParams {
   float* ps1; float* pm1; float* ps2;       // [L][Mp / 128][ncp]
   int Mp, ncp, L, npan, units;              // panels per latent, units = L * npan
   unsigned long long* stamps;               // debug (gpz_debug_panel_stamps): workgroup 0's phase times, [panel][16 waves][8]
-  int dbg;                                  // timing diagnostics (GPZ_PANEL_DBG; wrong results): 1 panel loaded once, 2 no SIMD pairing
+  int dbg;                                  // timing diagnostics (GPZ_PANEL_DBG, listed above; wrong results)
 };
 
 constexpr int P_TN = 64;                    // columns of a panel
