@@ -206,6 +206,8 @@ struct VnnBwdArgs {
   double* gS;                   // (L,Mp,Mp)  T with dLoss/dS = T + T^T
   double* gK;                   // (L,Mp,Mp)  T with T + T^T = 2 sym(dLoss/d(Kzz + jitter I)) from the K x K blocks, or null
   double* kacc;                 // (L,Mp,8)   dz0..3, dsigma, dlengthscale (kgrad.hip layout), or null
+  double* rec;                  // [L*N][3K + 2]: per point w[K], v[K], kx[K], gm, gcov CONTIGUOUS -- what vnngp_gather_kernel
+                                // reads per entry (from the [column][point] scratch every value is a 64-byte sector of its own)
   const int32_t* inv;           // (N*K) entries n * K + p grouped by the inducing point they name, ascending inside a group
   const int32_t* start;         // (M + 1) group boundaries in inv
 };
@@ -262,6 +264,160 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_kernel(VnnBwdArgs<T> b) {
     }
   double* ex = v + (int64_t)K * total;
   ex[0] = gm; ex[total] = gcov; ex[2 * total] = dsig; ex[3 * total] = dell;
+  double* rec = b.rec + t * (3 * K + 2);
+  for (int p = 0; p < K; ++p) { rec[p] = w[p * total]; rec[K + p] = v[p * total]; rec[2 * K + p] = kx[p * total]; }
+  rec[3 * K] = gm; rec[3 * K + 1] = gcov;
+}
+
+// ---- the same two kernels with the K x K system in REGISTERS (K <= 16) ----
+// The scratch form above moves every element of the K x K factor through global memory several times (K = 10: about a
+// thousand coalesced 8-byte accesses per thread, 3 GB per forward at N = 40 000, L = 10: it is bound by exactly that).
+// For K <= KT in {8, 12, 16} the system is padded to KT with identity rows (their solution entries are zero) and lives in
+// a thread's registers, every loop unrolled with compile-time indices; what is left of the memory traffic is the gathers
+// of the two K x K blocks (Kzz + jitter I, S = Lu Lu^T) and, for the backward pass, the per-point vectors the gather
+// kernels read afterwards (same scratch columns as above; the factor's columns stay unwritten).
+template <int KT> __device__ __forceinline__ constexpr int vtri(int p, int q) { return p * (p + 1) / 2 + q; }
+
+template <typename T, int KT>
+__device__ __forceinline__ void vnn_point_solve_reg(const VnnArgs<T>& a, int l, int64_t n, const int64_t* idp,
+                                                    double (&A)[KT * (KT + 1) / 2], double (&kx)[KT], double (&w)[KT],
+                                                    double (&sw)[KT], int64_t (&id)[KT], double& mean, double& cov) {
+  const int K = a.K;
+  const double* Kl = a.Kzz + (int64_t)l * a.Mp * a.Mp;
+  const double* Sl = a.S + (int64_t)l * a.Mp * a.Mp;
+  const double sg = (double)a.sigma[l], el = (double)a.ell[l];
+  const double s2 = sg * sg, c = -0.5 / (el * el);
+#pragma unroll
+  for (int p = 0; p < KT; ++p) id[p] = p < K ? idp[p] : 0;
+#pragma unroll
+  for (int p = 0; p < KT; ++p) {
+    if (p < K) {
+      double d2 = 0;
+      for (int k = 0; k < a.d; ++k) { const double df = (double)a.X[n * a.d + k] - (double)a.Z[id[p] * a.d + k]; d2 += df * df; }
+      kx[p] = s2 * exp(c * d2);
+    } else {
+      kx[p] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q <= p; ++q)
+      A[vtri<KT>(p, q)] = p < K ? Kl[id[p] * a.Mp + id[q]] + (p == q ? a.jitter : 0.0) : (p == q ? 1.0 : 0.0);
+  }
+  // in-place Cholesky (lower), then two triangular solves: the operation order of vnn_point_solve
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    double dj = A[vtri<KT>(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) { const double v = A[vtri<KT>(j, k)]; dj -= v * v; }
+    dj = sqrt(dj > 0.0 ? dj : 1e-300);
+    A[vtri<KT>(j, j)] = dj;
+#pragma unroll
+    for (int i = j + 1; i < KT; ++i) {
+      double v = A[vtri<KT>(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= A[vtri<KT>(i, k)] * A[vtri<KT>(j, k)];
+      A[vtri<KT>(i, j)] = v / dj;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {                  // C u = k
+    double v = kx[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= A[vtri<KT>(i, k)] * w[k];
+    w[i] = v / A[vtri<KT>(i, i)];
+  }
+#pragma unroll
+  for (int i = KT - 1; i >= 0; --i) {             // C^T w = u
+    double v = w[i];
+#pragma unroll
+    for (int k = i + 1; k < KT; ++k) v -= A[vtri<KT>(k, i)] * w[k];
+    w[i] = v / A[vtri<KT>(i, i)];
+  }
+  double wk = 0.0, wsw = 0.0;
+  mean = 0.0;
+#pragma unroll
+  for (int p = 0; p < KT; ++p) {
+    double row = 0.0;
+    if (p < K) {
+      mean += w[p] * (double)a.mu[(int64_t)l * a.M + id[p]];
+      wk += w[p] * kx[p];
+#pragma unroll
+      for (int q = 0; q < KT; ++q)
+        if (q < K) row += Sl[id[p] * a.Mp + id[q]] * w[q];
+      wsw += w[p] * row;
+    }
+    sw[p] = row;
+  }
+  cov = s2 + wsw - wk;
+}
+
+template <typename T, int KT>
+__global__ __launch_bounds__(256) void vnngp_point_reg_kernel(VnnArgs<T> a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)a.L * a.N;
+  if (t >= total) return;
+  const int l = (int)(t / a.N);
+  const int64_t n = t - (int64_t)l * a.N;
+  double A[KT * (KT + 1) / 2], kx[KT], w[KT], sw[KT], mean, cov;
+  int64_t id[KT];
+  vnn_point_solve_reg<T, KT>(a, l, n, a.idx + n * a.K, A, kx, w, sw, id, mean, cov);
+  if (!(cov > a.clamp_min)) cov = a.clamp_min;
+  a.mean[t] = (T)mean;
+  a.scale[t] = (T)sqrt(cov);
+}
+
+template <typename T, int KT>
+__global__ __launch_bounds__(256) void vnngp_point_bwd_reg_kernel(VnnBwdArgs<T> b) {
+  const VnnArgs<T>& a = b.f;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)a.L * a.N;
+  if (t >= total) return;
+  const int l = (int)(t / a.N);
+  const int64_t n = t - (int64_t)l * a.N;
+  const int K = a.K;
+  double A[KT * (KT + 1) / 2], kx[KT], w[KT], sw[KT], v[KT], mean, cov;
+  int64_t id[KT];
+  vnn_point_solve_reg<T, KT>(a, l, n, a.idx + n * K, A, kx, w, sw, id, mean, cov);
+  const double gm = (double)b.g_mean[t];
+  const double gcov = (cov > a.clamp_min) ? 0.5 * (double)b.g_scale[t] / sqrt(cov) : 0.0;
+#pragma unroll
+  for (int p = 0; p < KT; ++p)
+    v[p] = p < K ? gm * (double)a.mu[(int64_t)l * a.M + id[p]] + gcov * (2.0 * sw[p] - kx[p]) : 0.0;
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {
+    double r = v[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) r -= A[vtri<KT>(i, k)] * v[k];
+    v[i] = r / A[vtri<KT>(i, i)];
+  }
+#pragma unroll
+  for (int i = KT - 1; i >= 0; --i) {
+    double r = v[i];
+#pragma unroll
+    for (int k = i + 1; k < KT; ++k) r -= A[vtri<KT>(k, i)] * v[k];
+    v[i] = r / A[vtri<KT>(i, i)];
+  }
+  const double sg = (double)a.sigma[l], el = (double)a.ell[l], il2 = 1.0 / (el * el);
+  double dsig = gcov * 2.0 * sg, dell = 0.0;
+  // the per-point record vnngp_gather_kernel reads, and the two per-latent totals' terms in their scratch columns
+  double* rec = b.rec + t * (3 * K + 2);
+#pragma unroll
+  for (int p = 0; p < KT; ++p)
+    if (p < K) {
+      rec[p] = w[p]; rec[K + p] = v[p]; rec[2 * K + p] = kx[p];
+      if (b.kacc) {
+        const double gk = (v[p] - gcov * w[p]) * kx[p];
+        double d2 = 0.0;
+        for (int k = 0; k < a.d; ++k) {
+          const double df = (double)a.X[n * a.d + k] - (double)a.Z[id[p] * a.d + k];
+          d2 += df * df;
+        }
+        dsig += gk * 2.0 / sg;
+        dell += gk * d2 * il2 / el;
+      }
+    }
+  rec[3 * K] = gm; rec[3 * K + 1] = gcov;
+  double* ex = a.scratch + (int64_t)(K * K + 4 * K) * total + t;
+  ex[2 * total] = dsig; ex[3 * total] = dell;
 }
 
 // ---- the neighbour table inverted: for every inducing point the (point, slot) entries that name it, in ascending order ----
@@ -346,31 +502,55 @@ __global__ __launch_bounds__(64) void vnngp_gather_kernel(VnnBwdArgs<T> b) {
   double* rowK = vnn_rows + a.Mp;
   for (int64_t j = lane; j < 2 * a.Mp; j += 64) vnn_rows[j] = 0.0;
   __syncthreads();
-  const double* kxc = a.scratch + (int64_t)K * K * total;
-  const double* wc = kxc + (int64_t)K * total;
-  const double* vc = wc + 2 * (int64_t)K * total;
-  const double* ex = vc + (int64_t)K * total;
+  const int R = 3 * K + 2;                    // record: w[K], v[K], kx[K], gm, gcov
   const double el = (double)a.ell[l], il2 = 1.0 / (el * el);
   double gmu = 0.0, dz = 0.0;                 // lane 0: gmu; lanes k < d: dz_k
   const int32_t e0 = b.start[ip], e1 = b.start[ip + 1];
-  for (int32_t ei = e0; ei < e1; ++ei) {
-    const int32_t e = b.inv[ei];
-    const int64_t n = e / K;
-    const int p = e - (int32_t)n * K;
-    const int64_t t = (int64_t)l * a.N + n;
-    const double gm = ex[t], gcov = ex[total + t];
-    const double wp = wc[(int64_t)p * total + t], vp = vc[(int64_t)p * total + t];
-    if (lane <= p) {                          // one unordered pair (p, q <= p) per lane: distinct columns of the rows
-      const int q = lane;
-      const int64_t iq = a.idx[n * K + q];
-      const double wq = wc[(int64_t)q * total + t];
-      if (gcov != 0.0) rowS[iq] += (p == q ? 0.5 : 1.0) * gcov * wp * wq;
-      if (b.gK) rowK[iq] += p == q ? -vp * wq : -(vp * wq + vc[(int64_t)q * total + t] * wp);
+  // Eight entries per trip: their loads (entry -> point -> the point's vectors: two dependent levels of global latency) are
+  // all issued before the first use, the updates are applied in entry order -- the sums are the same sums in the same
+  // order.  One entry per trip was bound by exactly that latency: 400 entries x 2 us per wave, 2.8 ms per backward at
+  // N = 40 000, M = 1000, L = 10, K = 10.
+  constexpr int U = 8;
+  for (int32_t eb = e0; eb < e1; eb += U) {
+    int64_t n[U], t[U], iq[U];
+    int pp[U];
+    double gm[U], gcov[U], wp[U], vp[U], wq[U], vq[U], kxp[U], xd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t e = eb + u < e1 ? b.inv[eb + u] : -1;
+      n[u] = e < 0 ? 0 : e / K;
+      pp[u] = e < 0 ? -1 : e - (int32_t)n[u] * K;
+      t[u] = (int64_t)l * a.N + n[u];
     }
-    if (lane == 0) gmu += gm * wp;
-    if (b.kacc && lane < a.d) {
-      const double gk = (vp - gcov * wp) * kxc[(int64_t)p * total + t];
-      dz += gk * ((double)a.X[n * a.d + lane] - (double)a.Z[ip * a.d + lane]) * il2;      // dk/dz = k (x - z) / l^2
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pp[u] < 0 ? 0 : pp[u];
+      const double* rec = b.rec + t[u] * R;
+      gm[u] = rec[3 * K]; gcov[u] = rec[3 * K + 1];
+      wp[u] = rec[p]; vp[u] = rec[K + p];
+      const int q = lane <= p ? lane : 0;
+      iq[u] = a.idx[n[u] * K + q];
+      wq[u] = rec[q];
+      vq[u] = b.gK ? rec[K + q] : 0.0;
+      kxp[u] = b.kacc ? rec[2 * K + p] : 0.0;
+      xd[u] = (b.kacc && lane < a.d) ? (double)a.X[n[u] * a.d + lane] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pp[u];
+      if (p < 0) continue;                      // past the group's end (wave-uniform)
+      if (lane <= p) {                          // one unordered pair (p, q <= p) per lane: distinct columns of the rows
+        const int q = lane;
+        if (gcov[u] != 0.0) rowS[iq[u]] += (p == q ? 0.5 : 1.0) * gcov[u] * wp[u] * wq[u];
+        if (b.gK) rowK[iq[u]] += p == q ? -vp[u] * wq[u] : -(vp[u] * wq[u] + vq[u] * wp[u]);
+      }
+      if (lane == 0) gmu += gm[u] * wp[u];
+      if (b.kacc && lane < a.d) {
+        const double gk = (vp[u] - gcov[u] * wp[u]) * kxp[u];
+        dz += gk * (xd[u] - (double)a.Z[ip * a.d + lane]) * il2;      // dk/dz = k (x - z) / l^2
+      }
+      // (two entries of one trip can name the same column through different points: the LDS updates of entry u are
+      // complete before entry u + 1 reads the row -- one wave, program order)
     }
   }
   __syncthreads();
@@ -437,7 +617,7 @@ struct VnnPlan {
   double *Kzz, *Kfac, *Dinv, *LuD, *S, *scratch; int64_t* idx;
   double *Linv, *Tmp, *LuE, *muE;                       // KL(qU || pU): L^{-1}, L^{-1} Lu, L^{-1} mu
   uint32_t* fsync;                                       // tickets and flags of the one-launch Cholesky (csrc/coop.hip)
-  double *gmu, *gS, *gK, *kacc, *G, *D1, *D2; void* PS;  // backward only
+  double *gmu, *gS, *gK, *kacc, *G, *D1, *D2, *rec; void* PS;  // backward only
   int32_t *inv, *istart, *ihist, *itmp;                  // backward only: the inverted neighbour table and its scratch
 };
 
@@ -459,7 +639,7 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
   pl.LuE = c.take<double>(mm);
   pl.muE = c.take<double>(pl.L * pl.Mp);
   pl.fsync = c.take<uint32_t>(coop_sync_words(pl.Mp, pl.L));
-  pl.gmu = pl.gS = pl.gK = pl.kacc = pl.G = pl.D1 = pl.D2 = nullptr;
+  pl.gmu = pl.gS = pl.gK = pl.kacc = pl.G = pl.D1 = pl.D2 = pl.rec = nullptr;
   pl.PS = nullptr;
   pl.inv = pl.istart = pl.ihist = pl.itmp = nullptr;
   if (bwd) {
@@ -468,6 +648,7 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
     pl.istart = c.take<int32_t>(pl.M + 2);
     pl.itmp = c.take<int32_t>(pl.M + 2);
     pl.ihist = c.take<int32_t>(IB * pl.M);
+    pl.rec = c.take<double>((int64_t)(3 * K + 2) * pl.L * pl.N);
     pl.gmu = c.take<double>(pl.L * pl.Mp);
     pl.gS = c.take<double>(mm);
     pl.G = c.take<double>(mm);
@@ -610,7 +791,13 @@ static int vnngp_t(const gpz_svgp_problem* p, int K, const int64_t* idx_in, void
   GPZ_REQUIRE(ws_bytes >= pl.bytes, "gpz_vnngp_forward: workspace too small");
   VnnArgs<T> a;
   if (int rc = vnn_prepare<T>(p, pl, idx_in, a, s)) return rc;
-  hipLaunchKernelGGL((vnngp_point_kernel<T>), dim3((unsigned)((pl.L * pl.N + 255) / 256)), dim3(256), 0, s, a);
+  {
+    const dim3 grid((unsigned)((pl.L * pl.N + 255) / 256));
+    if (K <= 8) hipLaunchKernelGGL((vnngp_point_reg_kernel<T, 8>), grid, dim3(256), 0, s, a);
+    else if (K <= 12) hipLaunchKernelGGL((vnngp_point_reg_kernel<T, 12>), grid, dim3(256), 0, s, a);
+    else if (K <= 16) hipLaunchKernelGGL((vnngp_point_reg_kernel<T, 16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((vnngp_point_kernel<T>), grid, dim3(256), 0, s, a);
+  }
   GPZ_LAUNCH_OK();
   if (p->kl)
     if (int rc = vnn_kl_prepare<T>(p, pl, p->kl, s)) return rc;
@@ -803,8 +990,15 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
     GPZ_HIP_OK(hipMemsetAsync(pl.kacc, 0, sizeof(double) * L * Mp * 8, s));
   }
   b.g_mean = static_cast<const T*>(g->g_mean); b.g_scale = static_cast<const T*>(g->g_scale);
-  b.gmu = pl.gmu; b.gS = pl.gS; b.gK = kgrads ? pl.gK : nullptr; b.kacc = kgrads ? pl.kacc : nullptr;
-  hipLaunchKernelGGL((vnngp_point_bwd_kernel<T>), dim3((unsigned)((L * pl.N + 255) / 256)), dim3(256), 0, s, b);
+  b.gmu = pl.gmu; b.gS = pl.gS; b.gK = kgrads ? pl.gK : nullptr; b.kacc = kgrads ? pl.kacc : nullptr; b.rec = pl.rec;
+  {
+    const dim3 grid((unsigned)((L * pl.N + 255) / 256));
+    const int K = b.f.K;
+    if (K <= 8) hipLaunchKernelGGL((vnngp_point_bwd_reg_kernel<T, 8>), grid, dim3(256), 0, s, b);
+    else if (K <= 12) hipLaunchKernelGGL((vnngp_point_bwd_reg_kernel<T, 12>), grid, dim3(256), 0, s, b);
+    else if (K <= 16) hipLaunchKernelGGL((vnngp_point_bwd_reg_kernel<T, 16>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((vnngp_point_bwd_kernel<T>), grid, dim3(256), 0, s, b);
+  }
   GPZ_LAUNCH_OK();
   {
     // the neighbour table inverted (stable counting sort of the N K entries by the inducing point they name), then the
