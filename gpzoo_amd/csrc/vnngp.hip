@@ -206,7 +206,7 @@ struct VnnBwdArgs {
   double* gS;                   // (L,Mp,Mp)  T with dLoss/dS = T + T^T
   double* gK;                   // (L,Mp,Mp)  T with T + T^T = 2 sym(dLoss/d(Kzz + jitter I)) from the K x K blocks, or null
   double* kacc;                 // (L,Mp,8)   dz0..3, dsigma, dlengthscale (kgrad.hip layout), or null
-  double* rec;                  // [L*N][3K + 2]: per point w[K], v[K], kx[K], gm, gcov CONTIGUOUS -- what vnngp_gather_kernel
+  T* rec;                       // [L*N][3K + 2], in the problem's precision: per point w[K], v[K], kx[K], gm, gcov CONTIGUOUS -- what vnngp_gather_kernel
                                 // reads per entry (from the [column][point] scratch every value is a 64-byte sector of its own)
   const int32_t* inv;           // (N*K) entries n * K + p grouped by the inducing point they name, ascending inside a group
   const int32_t* start;         // (M + 1) group boundaries in inv
@@ -264,9 +264,9 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_kernel(VnnBwdArgs<T> b) {
     }
   double* ex = v + (int64_t)K * total;
   ex[0] = gm; ex[total] = gcov; ex[2 * total] = dsig; ex[3 * total] = dell;
-  double* rec = b.rec + t * (3 * K + 2);
-  for (int p = 0; p < K; ++p) { rec[p] = w[p * total]; rec[K + p] = v[p * total]; rec[2 * K + p] = kx[p * total]; }
-  rec[3 * K] = gm; rec[3 * K + 1] = gcov;
+  T* rec = b.rec + t * (3 * K + 2);
+  for (int p = 0; p < K; ++p) { rec[p] = (T)w[p * total]; rec[K + p] = (T)v[p * total]; rec[2 * K + p] = (T)kx[p * total]; }
+  rec[3 * K] = (T)gm; rec[3 * K + 1] = (T)gcov;
 }
 
 // ---- the same two kernels with the K x K system in REGISTERS (K <= 16) ----
@@ -399,11 +399,11 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_reg_kernel(VnnBwdArgs<T> 
   const double sg = (double)a.sigma[l], el = (double)a.ell[l], il2 = 1.0 / (el * el);
   double dsig = gcov * 2.0 * sg, dell = 0.0;
   // the per-point record vnngp_gather_kernel reads, and the two per-latent totals' terms in their scratch columns
-  double* rec = b.rec + t * (3 * K + 2);
+  T* rec = b.rec + t * (3 * K + 2);
 #pragma unroll
   for (int p = 0; p < KT; ++p)
     if (p < K) {
-      rec[p] = w[p]; rec[K + p] = v[p]; rec[2 * K + p] = kx[p];
+      rec[p] = (T)w[p]; rec[K + p] = (T)v[p]; rec[2 * K + p] = (T)kx[p];
       if (b.kacc) {
         const double gk = (v[p] - gcov * w[p]) * kx[p];
         double d2 = 0.0;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_reg_kernel(VnnBwdArgs<T> 
         dell += gk * d2 * il2 / el;
       }
     }
-  rec[3 * K] = gm; rec[3 * K + 1] = gcov;
+  rec[3 * K] = (T)gm; rec[3 * K + 1] = (T)gcov;
   double* ex = a.scratch + (int64_t)(K * K + 4 * K) * total + t;
   ex[2 * total] = dsig; ex[3 * total] = dell;
 }
@@ -525,14 +525,14 @@ __global__ __launch_bounds__(64) void vnngp_gather_kernel(VnnBwdArgs<T> b) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int p = pp[u] < 0 ? 0 : pp[u];
-      const double* rec = b.rec + t[u] * R;
-      gm[u] = rec[3 * K]; gcov[u] = rec[3 * K + 1];
-      wp[u] = rec[p]; vp[u] = rec[K + p];
+      const T* rec = b.rec + t[u] * R;
+      gm[u] = (double)rec[3 * K]; gcov[u] = (double)rec[3 * K + 1];
+      wp[u] = (double)rec[p]; vp[u] = (double)rec[K + p];
       const int q = lane <= p ? lane : 0;
       iq[u] = a.idx[n[u] * K + q];
-      wq[u] = rec[q];
-      vq[u] = b.gK ? rec[K + q] : 0.0;
-      kxp[u] = b.kacc ? rec[2 * K + p] : 0.0;
+      wq[u] = (double)rec[q];
+      vq[u] = b.gK ? (double)rec[K + q] : 0.0;
+      kxp[u] = b.kacc ? (double)rec[2 * K + p] : 0.0;
       xd[u] = (b.kacc && lane < a.d) ? (double)a.X[n[u] * a.d + lane] : 0.0;
     }
 #pragma unroll
@@ -990,7 +990,7 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
     GPZ_HIP_OK(hipMemsetAsync(pl.kacc, 0, sizeof(double) * L * Mp * 8, s));
   }
   b.g_mean = static_cast<const T*>(g->g_mean); b.g_scale = static_cast<const T*>(g->g_scale);
-  b.gmu = pl.gmu; b.gS = pl.gS; b.gK = kgrads ? pl.gK : nullptr; b.kacc = kgrads ? pl.kacc : nullptr; b.rec = pl.rec;
+  b.gmu = pl.gmu; b.gS = pl.gS; b.gK = kgrads ? pl.gK : nullptr; b.kacc = kgrads ? pl.kacc : nullptr; b.rec = reinterpret_cast<T*>(pl.rec);
   {
     const dim3 grid((unsigned)((L * pl.N + 255) / 256));
     const int K = b.f.K;
