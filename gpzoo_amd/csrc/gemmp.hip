@@ -435,24 +435,30 @@ bool panel_supported(int64_t Mp, int64_t ncp) {
 template <int NB, int GEN>
 static int launch_t(const PanelParams& p, bool store, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)P_TN * (p.Mp + 16) + 3 * NB * 64);
-  static std::once_flag once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(once, [&] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, false, GEN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr_rc == hipSuccess)
-      attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, true, GEN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  });
-  GPZ_HIP_OK(attr_rc);
-  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
-      n = 256;
-    cus = n;
+  // Dynamic LDS above 64 KB is an opt-in per kernel function AND per device (a process may drive several: the attribute set
+  // on the first one does not reach the others), as is the CU count the persistent grid is sized by.
+  struct PerDevice { bool attr = false; int cus = 0; };
+  static PerDevice seen[64];
+  static std::mutex mu;
+  int dev = 0;
+  GPZ_HIP_OK(hipGetDevice(&dev));
+  int cus = 256;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    PerDevice& d = seen[dev & 63];
+    if (!d.attr) {
+      GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, false, GEN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_kernel<NB, true, GEN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+      d.cus = n;
+      d.attr = true;
+    }
+    cus = d.cus;
   }
+  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   int wgs = cus * (per_cu > 2 ? 2 : per_cu);
   wgs -= wgs % 8;
   if (store) hipLaunchKernelGGL((panel_kernel<NB, true, GEN>), dim3(wgs), dim3(64 * NB), lds, s, p);
