@@ -90,8 +90,89 @@ def parse():
                          "csrc/gemmp.hip): the selectable path of DESIGN.md section 5, not the default")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="spots in the CPU-baseline sample (SURVEY §8d: 8192)")
     ap.add_argument("--with-backward", action="store_true",
-                    help="also time one forward + backward (mu, Lu gradients) pass, outside the timed region")
+                    help="(kept for old command lines: the training legs now run by default on one GPU)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the legs outside the timed region: forward + backward of this workload and the "
+                         "BASELINE configs[1] record (`small_m`); they never run with more than one rank")
     return ap.parse_args()
+
+
+# N-sized products of L*M^2*N flops (triangular operand counted once) in one training step since round 5:
+# forward Wt = Linv*Kzx and colsum((LuE^T Wt)^2); backward, mu / Lu only: H += Wt diag(gv2) Wt^T (lower tiles) -- ONE
+# product (rounds 1-4: P-bar and W P-bar^T, two); all parameters add P-bar, W-bar = LuE*P-bar - ..., K-bar_x = Linv^T W-bar
+# (the M x M gradient of the factor is algebra on H: DESIGN.md section 5 "Backward").
+TRAIN_PRODUCTS = {"mu_Lu": 3, "all_parameters": 6}
+
+
+def train_leg(ops, spec, g, c, extra, chunk, reps=2) -> dict:
+    """ms of one forward + backward pass as the gpzoo modules run a training step (gpzoo_amd/gp.py), per gradient set:
+    the factor of Kzz and the q(U) operands the forward prepared are handed to the backward pass of the same call in a
+    per-call buffer (never kept across calls), Wt of every chunk stays in HBM between the two.  Last of `reps` runs."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {}
+    for mode, kg in (("mu_Lu", False), ("all_parameters", True)):
+        for _ in range(reps):
+            ev0.record()
+            handoff = ops.FactorCache()
+            o = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
+                                 chunk=chunk, want_Lu=False, retain_wt=1.0 / 3, cache=handoff, **extra)
+            gmean = (o["mean"] - g["y"]) / c["noise_sd"] ** 2      # d(-ELBO)/dmean of the Gaussian closed form
+            gscale = o["scale"] / c["noise_sd"] ** 2                 # d(-ELBO)/dscale
+            ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], gmean,
+                              gscale, o["scale"], chunk=chunk, kernel_grads=kg, wt_cache=o.pop("wt_cache", None),
+                              cache=handoff, trust_cache=True, trust_qu=True, **extra)
+            ev1.record()
+            torch.cuda.synchronize()
+            out[mode] = ev0.elapsed_time(ev1)
+    return out
+
+
+def train_roofline(train_ms: dict, L: int, M: int, N: int, dname: str) -> dict:
+    prod = L * float(M) * M * N
+    r = {}
+    for mode, nprod in TRAIN_PRODUCTS.items():
+        fl = nprod * prod
+        r[mode] = {"bound": "mfma", "products_of_L_M2_N_flops": nprod, "algorithmic_flops": fl, "ms": train_ms[mode],
+                   "achieved_TFLOPs": fl / (train_ms[mode] * 1e-3) / 1e12, "peak_TFLOPs": PEAK[dname],
+                   "frac": fl / (train_ms[mode] * 1e-3) / 1e12 / PEAK[dname],
+                   "mfma_floor_ms": fl / (PEAK[dname] * 1e12) * 1e3}
+    return r
+
+
+def small_m_record(ops, dev) -> dict:
+    """BASELINE configs[1] (N=50 000, M=512, L=8, RBF, fp32) next to the headline line: ms per ELBO evaluation, of its
+    factorisation (Cholesky + inverse, fp64), and of a forward + backward pass -- the regime the reference's notebooks
+    train in.  Outside the timed region; about a second."""
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import make_config
+    c = make_config(2)
+    g = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in c.items()}
+    spec, extra = spec_for_config(g, dev)
+    N, M, L = c["X"].shape[0], c["Z"].shape[0], c["mu"].shape[0]
+
+    def ev():
+        return ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], y=g["y"],
+                                noise_sd=c["noise_sd"], want_Lu=False, **extra)
+    for _ in range(5):
+        ev()
+    torch.cuda.synchronize()
+    ops.profile_enable(True)
+    steps = 20
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o = ev()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    prof = ops.profile_read()
+    ops.profile_enable(False)
+    tr = train_leg(ops, spec, g, c, extra, 0, reps=3)
+    return {"workload": "BASELINE configs[1]: 2-D synthetic spatial, N=%d, M=%d, L=%d, %s, f32" % (N, M, L, c["kind"]),
+            "evaluation_ms": ms, "evals_per_s": 1e3 / ms, "elbo": float(o["elbo"]),
+            "evaluation_roofline": {"bound": "mfma", "algorithmic_flops": 2.0 * L * M * M * N,
+                                    "achieved_TFLOPs": 2.0 * L * M * M * N / (ms * 1e-3) / 1e12, "peak_TFLOPs": PEAK["f32"],
+                                    "frac": 2.0 * L * M * M * N / (ms * 1e-3) / 1e12 / PEAK["f32"]},
+            "factor_ms": prof["potrf_all"][0] / steps, "products_ms": prof["stage1"][0] / steps,
+            "forward_backward_ms": tr, "forward_backward_roofline": train_roofline(tr, L, M, N, "f32")}
 
 
 def usable_cpus() -> tuple:
@@ -383,26 +464,11 @@ def main():
     t = float(tmax)
     elbo = float(elbo)
 
-    train_ms = None
-    if a.with_backward:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        train_ms = {}
-        for mode, kg in (("mu_Lu", False), ("all_parameters", True)):
-            for rep in range(2):
-                ev0.record()
-                # as the gpzoo modules run a training step (gpzoo_amd/gp.py): the factor of Kzz and the q(U) operands the
-                # forward prepared are handed to the backward pass of the same call in a per-call buffer, never kept across calls
-                handoff = ops.FactorCache()
-                o = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
-                                     chunk=a.chunk, want_Lu=False, retain_wt=1.0 / 3, cache=handoff, **extra)   # Wt stays in HBM
-                gmean = (o["mean"] - g["y"]) / c["noise_sd"] ** 2      # d(-ELBO)/dmean of the Gaussian closed form
-                gscale = o["scale"] / c["noise_sd"] ** 2                 # d(-ELBO)/dscale
-                ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], gmean,
-                                  gscale, o["scale"], chunk=a.chunk, kernel_grads=kg, wt_cache=o.pop("wt_cache", None),
-                                  cache=handoff, trust_cache=True, trust_qu=True, **extra)
-                ev1.record()
-                torch.cuda.synchronize()
-                train_ms[mode] = ev0.elapsed_time(ev1)
+    train_ms = small_m = None
+    if world == 1 and not grouped and not a.no_extra_legs:
+        train_ms = train_leg(ops, spec, g, c, extra, a.chunk)
+        if cfg_id == 3 and (a.N, a.M, a.L) == (None, None, None):
+            small_m = small_m_record(ops, dev)
 
     if rank == 0:
         Mp = (M + 127) // 128 * 128
@@ -507,18 +573,9 @@ def main():
         }
         if train_ms is not None:
             res["forward_backward_ms"] = train_ms
-            # roofline of the training step: every big product is L*M^2*N flops (triangular operand counted once).
-            # forward: Wt = Linv*Kzx and colsum((Lu^T Wt)^2); mu/Lu backward adds P-bar = (Lu^T W) diag(.) and the
-            # (M x n)(n x M) lower-tile accumulation; all parameters add W-bar, K-bar_x = Linv^T W-bar and tril(K-bar_x W^T).
-            prod = Lper * float(M) * M * N
-            res["forward_backward_roofline"] = {}
-            for mode, nprod in (("mu_Lu", 4), ("all_parameters", 7)):
-                fl = nprod * prod
-                res["forward_backward_roofline"][mode] = {
-                    "bound": "mfma", "products_of_L_M2_N_flops": nprod, "algorithmic_flops": fl,
-                    "ms": train_ms[mode], "achieved_TFLOPs": fl / (train_ms[mode] * 1e-3) / 1e12,
-                    "peak_TFLOPs": PEAK[dname], "frac": fl / (train_ms[mode] * 1e-3) / 1e12 / PEAK[dname],
-                    "mfma_floor_ms": fl / (PEAK[dname] * 1e12) * 1e3}
+            res["forward_backward_roofline"] = train_roofline(train_ms, Lper, M, N, dname)
+        if small_m is not None:
+            res["small_m"] = small_m
         if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline(cfg_id, c, a.cpu_sample)
             # parity on the driver-run line: the HIP path on the very slice the CPU port just evaluated

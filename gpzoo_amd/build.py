@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpzoo_hip.so")
 SOURCES = ["runtime.hip", "kfill.hip", "gemm.hip", "gemmw.hip", "gemmp.hip", "diag128.hip", "coop.hip", "factor.hip", "kgrad.hip", "poisson.hip", "svgp.hip", "vnngp.hip", "collective.hip"]
-HEADERS = ["common.h", "gemm.h", "cov.h", "gemmw.h", "diag128.h", "factor.h", os.path.join("..", "..", "include", "gpzoo_hip.h")]
+HEADERS = ["common.h", "gemm.h", "cov.h", "gemmw.h", "gemmp.h", "diag128.h", "factor.h", os.path.join("..", "..", "include", "gpzoo_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 
 

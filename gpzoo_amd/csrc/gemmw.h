@@ -40,13 +40,16 @@ struct WideArgs {
 bool wide_product_supported(int64_t Mp, int64_t ncp);
 int wide_product_launch(const WideArgs& a, hipStream_t s);
 
-// C (L, Mp, Mp) += A (L, Mp, K) * B (L, Mp, K)^T, lower 128-tiles only (the tiles on the diagonal are written whole), fp32:
-// the backward pass's gradient accumulations over an N-chunk.
+// C (L, Mp, Mp) += A (L, Mp, K) * diag(w) * B (L, Mp, K)^T, lower 128-tiles only (the tiles on the diagonal are written
+// whole), fp32: the backward pass's gradient accumulation over an N-chunk (A == B: H += W diag(gv2) W^T).  w (L, K): column
+// weights, or null.  gate: device word -- when it is zero the launch leaves C alone (the rarely needed correction for
+// columns at the variance clamp), or null.
 bool wide_nt_supported(int64_t Mp, int64_t K);
 // With few tiles (small M, few latents) the k extent is cut into pieces that run side by side and are added up in a fixed
 // order; `scratch`: wide_nt_scratch_floats(Mp, K, L) floats (0: never cut), or null: one workgroup per tile walks all of k.
 int wide_nt_pieces(int64_t Mp, int64_t K, int L);
 size_t wide_nt_scratch_floats(int64_t Mp, int64_t K, int L);
-int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s, float* scratch = nullptr);
+int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s, float* scratch = nullptr,
+                   const float* w = nullptr, const int32_t* gate = nullptr);
 
 }  // namespace gpz

@@ -498,8 +498,9 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
   }
 }
 
-// ---------------- C += A B^T over a long k (the backward pass's M x M gradient accumulations) ----------------
-// G += W Pbar^T and GL += Kbar_x W^T (gp.py:276-296 under autograd): A, B (L, Mp, K) row-major with K = the N-chunk,
+// ---------------- C += A diag(w) B^T over a long k (the backward pass's M x M gradient accumulation) ----------------
+// H += W diag(gv2) W^T (gp.py:276-296 under autograd; svgp.hip explains why the backward pass needs only this one
+// N-sized product for mu and Lu): A, B (L, Mp, K) row-major with K = the N-chunk, w (L, K) column weights or null,
 // C (L, Mp, Mp), lower tiles only.  Same wave tiling and LDS-DMA staging as above; both operands are [row][16 k] images
 // (B's fragments are ds_read_b128 too), every step runs all sub-tiles, and the epilogue is a read-modify-write of the
 // 256 x 128 tile through the wave-private strips.  Tiles of one matrix take a contiguous range of blocks on ONE XCD
@@ -512,13 +513,16 @@ struct NTParams {
   // (tile, piece); its result goes to part[piece] (laid out like C, plain store) and nt_reduce_kernel adds the pieces to C
   int S, Ks;
   float* part; int64_t sPart;
+  const float* w; int64_t sW;               // column weights (L, K): C += A diag(w) B^T (applied to B's fragments), or null
+  const int32_t* gate;                      // device word: the launch does nothing when it is zero (null: always runs)
 };
 
 // TM = 256: 8 waves, two 128-row blocks per tile; TM = 128 (few blocks: at four 128-blocks the 256-row tile computes 12
 // block-slots for the 10 blocks of the lower triangle, at two blocks 4 for 3): 4 waves, one block per tile.
-template <int TM>
+template <int TM, bool WTS>
 __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_nt_kernel(const NTParams p) {
   constexpr int BK = W_BK, TN = 128;
+  if (p.gate && *p.gate == 0) return;
   constexpr int NW = TM / 32;                    // waves: (TM / 128) row blocks x 4 column strips
   constexpr int A_ELEMS = TM * BK, B_ELEMS = TN * BK, STAGE = A_ELEMS + B_ELEMS;
   extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
@@ -530,10 +534,14 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   {
     const int nb = (int)gridDim.x, qn = nb >> 3, rem = nb & 7, x = blockIdx.x & 7;
     const int lid0 = x * qn + min(x, rem) + (int)(blockIdx.x >> 3);
-    const int lid = lid0 / p.S;
-    piece = lid0 - lid * p.S;
-    b0 = lid / p.T;
-    const int t = lid - b0 * p.T;
+    // (matrix, piece of k, tile), tile fastest: the tiles of one (matrix, piece) are dispatched together on one XCD and walk
+    // the same k range -- every row block of it is read by several of them (at four 128-blocks: 4 times) and only the first
+    // read comes from HBM.  (Piece fastest, the first form, put the S pieces of ONE tile side by side: disjoint k ranges,
+    // nothing shared, every operand byte fetched 4 times over: 3.3 GB per launch at configs[1] for 0.82 GB of Wt.)
+    const int grp = lid0 / p.T;
+    const int t = lid0 - grp * p.T;
+    b0 = grp / p.S;
+    piece = grp - b0 * p.S;
     if constexpr (TM == 256) {
       // row tile ti holds column tiles 0 .. 2 ti + 1 (the last row of an odd block count one fewer): ti (ti + 1) tiles precede it
       int i = (int)((sqrtf(4.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -555,6 +563,8 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const int Mp = p.nblk * 128;
   const int db = (TM / 128) * ti + wm;               // this wave's 128-row block
   const bool active = db < p.nblk && tj <= db;       // blocks above the diagonal (and past the matrix) are not computed
+  // a diagonal tile of A diag(w) A^T: the B tile IS the A tile -- it is fetched once and B's fragments are read from A's image
+  const bool same = TM == 128 && p.A == p.B && tj == ti;
   typedef __attribute__((address_space(3))) void lds_void;
 #if defined(__HIP_DEVICE_COMPILE__)
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -580,12 +590,21 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(sA(buf) + (2 * wave + h) * 256), 16, voff, a_soff[h], 0, 0);
       a_soff[h] += BK * (int)sizeof(float);
     }
+    if (!same) {
 #pragma unroll
-    for (int h = 0; h < NPB; ++h)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sB(buf) + (wave * NPB + h) * 256), 16, voff,
-                                               b_soff + h * 16 * (int)p.ld * (int)sizeof(float), 0, 0);
-    b_soff += BK * (int)sizeof(float);
+      for (int h = 0; h < NPB; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)(sB(buf) + (wave * NPB + h) * 256), 16, voff,
+                                                 b_soff + h * 16 * (int)p.ld * (int)sizeof(float), 0, 0);
+      b_soff += BK * (int)sizeof(float);
+    }
 #endif
+  };
+  // the step's 16 column weights: lane group q owns k = 4q .. 4q+3 of a 16-deep step, so one 16-byte load per lane and
+  // step, issued with the step's tile loads (one step ahead) and waited for with them
+  const float* wk = WTS ? p.w + b0 * p.sW + (int64_t)piece * p.Ks + 4 * (lane >> 4) : nullptr;
+  f32x4 wv[2];
+  auto w_load = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (WTS) { wv[buf] = *reinterpret_cast<const f32x4*>(wk); wk += BK; }
   };
   f32x4 acc[8][2];
 #pragma unroll
@@ -593,11 +612,14 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
   const int fr_a = (wm * 128 + r) * BK + ((q ^ gperm(r)) * 4);
-  const int fr_b = (wn * 32 + r) * BK + ((q ^ gperm(r)) * 4);
+  const int fr_b = (wn * 32 + r) * BK + ((q ^ gperm(r)) * 4) + (same ? -A_ELEMS : 0);
   auto mma_step = [&](int buf) __attribute__((always_inline)) {
     f32x4 fb[2];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) fb[ni] = *reinterpret_cast<const f32x4*>(sB(buf) + fr_b + ni * 16 * BK);
+    for (int ni = 0; ni < 2; ++ni) {
+      fb[ni] = *reinterpret_cast<const f32x4*>(sB(buf) + fr_b + ni * 16 * BK);
+      if constexpr (WTS) fb[ni] *= wv[buf];
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       f32x4 fa[4];
@@ -614,16 +636,17 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   };
   const int nk = (min(p.K, (piece + 1) * p.Ks) - piece * p.Ks) / BK;      // even: K is a multiple of 128, Ks of 32
   stage_load(0);
+  w_load(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // (the wave-uniform `active` test sits outside the loops: no MFMA under a run-time branch)
   if (active) {
     for (int t = 0; t < nk; t += 2) {
-      if (t + 1 < nk) stage_load(1);
+      if (t + 1 < nk) { stage_load(1); w_load(1); }
       mma_step(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (t + 2 < nk) stage_load(0);
+      if (t + 2 < nk) { stage_load(0); w_load(0); }
       mma_step(1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -671,9 +694,9 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 
 // C += part[0] + part[1] + ... (ascending: reproducible) over the 128-blocks the product computes (column block <= row block)
 __global__ __launch_bounds__(256) void nt_reduce_kernel(float* __restrict__ C, const float* __restrict__ part, int S, int64_t sPart,
-                                                        int Mp, int64_t total4) {
+                                                        int Mp, int64_t total4, const int32_t* __restrict__ gate) {
   const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i4 >= total4) return;
+  if (i4 >= total4 || (gate && *gate == 0)) return;
   const int64_t e = i4 * 4;
   const int col = (int)(e % Mp), row = (int)((e / Mp) % Mp);
   if ((col >> 7) > (row >> 7)) return;
@@ -829,7 +852,9 @@ static int64_t nt_tiles(int64_t nblk) {
 int wide_nt_pieces(int64_t Mp, int64_t K, int L) {
   const int64_t tiles = nt_tiles(Mp / 128) * L;
   if (tiles >= 384) return 1;
-  int64_t S = 512 / tiles;                      // one round of two workgroups per CU, not a second round with a few stragglers
+  // one round of resident workgroups, not a second round with a few stragglers: two 8-wave workgroups per CU, or four of
+  // the 4-wave ones (one 128-block per tile)
+  int64_t S = (nt_small_tiles(Mp / 128) ? 1024 : 512) / tiles;
   S = std::min<int64_t>(S, K / 1024);           // at least 64 steps per piece
   S = std::min<int64_t>(S, 16);
   return (int)std::max<int64_t>(S, 1);
@@ -840,9 +865,11 @@ size_t wide_nt_scratch_floats(int64_t Mp, int64_t K, int L) {
   return S > 1 ? (size_t)S * L * Mp * Mp : 0;
 }
 
-int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s, float* scratch) {
+int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s, float* scratch,
+                   const float* w, const int32_t* gate) {
   GPZ_REQUIRE(A && B && C && wide_nt_supported(Mp, K) && L > 0, "wide A B^T: bad arguments");
   NTParams p;
+  p.w = w; p.sW = K; p.gate = gate;
   p.A = A; p.B = B; p.C = C; p.ld = K; p.sAB = Mp * K; p.ldc = Mp; p.sC = Mp * Mp;
   p.K = (int)K; p.nblk = (int)(Mp / 128); p.mt = (p.nblk + 1) / 2; p.L = L;
   const bool small = nt_small_tiles(p.nblk);
@@ -855,15 +882,17 @@ int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t
   GPZ_REQUIRE(nblocks > 0 && nblocks < (1ll << 31), "wide A B^T: bad grid");
   if (small) {
     constexpr size_t lds = sizeof(float) * 2 * (128 + 128) * W_BK;
-    hipLaunchKernelGGL(gemmw_nt_kernel<128>, dim3((unsigned)nblocks), dim3(256), lds, s, p);
+    if (w) hipLaunchKernelGGL((gemmw_nt_kernel<128, true>), dim3((unsigned)nblocks), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((gemmw_nt_kernel<128, false>), dim3((unsigned)nblocks), dim3(256), lds, s, p);
   } else {
     constexpr size_t lds = sizeof(float) * 2 * (256 + 128) * W_BK;
-    hipLaunchKernelGGL(gemmw_nt_kernel<256>, dim3((unsigned)nblocks), dim3(512), lds, s, p);
+    if (w) hipLaunchKernelGGL((gemmw_nt_kernel<256, true>), dim3((unsigned)nblocks), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((gemmw_nt_kernel<256, false>), dim3((unsigned)nblocks), dim3(512), lds, s, p);
   }
   GPZ_LAUNCH_OK();
   if (S > 1) {
     const int64_t total4 = (int64_t)L * Mp * Mp / 4;
-    hipLaunchKernelGGL(nt_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, C, scratch, S, p.sPart, (int)Mp, total4);
+    hipLaunchKernelGGL(nt_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, C, scratch, S, p.sPart, (int)Mp, total4, gate);
     GPZ_LAUNCH_OK();
   }
   return 0;

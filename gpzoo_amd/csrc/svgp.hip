@@ -772,20 +772,28 @@ static int precomputed_t(const void* W, const void* sigma, const void* mu, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward pass for frozen kernel hyper-parameters (the big notebooks' training mode,
-// Slideseq_NSF_newest_version.ipynb:500-504): gradients of a scalar loss w.r.t. mu and the raw
-// Lu, given dLoss/dmean and dLoss/dscale of q(F).  With W = Linv Kzx, P = LuE^T W,
-// gv2 = dLoss/dscale / scale (= 2 dLoss/dvar, zero where the variance clamp is active):
-//   d/d muE = W gm,   d/d LuE = tril(W (P diag(gv2))^T)
-// whitened: LuE = Lu, muE = mu;  un-whitened: LuE = Linv Lu, muE = Linv mu, so the results are
-// pulled back through Linv^T.  Cost: the forward's two products (W is recomputed per chunk, P is
-// stored column-scaled) plus one (M x n)(n x M) accumulation -- 1.5x the forward.
+// Backward pass: gradients of a scalar loss w.r.t. mu and the raw Lu (always) and, on request, the kernel
+// hyper-parameters and Z, given dLoss/dmean and dLoss/dscale of q(F).  With W = Linv Kzx, P = LuE^T W,
+// gv2 = dLoss/dscale / scale (= 2 dLoss/dvar, zero where the variance clamp is active), D = diag(gv2):
+//   d/d muE = W gm,   d/d LuE = tril(W (P D)^T) = tril(H LuE)   with   H = W D W^T  (symmetric, M x M)
+// whitened: LuE = Lu, muE = mu;  un-whitened: LuE = Linv Lu, muE = Linv mu, so the results are pulled back through
+// Linv^T.  Since round 5 the N-sized work of this mode (the big notebooks' training mode, frozen hyper-parameters:
+// Slideseq_NSF_newest_version.ipynb:500-504) is ONE weighted symmetric product per chunk, H += W D W^T -- lower tiles
+// only, L M^2 N flop -- followed by an M x M product; rounds 1-4 formed Pbar = P D (a second pass over W: L M^2 N flop
+// more) and accumulated W Pbar^T.  Forward + backward = 3 triangular-product units instead of 4.
+// With the kernel hyper-parameters / Z (`full`): Wbar = LuE Pbar - W diag(gv2 c) + muE gm^T, Kbar_x = Linv^T Wbar feeds
+// kgrad.hip, and dLoss/dL = -tril(GL) with GL = sum_chunks Kbar_x W^T = Linv^T Q,
+//   Q = sum Wbar W^T = LuE (Pbar W^T) - W diag(gv2 c) W^T + muE (W gm)^T = (Sw - I) H + Hd + muE v^T,
+// Sw = LuE LuE^T, Hd = W diag(gv2 (1 - c)) W^T (c = 0 on the columns whose whitened prior term sits at its clamp, gp.py:287;
+// zero everywhere else, so Hd is accumulated only in chunks that hold such a column), v = W gm -- M x M algebra in
+// fp64 on the same H instead of a third N-sized accumulation: 6 units instead of 7 for the all-parameter step.
 template <typename T>
 __global__ void colscale_kernel(const T* __restrict__ g_scale, const T* __restrict__ scale, int64_t N, int64_t n0,
                                 int64_t ncp, int whitened, double clamp_min, T* __restrict__ out,
                                 const T* __restrict__ g_mean = nullptr, const T* __restrict__ ps1 = nullptr, int mt = 0,
                                 const T* __restrict__ sigma = nullptr, T* __restrict__ out_c = nullptr,
-                                T* __restrict__ out_gm = nullptr) {
+                                T* __restrict__ out_gm = nullptr, T* __restrict__ out_d = nullptr,
+                                int32_t* __restrict__ any_d = nullptr) {
   const int l = blockIdx.y;
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= ncp) return;
@@ -807,6 +815,59 @@ __global__ void colscale_kernel(const T* __restrict__ g_scale, const T* __restri
   out[(int64_t)l * ncp + c] = v;
   if (out_c) out_c[(int64_t)l * ncp + c] = vc;
   if (out_gm) out_gm[(int64_t)l * ncp + c] = gm;
+  if (out_d) {                         // gv2 (1 - c): the weights of Hd; *any_d says whether the chunk has any
+    out_d[(int64_t)l * ncp + c] = v - vc;
+    if (v != vc) atomicOr(any_d, 1);
+  }
+}
+
+// Ws[l][m][c] = W[l][m][c] * w[l][c]   (the weighted operand of H += W diag(w) W^T for the 128 x 128-tile kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_cols_kernel(const T* __restrict__ W, const T* __restrict__ w, int64_t Mp,
+                                                        int64_t ncp, T* __restrict__ out) {
+  const int l = blockIdx.z;
+  const int64_t m = blockIdx.y, c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncp) return;
+  const int64_t o = ((int64_t)l * Mp + m) * ncp + c;
+  out[o] = W[o] * w[(int64_t)l * ncp + c];
+}
+
+// H's strict upper triangle <- its lower one (the accumulation computes the lower tiles; within a diagonal tile the two
+// halves differ by rounding: only one operand carries the weights)
+template <typename T>
+__global__ __launch_bounds__(256) void mirror_lower_kernel(T* __restrict__ H, int64_t Mp) {
+  __shared__ T tile[32][33];
+  const int l = blockIdx.z;
+  const int64_t bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  T* Hl = H + (int64_t)l * Mp * Mp;
+  for (int rr = ty; rr < 32; rr += 8) tile[rr][tx] = Hl[(bi * 32 + rr) * Mp + bj * 32 + tx];
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8)              // element (bj*32 + rr, bi*32 + tx) = H[bi*32 + tx][bj*32 + rr]
+    if (bj < bi || tx > rr) Hl[(bj * 32 + rr) * Mp + bi * 32 + tx] = tile[tx][rr];
+}
+
+// dst (fp64) = src, or dst += src
+template <typename T>
+__global__ void widen_kernel(const T* __restrict__ src, double* __restrict__ dst, int64_t n, int add) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (add ? dst[i] : 0.0) + (double)src[i];
+}
+
+// A[i][i] -= 1
+__global__ void minus_identity_kernel(double* __restrict__ A, int64_t Mp) {
+  const int l = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < Mp) A[(int64_t)l * Mp * Mp + i * (Mp + 1)] -= 1.0;
+}
+
+// me[l][i] = mu[l][i] in fp64, zero padded (whitened: muE = mu)
+template <typename T>
+__global__ void mu_widen_kernel(const T* __restrict__ mu, int64_t M, int64_t Mp, double* __restrict__ me) {
+  const int l = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < Mp) me[(int64_t)l * Mp + i] = i < M ? (double)mu[(int64_t)l * M + i] : 0.0;
 }
 
 // acc[l] += sigma_l * sum_c csc[l][c]   (d var / d sigma through Kxx = sigma^2; one block per latent)
@@ -838,7 +899,7 @@ __global__ __launch_bounds__(256) void tril_transpose_kernel(const double* __res
 
 // Lbar = -tril(GL) (+ tril(upstream dLoss/dchol)) in fp64
 template <typename T>
-__global__ void lbar_kernel(const T* __restrict__ GL, int64_t Mp, int64_t M, const T* __restrict__ g_chol,
+__global__ void lbar_kernel(const double* __restrict__ GL, int64_t Mp, int64_t M, const T* __restrict__ g_chol,
                             const double* __restrict__ E, double* __restrict__ Lbar,
                             const double* __restrict__ g_kl = nullptr, const double* __restrict__ Lc = nullptr) {
   const int l = blockIdx.z;
@@ -846,7 +907,7 @@ __global__ void lbar_kernel(const T* __restrict__ GL, int64_t Mp, int64_t M, con
   if (j >= Mp) return;
   double v = 0.0;
   if (j <= i) {
-    v = -(double)GL[(int64_t)l * Mp * Mp + i * Mp + j];
+    v = -GL[(int64_t)l * Mp * Mp + i * Mp + j];
     if (E) v -= E[(int64_t)l * Mp * Mp + i * Mp + j];
     if (g_chol && i < M) v += (double)g_chol[(int64_t)l * M * M + i * M + j];
     if (g_kl && i == j && i < M) v += g_kl[l] / Lc[(int64_t)l * Mp * Mp + i * Mp + i];   // d(sum log diag L)/dL
@@ -1057,10 +1118,11 @@ __global__ void kl_add_kernel(T* __restrict__ G, int64_t Mp, const double* __res
 
 template <typename T>
 struct BwdBuffers {
-  T *Pc, *G, *G2, *LinvT, *cs; double *mu_part, *mu_sum;
+  T *Pc, *H, *G, *G2, *LinvT, *cs; double *mu_part, *mu_sum;
   float* nt_part;                            // fp32, few tiles: pieces of the A B^T accumulations (gemmw.hip, wide_nt_pieces)
   // kernel / Z gradients only
-  T *LuN, *GL, *csc, *gmc, *PS; double *D1, *D2, *D3, *kacc, *sig_direct;
+  T *LuN, *Hd, *csc, *csd, *gmc, *PS; double *D1, *D2, *D3, *D4, *D5, *me, *kacc, *sig_direct;
+  int32_t* any_d;                            // per chunk: does it hold a column at the whitened clamp (weights of Hd)?
   size_t bytes;
 };
 
@@ -1070,7 +1132,10 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* w
   Carver c(ws);
   c.off = offset;
   const int64_t mm = pl.L * pl.Mp * pl.Mp;
+  // Pbar / Kbar_x chunk (full), and the weighted operand of H for the 128 x 128-tile kernel (the wide kernel applies the
+  // weights itself)
   b.Pc = c.take<T>(pl.L * pl.Mp * pl.nc);
+  b.H = c.take<T>(mm);
   b.G = c.take<T>(mm);
   b.G2 = whitened ? nullptr : c.take<T>(mm);
   b.LinvT = (whitened && !full) ? nullptr : c.take<T>(mm);
@@ -1079,19 +1144,25 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* w
   b.mu_sum = c.take<double>(pl.L * pl.Mp);
   const size_t ntf = sizeof(T) == 4 && wide_nt_supported(pl.Mp, pl.nc) ? wide_nt_scratch_floats(pl.Mp, pl.nc, (int)pl.L) : 0;
   b.nt_part = ntf ? c.take<float>((int64_t)ntf) : nullptr;
-  b.LuN = b.GL = b.csc = b.gmc = b.PS = nullptr;
-  b.D1 = b.D2 = b.D3 = b.kacc = b.sig_direct = nullptr;
+  b.LuN = b.Hd = b.csc = b.csd = b.gmc = b.PS = nullptr;
+  b.D1 = b.D2 = b.D3 = b.D4 = b.D5 = b.me = b.kacc = b.sig_direct = nullptr;
+  b.any_d = nullptr;
   if (full) {
     b.LuN = c.take<T>(mm);
-    b.GL = c.take<T>(mm);
+    b.Hd = whitened ? c.take<T>(mm) : nullptr;
     b.PS = c.take<T>(mm);
     b.csc = c.take<T>(pl.L * pl.nc);
+    b.csd = whitened ? c.take<T>(pl.L * pl.nc) : nullptr;
     b.gmc = c.take<T>(pl.L * pl.nc);
     b.D1 = c.take<double>(mm);
     b.D2 = c.take<double>(mm);
     b.D3 = c.take<double>(mm);
+    b.D4 = c.take<double>(mm);
+    b.D5 = c.take<double>(mm);
+    b.me = c.take<double>(pl.L * pl.Mp);
     b.kacc = c.take<double>(pl.L * pl.Mp * 8);
     b.sig_direct = c.take<double>(pl.L);
+    b.any_d = c.take<int32_t>(pl.nchunks + 1);
   }
   b.bytes = c.used();
   return b;
@@ -1111,11 +1182,15 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   gpz_svgp_problem q = *p;          // forward-only outputs are not produced again
   q.chol = nullptr; q.Lu = nullptr;
   if (int rc = prepare_t<T>(&q, pl, b, s)) return rc;
-  GPZ_HIP_OK(hipMemsetAsync(w.G, 0, sizeof(T) * L * mm, s));
+  GPZ_HIP_OK(hipMemsetAsync(w.H, 0, sizeof(T) * L * mm, s));
+  GPZ_HIP_OK(hipMemsetAsync(w.G, 0, sizeof(T) * L * mm, s));      // (its tiles above the diagonal are never written)
   const dim3 g32((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32);
   const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
   if (full) {
-    GPZ_HIP_OK(hipMemsetAsync(w.GL, 0, sizeof(T) * L * mm, s));
+    if (wh) {
+      GPZ_HIP_OK(hipMemsetAsync(w.Hd, 0, sizeof(T) * L * mm, s));
+      GPZ_HIP_OK(hipMemsetAsync(w.any_d, 0, sizeof(int32_t) * (pl.nchunks + 1), s));
+    }
     GPZ_HIP_OK(hipMemsetAsync(w.kacc, 0, sizeof(double) * L * Mp * 8, s));
     GPZ_HIP_OK(hipMemsetAsync(w.sig_direct, 0, sizeof(double) * L, s));
     // Lu (lower, not transposed) in GEMM precision and Linv^T
@@ -1170,46 +1245,59 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
         if (int rc = gemm_launch(g1, full ? EPI_STORE_STATS : EPI_STORE, s)) return rc;
       }
     }
+    const bool with_hd = full && wh;     // columns at the whitened clamp: their weights gv2 (1 - c) and the chunk's flag
     hipLaunchKernelGGL((colscale_kernel<T>), dim3((unsigned)((ncp + 255) / 256), L32), dim3(256), 0, s,
                        static_cast<const T*>(g->g_scale), static_cast<const T*>(g->scale), N, n0, ncp, (int)wh,
                        p->var_clamp_min, w.cs, static_cast<const T*>(g->g_mean), (const T*)ps1, (int)pl.nblk,
-                       static_cast<const T*>(p->k.sigma), w.csc, w.gmc);
+                       static_cast<const T*>(p->k.sigma), w.csc, w.gmc, with_hd ? w.csd : (T*)nullptr,
+                       with_hd ? w.any_d + ci : (int32_t*)nullptr);
     GPZ_LAUNCH_OK();
-    {                  // Pbar = (LuE^T W) diag(gv2)
-      bool done = false;
-      if constexpr (sizeof(T) == 4) {
-        if (wide) {
-          WideArgs wa = {};
-          wa.A = b.LuT; wa.B = Wc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 1; wa.epilogue = WIDE_STORE_COLSCALE;
-          wa.C = w.Pc; wa.colscale = w.cs;
-          if (int rc = wide_product_launch(wa, s)) return rc;
-          done = true;
-        }
-      }
-      if (!done) {
-        GemmParams<T> g2;
-        g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
-        g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
-        g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
-        g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-        g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
-        if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
-      }
-    }
-    GemmParams<T> g3;  // G += W Pbar^T  (lower tiles)
-    g3.A = Wc; g3.lda = ncp; g3.sA0 = Mp * ncp;
-    g3.B = w.Pc; g3.ldb = ncp; g3.sB0 = Mp * ncp;
-    g3.C = w.G; g3.ldc = Mp; g3.sC0 = mm;
-    g3.nb0 = L32; g3.mt = g3.nt = (int)pl.nblk; g3.K = (int)ncp; g3.flags = GF_B_TRANS | GF_TILES_LOWER;
-    g3.alpha = 1; g3.beta = 1;
+    // C += W diag(wts) W^T (lower tiles): the wide kernel weights its B fragments itself; the 128 x 128-tile kernel
+    // gets a weighted copy of W (in the Pbar buffer, free at this point)
     const bool wide_nt = sizeof(T) == 4 && wide && wide_nt_supported(Mp, ncp);
-    if (wide_nt) {
-      if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(Wc, w.Pc, w.G, Mp, ncp, L32, s, w.nt_part)) return rc; }
-    } else if (int rc = gemm_launch(g3, EPI_STORE, s)) return rc;
+    auto syrk = [&](const T* wts, T* C, const int32_t* gate) -> int {
+      if (wide_nt) {
+        if constexpr (sizeof(T) == 4) return wide_nt_launch(Wc, Wc, C, Mp, ncp, L32, s, w.nt_part, wts, gate);
+      }
+      hipLaunchKernelGGL((scale_cols_kernel<T>), dim3((unsigned)((ncp + 255) / 256), (unsigned)Mp, L32), dim3(256), 0, s,
+                         (const T*)Wc, wts, Mp, ncp, w.Pc);
+      GPZ_LAUNCH_OK();
+      GemmParams<T> g3;
+      g3.A = w.Pc; g3.lda = ncp; g3.sA0 = Mp * ncp;
+      g3.B = Wc; g3.ldb = ncp; g3.sB0 = Mp * ncp;
+      g3.C = C; g3.ldc = Mp; g3.sC0 = mm;
+      g3.nb0 = L32; g3.mt = g3.nt = (int)pl.nblk; g3.K = (int)ncp; g3.flags = GF_B_TRANS | GF_TILES_LOWER;
+      g3.alpha = 1; g3.beta = 1;
+      return gemm_launch(g3, EPI_STORE, s);
+    };
+    if (int rc = syrk(w.cs, w.H, nullptr)) return rc;                      // H  += W diag(gv2) W^T
+    if (with_hd)
+      if (int rc = syrk(w.csd, w.Hd, w.any_d + ci)) return rc;             // Hd += W diag(gv2 (1 - c)) W^T, if any
     hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, Wc, Mp, ncp,
                        static_cast<const T*>(g->g_mean), N, n0, w.mu_part, pl.nchunks, ci);
     GPZ_LAUNCH_OK();
     if (full) {
+      {                  // Pbar = (LuE^T W) diag(gv2)
+        bool done = false;
+        if constexpr (sizeof(T) == 4) {
+          if (wide) {
+            WideArgs wa = {};
+            wa.A = b.LuT; wa.B = Wc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 1; wa.epilogue = WIDE_STORE_COLSCALE;
+            wa.C = w.Pc; wa.colscale = w.cs;
+            if (int rc = wide_product_launch(wa, s)) return rc;
+            done = true;
+          }
+        }
+        if (!done) {
+          GemmParams<T> g2;
+          g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+          g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+          g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
+          g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+          g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
+          if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
+        }
+      }
       // Wbar = Lu Pbar - W diag(gv2 c) + mu gm^T            (into the Kzx buffer, no longer needed)
       bool done = false;
       if constexpr (sizeof(T) == 4) {
@@ -1244,13 +1332,8 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
         g5.super_cols = sched_plain.cols;
         if (int rc = gemm_launch(g5, EPI_STORE, s)) return rc;
       }
-      // GL += Kbar_x W^T  (lower tiles):  dLoss/dL = -tril(GL)
-      GemmParams<T> g6 = g3;
-      g6.A = w.Pc; g6.B = Wc; g6.C = w.GL;
-      if (wide_nt) {
-        if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(w.Pc, Wc, w.GL, Mp, ncp, L32, s, w.nt_part)) return rc; }
-      } else if (int rc = gemm_launch(g6, EPI_STORE, s)) return rc;
-      // kernel hyper-parameter and Z gradients from Kbar_x
+      // kernel hyper-parameter and Z gradients from Kbar_x  (dLoss/dL needs no accumulation over the chunk: GL = Linv^T Q
+      // is M x M algebra on H, below)
       KgradArgs ka;
       ka.Kbar = w.Pc; ka.ld = ncp; ka.stride = Mp * ncp; ka.Z = p->Z; ka.X = Xc;
       ka.gZ = p->gZ; ka.gX = p->gX ? p->gX + n0 : nullptr;
@@ -1266,6 +1349,56 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.mu_part, pl.nchunks,
                      Mp, w.mu_sum);
   GPZ_LAUNCH_OK();
+  auto dgemm = [&](const double* A, const double* B, double* C, int flags) -> int {
+    GemmParams<double> d;
+    d.A = A; d.lda = Mp; d.sA0 = mm; d.B = B; d.ldb = Mp; d.sB0 = mm; d.C = C; d.ldc = Mp; d.sC0 = mm;
+    d.nb0 = L32; d.mt = d.nt = (int)pl.nblk; d.K = (int)Mp; d.flags = flags;
+    return gemm_launch(d, EPI_STORE, s);
+  };
+  // dLoss/dLuE = tril(H LuE): H made symmetric, then one M x M product (LuT = LuE^T is the forward's stage-2 operand)
+  hipLaunchKernelGGL((mirror_lower_kernel<T>), g32, dim3(256), 0, s, w.H, Mp);
+  GPZ_LAUNCH_OK();
+  {
+    GemmParams<T> gh;
+    gh.A = w.H; gh.lda = Mp; gh.sA0 = mm;
+    gh.B = b.LuT; gh.ldb = Mp; gh.sB0 = mm;
+    gh.C = w.G; gh.ldc = Mp; gh.sC0 = mm;
+    gh.nb0 = L32; gh.mt = gh.nt = (int)pl.nblk; gh.K = (int)Mp; gh.flags = GF_B_TRANS | GF_B_LOWER | GF_TILES_LOWER;
+    if (int rc = gemm_launch(gh, EPI_STORE, s)) return rc;
+  }
+  if (full) {
+    // GL = sum_chunks Kbar_x W^T = Linv^T Q,  Q = (Sw - I) H + Hd + muE v^T   (fp64; v = W gm, before the KL is folded in)
+    hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.H, w.D1, L * mm, 0);      // D1 = H
+    GPZ_LAUNCH_OK();
+    const double* LuE64 = b.LuW;
+    if (wh) {
+      hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.LuN, w.D4, L * mm, 0);
+      GPZ_LAUNCH_OK();
+      LuE64 = w.D4;
+    }
+    if (int rc = dgemm(LuE64, LuE64, w.D2, GF_A_LOWER | GF_B_UPPER | GF_B_TRANS)) return rc;               // D2 = Sw
+    hipLaunchKernelGGL(minus_identity_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.D2, Mp);
+    GPZ_LAUNCH_OK();
+    if (int rc = dgemm(w.D2, w.D1, w.D3, 0)) return rc;                                                      // D3 = (Sw - I) H
+    if (wh) {
+      hipLaunchKernelGGL((mirror_lower_kernel<T>), g32, dim3(256), 0, s, w.Hd, Mp);
+      GPZ_LAUNCH_OK();
+      hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.Hd, w.D3, L * mm, 1);   //    + Hd
+      GPZ_LAUNCH_OK();
+      hipLaunchKernelGGL((mu_widen_kernel<T>), dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s,
+                         static_cast<const T*>(p->mu), M, Mp, w.me);
+    } else {
+      hipLaunchKernelGGL((linv_mu_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Linv,
+                         static_cast<const T*>(p->mu), Mp, M, w.me);
+    }
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL(rank1_update_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)(M < 1024 ? M : 1024), L32),
+                       dim3(256), 0, s, w.D3, Mp, M, w.me, w.mu_sum);                                        //    + muE v^T
+    GPZ_LAUNCH_OK();
+    hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Linv, Mp, w.D1);                       // D1 = Linv^T
+    GPZ_LAUNCH_OK();
+    if (int rc = dgemm(w.D1, w.D3, w.D5, GF_A_UPPER)) return rc;                                             // D5 = GL
+  }
   const double* g_kl = g->g_kl;
   if (g_kl && !wh) {
     hipLaunchKernelGGL((kl_add_kernel<T>), gm, dim3(256), 0, s, w.G, Mp, b.LuW, w.mu_sum, b.muE, g_kl);
@@ -1299,12 +1432,6 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   GPZ_LAUNCH_OK();
   if (full) {
     // Cholesky backward (Murray 2016): Kbar_zz = Linv^T Phi(L^T Lbar) Linv with Lbar = -tril(GL)
-    auto dgemm = [&](const double* A, const double* B, double* C, int flags) -> int {
-      GemmParams<double> d;
-      d.A = A; d.lda = Mp; d.sA0 = mm; d.B = B; d.ldb = Mp; d.sB0 = mm; d.C = C; d.ldc = Mp; d.sC0 = mm;
-      d.nb0 = L32; d.mt = d.nt = (int)pl.nblk; d.K = (int)Mp; d.flags = flags;
-      return gemm_launch(d, EPI_STORE, s);
-    };
     const double* E = nullptr;
     if (!wh) {
       // muE = Linv mu and LuE = Linv Lu also depend on the factor:
@@ -1312,19 +1439,15 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       hipLaunchKernelGGL((tril_to_double_kernel<T>), gm, dim3(256), 0, s, w.G, Mp, w.D1);
       GPZ_LAUNCH_OK();
       if (int rc = dgemm(w.D1, b.LuW, w.D2, GF_A_LOWER | GF_B_UPPER | GF_B_TRANS)) return rc;     // D2 = tril(G) LuE^T
-      double* const me = w.D3;      // (L, Mp) scratch: D3 is only written by the product below
-      hipLaunchKernelGGL((linv_mu_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Linv,
-                         static_cast<const T*>(p->mu), Mp, M, me);
-      GPZ_LAUNCH_OK();
       hipLaunchKernelGGL(rank1_update_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)(M < 1024 ? M : 1024), L32),
-                         dim3(256), 0, s, w.D2, Mp, M, w.mu_sum, me);
+                         dim3(256), 0, s, w.D2, Mp, M, w.mu_sum, w.me);                           // (me = Linv mu, above)
       GPZ_LAUNCH_OK();
       hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Linv, Mp, w.D1);         // D1 = Linv^T
       GPZ_LAUNCH_OK();
       if (int rc = dgemm(w.D1, w.D2, w.D3, GF_A_UPPER)) return rc;                                // D3 = E
       E = w.D3;
     }
-    hipLaunchKernelGGL((lbar_kernel<T>), gm, dim3(256), 0, s, w.GL, Mp, M, static_cast<const T*>(g->g_chol), E, w.D2,
+    hipLaunchKernelGGL((lbar_kernel<T>), gm, dim3(256), 0, s, w.D5, Mp, M, static_cast<const T*>(g->g_chol), E, w.D2,
                        wh ? nullptr : g_kl, b.Kzz);
     GPZ_LAUNCH_OK();                                                                              // D2 = Lbar
     hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Kzz, Mp, w.D1);            // D1 = L^T

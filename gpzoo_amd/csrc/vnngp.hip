@@ -15,12 +15,15 @@
 //   vnngp_point_kernel thread = (latent, datum): gathers the K x K blocks, Cholesky-solves for W in
 //                     fp64 and evaluates mean = W mu[idx], cov = s^2 + W S W^T - W k.  Per-thread
 //                     matrices sit in a [element][thread] global scratch so every access is coalesced.
-//   vnngp_point_bwd_kernel  same thread mapping: recomputes the point's solve and pushes dLoss/dmean,
-//                     dLoss/dscale back to mu[idx], the S and Kzz blocks and k_xz[idx].  The K-sparse
-//                     contributions are scattered with hardware fp64 atomics into dense (L,M) / (L,M,M)
-//                     accumulators (sums of doubles in arbitrary order: reproducible to rounding, not
-//                     bitwise); the dense tails -- dS -> dLu, Cholesky backward of dLoss/dchol, the
-//                     contraction with dKzz/d(sigma, lengthscale, Z) -- reuse the fp64 GEMM and kgrad.hip.
+//   vnngp_point_bwd_kernel  same thread mapping: recomputes the point's solve and leaves per point w,
+//                     v = A^{-1} gW, k_xz and the upstream factors as a contiguous record.
+//   vnngp_gather_kernel  one wave per (inducing point, latent) walks the entries of the inverted neighbour
+//                     table (stable counting sort) in ascending order and forms dLoss/dmu[idx], the rows of
+//                     the S and Kzz block gradients and dLoss/dZ through k_xz in that FIXED order: no
+//                     atomics on values, bitwise reproducible (a table with a repeated neighbour is summed
+//                     lane after lane, vnn_dup_kernel).  The dense tails -- dS -> dLu, Cholesky backward of
+//                     dLoss/dchol, the contraction with dKzz/d(sigma, lengthscale, Z) -- reuse the fp64
+//                     GEMM and kgrad.hip.
 #include "common.h"
 #include "factor.h"
 #include "gemm.h"
@@ -210,6 +213,8 @@ struct VnnBwdArgs {
                                 // reads per entry (from the [column][point] scratch every value is a 64-byte sector of its own)
   const int32_t* inv;           // (N*K) entries n * K + p grouped by the inducing point they name, ascending inside a group
   const int32_t* start;         // (M + 1) group boundaries in inv
+  const int32_t* dup;           // one word: non-zero when some point names an inducing point twice (caller-supplied tables
+                                // only; gpz_knn's lists are distinct by construction), or null
 };
 
 template <typename T>
@@ -488,6 +493,21 @@ __global__ __launch_bounds__(256) void vnn_inv_fill_kernel(const int64_t* __rest
   }
 }
 
+// one thread per point: does its neighbour list name an inducing point twice?  (a caller-supplied table may; the
+// reference's gathers and its inverse of little_Kzz + jitter I accept that, gp.py:66-77)
+__global__ __launch_bounds__(256) void vnn_dup_kernel(const int64_t* __restrict__ idx, int64_t N, int K,
+                                                     int32_t* __restrict__ flag) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int64_t* id = idx + n * K;
+  bool dup = false;
+  for (int p = 1; p < K; ++p) {
+    const int64_t ip = id[p];
+    for (int q = 0; q < p; ++q) dup |= id[q] == ip;
+  }
+  if (dup) atomicOr(flag, 1);
+}
+
 // One wave per (inducing point ip, latent l): walks the entries that name ip in ascending order and forms, with the two
 // rows resident in LDS, row ip of T_S and T_K, gmu[ip] and the dz part of kacc -- the sums the point kernel used to
 // scatter with atomics.  The dsigma / dlengthscale totals of a latent go through vnn_theta_sum_kernel.
@@ -506,6 +526,10 @@ __global__ __launch_bounds__(64) void vnngp_gather_kernel(VnnBwdArgs<T> b) {
   const double el = (double)a.ell[l], il2 = 1.0 / (el * el);
   double gmu = 0.0, dz = 0.0;                 // lane 0: gmu; lanes k < d: dz_k
   const int32_t e0 = b.start[ip], e1 = b.start[ip + 1];
+  // With pairwise distinct neighbours the lanes q <= p of an entry add into distinct columns of the two rows.  A table that
+  // names an inducing point twice (b.dup) makes two lanes meet in one column: those launches add lane after lane, which
+  // is the same sum in the order q = 0, 1, ... -- still a fixed order.
+  const bool serial = b.dup != nullptr && *b.dup != 0;
   // Eight entries per trip: their loads (entry -> point -> the point's vectors: two dependent levels of global latency) are
   // all issued before the first use, the updates are applied in entry order -- the sums are the same sums in the same
   // order.  One entry per trip was bound by exactly that latency: 400 entries x 2 us per wave, 2.8 ms per backward at
@@ -539,10 +563,18 @@ __global__ __launch_bounds__(64) void vnngp_gather_kernel(VnnBwdArgs<T> b) {
     for (int u = 0; u < U; ++u) {
       const int p = pp[u];
       if (p < 0) continue;                      // past the group's end (wave-uniform)
-      if (lane <= p) {                          // one unordered pair (p, q <= p) per lane: distinct columns of the rows
-        const int q = lane;
-        if (gcov[u] != 0.0) rowS[iq[u]] += (p == q ? 0.5 : 1.0) * gcov[u] * wp[u] * wq[u];
-        if (b.gK) rowK[iq[u]] += p == q ? -vp[u] * wq[u] : -(vp[u] * wq[u] + vq[u] * wp[u]);
+      if (!serial) {
+        if (lane <= p) {                        // one unordered pair (p, q <= p) per lane: distinct columns of the rows
+          const int q = lane;
+          if (gcov[u] != 0.0) rowS[iq[u]] += (p == q ? 0.5 : 1.0) * gcov[u] * wp[u] * wq[u];
+          if (b.gK) rowK[iq[u]] += p == q ? -vp[u] * wq[u] : -(vp[u] * wq[u] + vq[u] * wp[u]);
+        }
+      } else {
+        for (int q = 0; q <= p; ++q)
+          if (lane == q) {
+            if (gcov[u] != 0.0) rowS[iq[u]] += (p == q ? 0.5 : 1.0) * gcov[u] * wp[u] * wq[u];
+            if (b.gK) rowK[iq[u]] += p == q ? -vp[u] * wq[u] : -(vp[u] * wq[u] + vq[u] * wp[u]);
+          }
       }
       if (lane == 0) gmu += gm[u] * wp[u];
       if (b.kacc && lane < a.d) {
@@ -618,7 +650,7 @@ struct VnnPlan {
   double *Linv, *Tmp, *LuE, *muE;                       // KL(qU || pU): L^{-1}, L^{-1} Lu, L^{-1} mu
   uint32_t* fsync;                                       // tickets and flags of the one-launch Cholesky (csrc/coop.hip)
   double *gmu, *gS, *gK, *kacc, *G, *D1, *D2, *rec; void* PS;  // backward only
-  int32_t *inv, *istart, *ihist, *itmp;                  // backward only: the inverted neighbour table and its scratch
+  int32_t *inv, *istart, *ihist, *itmp, *idup;           // backward only: the inverted neighbour table and its scratch
 };
 
 // M is a few thousand at most on this path: every mode carves the same (generous) set of M x M buffers
@@ -641,12 +673,13 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
   pl.fsync = c.take<uint32_t>(coop_sync_words(pl.Mp, pl.L));
   pl.gmu = pl.gS = pl.gK = pl.kacc = pl.G = pl.D1 = pl.D2 = pl.rec = nullptr;
   pl.PS = nullptr;
-  pl.inv = pl.istart = pl.ihist = pl.itmp = nullptr;
+  pl.inv = pl.istart = pl.ihist = pl.itmp = pl.idup = nullptr;
   if (bwd) {
     const int64_t NK = pl.N * K, IB = (NK + VNN_IB - 1) / VNN_IB;
     pl.inv = c.take<int32_t>(NK);
     pl.istart = c.take<int32_t>(pl.M + 2);
     pl.itmp = c.take<int32_t>(pl.M + 2);
+    pl.idup = c.take<int32_t>(16);
     pl.ihist = c.take<int32_t>(IB * pl.M);
     pl.rec = c.take<double>((int64_t)(3 * K + 2) * pl.L * pl.N);
     pl.gmu = c.take<double>(pl.L * pl.Mp);
@@ -1016,7 +1049,13 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
     GPZ_LAUNCH_OK();
     hipLaunchKernelGGL(vnn_inv_fill_kernel, dim3((unsigned)IB), dim3(256), 0, s, b.f.idx, NK, M, pl.ihist, pl.istart, pl.inv);
     GPZ_LAUNCH_OK();
-    b.inv = pl.inv; b.start = pl.istart;
+    b.inv = pl.inv; b.start = pl.istart; b.dup = nullptr;
+    if (idx_in) {                    // a caller's table may repeat a neighbour; the lists of gpz_knn cannot
+      GPZ_HIP_OK(hipMemsetAsync(pl.idup, 0, sizeof(int32_t), s));
+      hipLaunchKernelGGL(vnn_dup_kernel, dim3((unsigned)((pl.N + 255) / 256)), dim3(256), 0, s, b.f.idx, pl.N, K, pl.idup);
+      GPZ_LAUNCH_OK();
+      b.dup = pl.idup;
+    }
     const size_t lds = 2 * Mp * sizeof(double);
     if (lds > 64 * 1024) {
       static bool set[64] = {};

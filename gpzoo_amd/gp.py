@@ -120,8 +120,17 @@ class _FusedQU(distributions.MultivariateNormal):
         return t
 
     @_unbroadcasted_scale_tril.setter
-    def _unbroadcasted_scale_tril(self, value):      # (the eager constructor path and Distribution.expand assign it)
+    def _unbroadcasted_scale_tril(self, value):      # (the eager constructor path assigns it)
         self.__dict__["_gpz_tril"] = value
+
+    def expand(self, batch_shape, _instance=None):
+        """As MultivariateNormal.expand (a subclass with its own __init__ has to say how): the expanded distribution
+        is a plain MultivariateNormal over the materialised factor -- the fused KL belongs to this very q(U)."""
+        batch_shape = torch.Size(batch_shape)
+        tril = self._unbroadcasted_scale_tril
+        return distributions.MultivariateNormal(self.loc.expand(batch_shape + self.event_shape),
+                                                scale_tril=tril.expand(batch_shape + tril.shape[-2:]),
+                                                validate_args=False)
 
 
 class _FusedPU(distributions.MultivariateNormal):

@@ -248,11 +248,30 @@ class Hybrid_NSF2(nn.Module):
 
 class Hybrid_NSF_Exact(Hybrid_NSF2):
     """Hybrid model with the log-normal mean exp(m + s^2/2) in place of sampling; reference
-    likelihoods.py:165-224."""
+    likelihoods.py:167-222.  Nothing is sampled, so the rate has NO sample axis: ``pY.rate`` is (D,N) and ``E`` is
+    ignored, as in the reference."""
 
     def _pY(self, qF1, qF2, V, E):
         Z = self.sf.get_rate(qF1.mean + 0.5 * qF1.scale ** 2) + self.cf.get_rate(qF2.mean + 0.5 * qF2.scale ** 2)
         return distributions.Poisson(V * Z)
+
+    def expected_loglik(self, X, y, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
+        """The closed-form objective of THIS class as the reference's loops evaluate it -- not the sampled one of
+        Hybrid_NSF2.  With a (D,N) rate, ``pY.log_prob(y).mean(axis=0).sum()`` (utilities.py:537) and
+        ``(y log r - r).mean(axis=0).sum()`` (utilities.py:508-510) average over the GENE axis: the value is
+        (1/D) sum_dn log Poisson(y | V (W1 exp(m1 + s1^2/2) + W2 exp(m2 + s2^2/2))).  Evaluated by the fused kernel as
+        one noise-free "sample" of F = m + s^2/2 (gpz_poisson_nsf; the chain to m and s runs through torch);
+        ``E`` and ``eps`` are accepted and unused."""
+        Xb = X if idx is None else X[idx]
+        V = self.V if idx is None else self.V[idx]
+        qF1, qU, pU = self.sf.prior(X=Xb, **kwargs)
+        qF2, pF2 = self.cf.prior() if idx is None else self.cf.prior.forward_batched(idx)
+        sp = torch.nn.functional.softplus
+        m = torch.cat([qF1.mean + 0.5 * qF1.scale ** 2, qF2.mean + 0.5 * qF2.scale ** 2], dim=0)
+        zero = torch.zeros_like(m)
+        ll = _PoissonLogLik.apply(m, zero, torch.cat([sp(self.sf.W), sp(self.cf.W)], dim=1), sp(V), zero[None], y,
+                                  with_lgamma)
+        return ll / y.shape[0], qF1, qU, pU, qF2, pF2
 
 
 class Hybrid_NSF(NSF):

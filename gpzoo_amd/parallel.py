@@ -257,8 +257,12 @@ def _dist_allgather(t: torch.Tensor, group, comm):
 
 def _dist_reduce_scatter(t: torch.Tensor, group, comm):
     """t (world, ...) -> this rank's slice of the sum over ranks."""
-    if comm is not None and t.dtype == torch.float32:
-        return comm.reduce_scatter_sum(t.contiguous())
+    if comm is not None:
+        if t.dtype == torch.float32:
+            return comm.reduce_scatter_sum(t.contiguous())
+        if t.dtype == torch.float64:               # the C ABI's fp64 exchange is the all-reduce: sum, keep the slice
+            return comm.allreduce_sum_(t.detach().contiguous().clone())[comm.rank]
+        raise ValueError(f"reduce-scatter through the C-ABI communicator takes float32 or float64, got {t.dtype}")
     rank = dist.get_rank(group)
     if dist.get_backend(group) == "gloo":          # gloo has no reduce-scatter: all-reduce, keep the slice
         h = t.detach().cpu().contiguous() if t.is_cuda else t.detach().contiguous().clone()

@@ -99,17 +99,27 @@ def _spots(X, batch_size):
     return torch.multinomial(torch.ones(X.shape[0], device=X.device), num_samples=batch_size, replacement=False)
 
 
-def train(model, optimizer, X, y, device=None, steps=200, E=20, **kwargs):
+def train(model, optimizer, X, y, device=None, steps=200, E=20, fused=True, sync_losses=True, **kwargs):
     """Full-batch optimisation loop with the reference's signature (utilities.py:471-493).  The
     forward and the gradients run on the fused HIP path; the optimiser step is torch's.
-    Returns the list of losses (one host sync per step, as in the reference)."""
+    ``fused``: Poisson factor models evaluate ``pY.log_prob(y).mean(0).sum()`` through ``model.expected_loglik``
+    (gpz_poisson_nsf: the (E,D,N) rate is never materialised), as the mini-batch loops below do.
+    Returns the list of losses: floats, one host sync per step as in the reference (``losses.append(loss.item())``,
+    utilities.py:487), or with ``sync_losses=False`` 0-d device tensors converted once at the end -- the same numbers
+    without stalling the launch queue every step, which is most of a step at the notebooks' small sizes."""
     losses = []
     for _ in range(steps):
         optimizer.zero_grad()
-        loss = _elbo_terms(model, X, y, E, **kwargs)
+        if fused and hasattr(model, "expected_loglik"):
+            ll, _, qU, pU = model.expected_loglik(X, y, E=E, **kwargs)     # (the hybrids' 6-tuples fail here as in the reference)
+            loss = -(ll - _kl_u(qU, pU))
+        else:
+            loss = _elbo_terms(model, X, y, E, **kwargs)
         loss.backward()
         optimizer.step()
-        losses.append(loss.item())
+        losses.append(loss.item() if sync_losses else loss.detach())
+    if not sync_losses and losses:
+        losses = torch.stack(losses).tolist()
     return losses
 
 

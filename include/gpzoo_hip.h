@@ -92,8 +92,12 @@ int gpz_kgrad(const gpz_kernel_desc* k, const void* A, int64_t nA, const void* B
 
 /* In-place lower Cholesky of `batch` (M,M) matrices stored as `dtype` (the arithmetic is fp64 either way:
  * "factor precision"), zeros written above the diagonal; info[b] as described above.  Replaces
- * torch.linalg.cholesky at gp.py:213, 270, 360.  Blocked right-looking: LDS-resident diagonal panel,
- * MFMA (v_mfma_f64_16x16x4_f64) panel solve and trailing SYRK/GEMM update. */
+ * torch.linalg.cholesky at gp.py:213, 270, 360.  Default: ONE launch, a left-looking dataflow over 128 x 128 tiles
+ * (csrc/coop.hip: diagonal blocks factored in LDS, every tile's sum kept in its owner's registers on
+ * v_mfma_f64_16x16x4_f64, hand-offs through flags).  Orders beyond that launch's task list, or
+ * GPZ_FACTOR_PATH=launches, take the blocked right-looking chain of launches (csrc/factor.hip: LDS-resident diagonal
+ * panel, MFMA panel solve and trailing SYRK/GEMM update).  info[b] = -7 anywhere (a hand-off of the one-launch path
+ * timed out) invalidates the WHOLE batch: matrices the aborting workgroups had not reached are left unfactored. */
 /* Which factorisation matrices of order M take: 1 = the one-launch tile dataflow (Cholesky and, with_inverse, the
  * triangular inverse in the same launch; csrc/coop.hip), 0 = one launch per step of the blocked algorithm (orders whose
  * task list exceeds the kernel-argument space, or GPZ_FACTOR_PATH=launches in the environment). */
@@ -237,8 +241,9 @@ int gpz_svgp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int64_
  * standard-normal draws of rsample; W (D,Lt), V (N,): POSITIVE loadings / size factors (after
  * softplus); y (D,N) counts.  Outputs: loglik (2,) fp64: [0] = (1/E) sum_e sum_dn [y log(VZ) - VZ],
  * [1] = sum_dn lgamma(y+1) (0 unless with_lgamma; Poisson.log_prob = [0] - [1]); and
- * d loglik[0] / d{mean, scale, W, V}.  Lt <= 64 factors; E <= 4 samples per call (more samples:
- * one call per group of four, as gpzoo_amd/ops.py does).  The three dense products (rate, dW, d exp F) run on MFMA. */
+ * d loglik[0] / d{mean, scale, W, V}.  Lt <= 64 factors; E <= 32 samples per call (more samples: one call per group
+ * of 32, as gpzoo_amd/ops.py does; y is read once per pass whatever E is).  The three dense products (rate, dW,
+ * d exp F) run on MFMA. */
 size_t gpz_poisson_nsf_workspace_bytes(int64_t N, int64_t D, int32_t Lt, int32_t E);
 int gpz_poisson_nsf(const float* mean, const float* scale, const float* eps, const float* W,
                     const float* V, const float* y, int64_t N, int64_t D, int32_t Lt, int32_t E,
@@ -264,8 +269,11 @@ int gpz_vnngp_forward(const gpz_svgp_problem* p, int32_t K, const int64_t* idx, 
  * grad_theta / grad_Z are non-NULL, the gradients w.r.t. (sigma, lengthscale) per latent and Z.
  * The neighbour table is a constant of the graph (argsort has no gradient).  `scale` of
  * gpz_svgp_grads is unused (the variance is recomputed); `g_kl` folds the gradient of the forward's
- * per-latent KL(qU || pU) (problem field `kl`) in, as in gpz_svgp_backward.  The K-sparse terms are accumulated with
- * fp64 atomics: results are reproducible to rounding, not bitwise. */
+ * per-latent KL(qU || pU) (problem field `kl`) in, as in gpz_svgp_backward.  The K-sparse terms (the sums over the
+ * points that name an inducing point) are formed in a fixed order over the inverted neighbour table -- no atomics on
+ * values, bitwise reproducible.  A caller-supplied idx may repeat a neighbour inside a row (checked on the device; those
+ * calls add lane after lane); its entries must lie in [0, M).  Limits of the backward pass beyond the forward's:
+ * M <= 8192 (two fp64 rows of the padded order in 128 KB of LDS) and N * K < 2^31. */
 size_t gpz_vnngp_backward_workspace_bytes(const gpz_svgp_problem* p, int32_t K);
 int gpz_vnngp_backward(const gpz_svgp_problem* p, const gpz_svgp_grads* g, int32_t K,
                        const int64_t* idx, void* ws, size_t ws_bytes, void* stream);

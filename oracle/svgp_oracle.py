@@ -223,11 +223,12 @@ def elbo_eval(kind: str, whitened: bool, X, y, Z, sigma, lengthscale, mu, Lu_raw
 # VNNGP: K nearest inducing points per datum (gp.py:7-122)
 # --------------------------------------------------------------------------
 
-def vnngp_moments(X, Z, sigma, lengthscale, mu, Lu_raw, jitter: float, K: int):
+def vnngp_moments(X, Z, sigma, lengthscale, mu, Lu_raw, jitter: float, K: int, idx=None):
     """q(F) of the nearest-neighbour variational GP (gp.py:21-122): for every x the K nearest
     inducing points (argsort of torch.cdist, gp.py:31,64), the K x K blocks of L L^T = Kzz + jitter I
     (jittered once more in place, gp.py:68-77), W = k_xz[idx] inv(block), S block from Lu[idx],
     then svgp_forward (utilities.py:382-397) and clamp(cov, 5e-2) (gp.py:117).
+    ``idx``: a neighbour table to use instead of the argsort (every later line of gp.py:66-122 is a gather on it).
     Returns mean, scale (L,N) or (N,), the neighbour indices (N,K), Lu, chol."""
     batched = sigma.dim() > 0
     s = sigma.reshape(-1, 1, 1)
@@ -237,7 +238,8 @@ def vnngp_moments(X, Z, sigma, lengthscale, mu, Lu_raw, jitter: float, K: int):
     Kzz = s ** 2 * torch.exp(-0.5 * torch.cdist(Z, Z) ** 2 / ell ** 2)
     Lq = lower_cholesky_param(Lu_raw).reshape(-1, Z.shape[0], Z.shape[0])
     chol = torch.linalg.cholesky(add_jitter_(Kzz.contiguous(), jitter))
-    idx = torch.argsort(dist, dim=1)[:, :K]                                     # (N,K)
+    if idx is None:
+        idx = torch.argsort(dist, dim=1)[:, :K]                                 # (N,K)
     lL = chol[:, idx]                                                           # (L,N,K,M)
     lK = lL @ lL.transpose(-2, -1)
     lK = add_jitter_(lK.reshape(-1, K, K).contiguous(), jitter).reshape(lK.shape)
@@ -251,3 +253,32 @@ def vnngp_moments(X, Z, sigma, lengthscale, mu, Lu_raw, jitter: float, K: int):
     if not batched:
         mean, scale = mean[0], scale[0]
     return mean, scale, idx, lower_cholesky_param(Lu_raw), chol if batched else chol[0]
+
+
+# --------------------------------------------------------------------------
+# Poisson factor models: the step right after the path (likelihoods.py:39-53, 74-97, 100-222)
+# --------------------------------------------------------------------------
+
+def poisson_expected_loglik(mean, scale, eps, W_pos, V_pos, y, with_lgamma: bool = True) -> torch.Tensor:
+    """Monte-Carlo objective of NSF2 / Hybrid_NSF2 as the reference's loops evaluate it: F = qF.rsample((E,)) =
+    mean + scale * eps (E,Lt,N); rate = V * (softplus(W) @ exp(F)) (likelihoods.py:49-53, 81-86; the hybrids add their
+    two factor sets' rates, :111-121 -- here both sets are rows of one (Lt,N) / columns of one (D,Lt) operand);
+    pY.log_prob(y).mean(axis=0).sum() (utilities.py:479, 537, 612) or, without the log y! term,
+    (y log rate - rate).mean(axis=0).sum() (utilities.py:508-510).  W_pos, V_pos: after softplus."""
+    F = mean[None] + scale[None] * eps
+    rate = V_pos * torch.matmul(W_pos, torch.exp(F))
+    ll = y * torch.log(rate) - rate
+    if with_lgamma:
+        ll = ll - torch.lgamma(y + 1)
+    return ll.mean(dim=0).sum()
+
+
+def hybrid_exact_loglik(mean1, scale1, mean2, scale2, W1_pos, W2_pos, V_pos, y, with_lgamma: bool = True):
+    """Hybrid_NSF_Exact (likelihoods.py:167-222): rate = V * (W1 exp(m1 + s1^2/2) + W2 exp(m2 + s2^2/2)), a (D,N)
+    matrix -- nothing is sampled, so the loops' `.mean(axis=0)` (utilities.py:510, 537) averages over GENES.
+    Returns (objective, rate)."""
+    rate = V_pos * (W1_pos @ torch.exp(mean1 + 0.5 * scale1 ** 2) + W2_pos @ torch.exp(mean2 + 0.5 * scale2 ** 2))
+    ll = y * torch.log(rate) - rate
+    if with_lgamma:
+        ll = ll - torch.lgamma(y + 1)
+    return ll.mean(dim=0).sum(), rate

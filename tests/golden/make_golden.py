@@ -499,10 +499,11 @@ if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "tra
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "state_dict"):
     state_dict_cases()
 
-if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1" and os.environ.get("GPZ_GOLDEN_ONLY", "") not in ("state_dict", "trajectory", "extra"):
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_POISSON", "1") == "1" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "poisson", "vnngp"):
     if os.environ.get("GPZ_GOLDEN_ONLY", "") != "vnngp":
         poisson_cases()
-    vnngp_cases()
+    if os.environ.get("GPZ_GOLDEN_ONLY", "") != "poisson":
+        vnngp_cases()
 
 
 def kernel_grad_cases():
@@ -671,3 +672,54 @@ def multiblock_cases():
 
 if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "multiblock"):
     multiblock_cases()
+
+
+def hybrid_exact_case():
+    """Hybrid_NSF_Exact (reference likelihoods.py:167-222): the rate is built from the log-normal mean
+    exp(m + s^2/2) -- no sampling, hence NO sample axis: pY.rate is (D,N) and the objective of the reference's
+    own loops, `pY.log_prob(y).mean(axis=0).sum()` (utilities.py:537) / `(y log r - r).mean(axis=0).sum()`
+    (utilities.py:510), averages over the GENE axis.  Stored: both objectives as those lines compute them and the
+    gradients of the first one's loss (train_hybrid's, with both KL terms) through the reference's autograd."""
+    N, M, L, T, D = 160, 36, 3, 2, 25
+    inp = make_inputs(900, N=N, M=M, d=2, L=L)
+    g = torch.Generator().manual_seed(911)
+    y = torch.poisson(3.0 * torch.rand(D, N, generator=g), generator=g).float()
+    kern = build_kernel("nsf_rbf", L).float()
+    gp = rgp.WSVGP(kern, dim=2, M=M, jitter=1e-2)
+    gp.Z = nn.Parameter(inp["Z"].float(), requires_grad=False)
+    gp.mu = nn.Parameter(0.2 * inp["mu"].float())
+    gp.Lu = nn.Parameter(inp["Lu_raw"].float())
+    for t in kern.parameters():
+        t.requires_grad_(False)
+    torch.manual_seed(11)
+    prior = rgp.GaussianPrior(y, L=T)
+    model = rl.Hybrid_NSF_Exact(gp, prior, y, L=L, T=T)
+    with torch.no_grad():
+        model.V.copy_(0.3 + torch.rand(N, generator=g))
+        prior.mean.copy_(0.3 * torch.randn(T, N, generator=g))
+    X = inp["X"].float()
+    pY, qF1, qU, pU, qF2, pF2 = model(X=X, E=7)
+    assert pY.rate.shape == (D, N) and pU is None
+    loglik = pY.log_prob(y).mean(axis=0).sum()                     # utilities.py:537
+    kl = torch.stack([whitened_KL(qU.mean[l], qU.scale_tril[l]) for l in range(L)]).sum()
+    loss = -(loglik - kl - distributions.kl_divergence(qF2, pF2).sum())
+    loss.backward()
+    idx = torch.arange(0, N, 3)
+    with torch.no_grad():
+        pYb = model.forward_batched(X=X, idx=idx, E=7)[0]
+        loglik_b = (y[:, idx] * torch.log(pYb.rate) - pYb.rate).mean(axis=0).sum()   # utilities.py:508-510
+    rec = dict(X=X.numpy(), Z=inp["Z"].float().numpy(), mu=gp.mu.detach().numpy(), Lu_raw=gp.Lu.detach().numpy(),
+               y=y.numpy(), sigma=kern.sigma.detach().numpy(), lengthscale=kern.lengthscale.detach().numpy(),
+               W=model.sf.W.detach().numpy(), W2=model.cf.W.detach().numpy(), V=model.V.detach().numpy(),
+               mean2=prior.mean.detach().numpy(), scale2=prior.scale.detach().numpy(),
+               loglik=np.float64(float(loglik)), loss=np.float64(float(loss)), rate=pY.rate.detach().numpy(),
+               idx_b=idx.numpy(), loglik_b=np.float64(float(loglik_b)),
+               grad_W=model.sf.W.grad.numpy(), grad_W2=model.cf.W.grad.numpy(), grad_V=model.V.grad.numpy(),
+               grad_mu=gp.mu.grad.numpy(), grad_Lu=gp.Lu.grad.numpy(), grad_mean2=prior.mean.grad.numpy(),
+               grad_scale2=prior.scale.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, "poisson_hybrid_nsf_exact_f32.npz"), **rec)
+    print(f"poisson_hybrid_nsf_exact_f32: loglik={float(loglik):.6f} loglik_b={float(loglik_b):.6f}")
+
+
+if __name__ == "__main__" and os.environ.get("GPZ_GOLDEN_ONLY", "") in ("", "hybrid_exact"):
+    hybrid_exact_case()

@@ -114,3 +114,18 @@ def from_wire(obj):
     if isinstance(obj, dict):
         return {k: from_wire(v) for k, v in obj.items()}
     return obj
+
+
+def record(name: str, rec: dict, append: bool = False) -> None:
+    """Write a measurement a test made to $GPZ_TEST_RECORD_DIR/<name> (nothing when the variable is unset: a test run
+    leaves no files behind; tools/_run_all_gpu.sh sets it to gpurun_out/ when the numbers are wanted)."""
+    import json
+    d = os.environ.get("GPZ_TEST_RECORD_DIR")
+    if not d:
+        return
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "a" if append else "w") as f:
+            f.write(json.dumps(rec) + ("\n" if append else ""))
+    except OSError:
+        pass

@@ -184,3 +184,48 @@ def test_user_defined_covariance_is_refused_not_replaced():
         k(X, X)
     with pytest.raises(RuntimeError, match="GPU only"):
         batched_RBF()(X, X)                      # the shipped form passes the check and then wants CUDA tensors
+
+
+def test_fused_qu_expands_like_a_multivariate_normal():
+    """q(U) of the training modules keeps its raw parameter and builds scale_tril lazily; `expand` -- which torch asks a
+    subclass with its own __init__ to define -- gives what the reference's plain MultivariateNormal gives."""
+    from torch import distributions
+    from gpzoo_amd.gp import _FusedQU
+    g = torch.Generator().manual_seed(0)
+    raw = torch.randn(3, 5, 5, generator=g, dtype=torch.float64)
+    loc = torch.randn(3, 5, generator=g, dtype=torch.float64)
+    q = _FusedQU(loc, raw=raw)
+    tril = raw.tril(-1) + torch.diag_embed(torch.diagonal(raw, dim1=-2, dim2=-1).exp())
+    ref = distributions.MultivariateNormal(loc, scale_tril=tril)
+    e, r = q.expand((2, 3)), ref.expand((2, 3))
+    assert e.batch_shape == r.batch_shape == (2, 3) and e.event_shape == r.event_shape
+    torch.testing.assert_close(e.scale_tril, r.scale_tril)
+    torch.testing.assert_close(e.loc, r.loc)
+    x = torch.randn(2, 3, 5, generator=g, dtype=torch.float64)
+    torch.testing.assert_close(e.log_prob(x), r.log_prob(x))
+    torch.testing.assert_close(distributions.kl_divergence(e, r), torch.zeros(2, 3, dtype=torch.float64))
+
+
+def test_reduce_scatter_through_a_c_abi_communicator_alone():
+    """parallel._dist_reduce_scatter with only an AbiCommunicator (no torch.distributed group): fp32 goes to
+    gpz_reduce_scatter_sum_f32, fp64 to the ABI's all-reduce + slice, anything else is refused by name."""
+    from gpzoo_amd import parallel
+
+    class Comm:                                    # the two entry points the function may take, with a 2-rank sum faked
+        world, rank = 2, 1
+        calls = []
+        def reduce_scatter_sum(self, t):
+            self.calls.append(("rs32", t.dtype)); return 2 * t[self.rank]
+        def allreduce_sum_(self, t):
+            self.calls.append(("ar64", t.dtype)); return t.mul_(2)
+    c = Comm()
+    assert not torch.distributed.is_initialized()
+    t32 = torch.arange(12, dtype=torch.float32).reshape(2, 2, 3)
+    torch.testing.assert_close(parallel._dist_reduce_scatter(t32, None, c), 2 * t32[1])
+    t64 = t32.double()
+    keep = t64.clone()
+    torch.testing.assert_close(parallel._dist_reduce_scatter(t64, None, c), 2 * keep[1])
+    torch.testing.assert_close(t64, keep)          # the caller's tensor is not summed in place
+    assert c.calls == [("rs32", torch.float32), ("ar64", torch.float64)]
+    with pytest.raises(ValueError, match="float32 or float64"):
+        parallel._dist_reduce_scatter(t32.half(), None, c)

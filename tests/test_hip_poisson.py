@@ -76,6 +76,51 @@ def test_fused_expected_loglik_and_gradients_match_reference(name, hybrid):
         close(model.cf.prior.scale.grad, c["grad_scale2"])
 
 
+def test_hybrid_exact_closed_form_objective_matches_reference():
+    """Hybrid_NSF_Exact (likelihoods.py:167-222): no sampling, a (D,N) rate, and the reference loops' `.mean(axis=0)`
+    therefore averages over genes.  `forward`'s rate, `expected_loglik` (what train_hybrid / train_hybrid_batched take
+    with fused=True) and every gradient against the reference's own run (tests/golden/make_golden.py hybrid_exact_case);
+    the fused and the literal form of the loop give the same loss."""
+    from gpzoo.gp import GaussianPrior, WSVGP
+    from gpzoo.kernels import NSF_RBF
+    from gpzoo.likelihoods import Hybrid_NSF_Exact
+    from gpzoo.utilities import whitened_KL_batched
+    c = load("poisson_hybrid_nsf_exact_f32")
+    L, M = c["mu"].shape
+    k = NSF_RBF(L=L)
+    k.sigma = nn.Parameter(c["sigma"].clone(), requires_grad=False)
+    k.lengthscale = nn.Parameter(c["lengthscale"].clone(), requires_grad=False)
+    gp = WSVGP(k, dim=2, M=M, jitter=1e-2)
+    gp.Z = nn.Parameter(c["Z"].clone(), requires_grad=False)
+    gp.mu = nn.Parameter(c["mu"].clone()); gp.Lu = nn.Parameter(c["Lu_raw"].clone())
+    y = c["y"]
+    prior = GaussianPrior(y, L=c["W2"].shape[1])
+    prior.mean = nn.Parameter(c["mean2"].clone()); prior.scale = nn.Parameter(c["scale2"].clone())
+    model = Hybrid_NSF_Exact(gp, prior, y, L=L, T=c["W2"].shape[1])
+    model.sf.W = nn.Parameter(c["W"].clone()); model.cf.W = nn.Parameter(c["W2"].clone())
+    model.V = nn.Parameter(c["V"].clone())
+    model = model.cuda()
+    X, yd = c["X"].cuda(), y.cuda()
+    with torch.no_grad():
+        pY = model(X=X, E=7)[0]
+    assert pY.rate.shape == tuple(c["rate"].shape)                 # (D,N): no sample axis
+    close(pY.rate, c["rate"], rt=1e-3)
+    assert float(pY.log_prob(yd).mean(0).sum()) == pytest.approx(c["loglik"], rel=1e-4)
+    res = model.expected_loglik(X, yd, E=7)
+    assert float(res[0].detach()) == pytest.approx(c["loglik"], rel=1e-4)
+    loss = -(res[0] - whitened_KL_batched(res[2].mean, res[2].scale_tril).sum()
+             - torch.distributions.kl_divergence(res[4], res[5]).sum())
+    assert float(loss.detach()) == pytest.approx(c["loss"], rel=1e-4)
+    loss.backward()
+    close(model.sf.W.grad, c["grad_W"]); close(model.cf.W.grad, c["grad_W2"]); close(model.V.grad, c["grad_V"])
+    close(gp.mu.grad, c["grad_mu"]); close(gp.Lu.grad, c["grad_Lu"])
+    close(prior.mean.grad, c["grad_mean2"]); close(prior.scale.grad, c["grad_scale2"])
+    idx = c["idx_b"].long().cuda()
+    with torch.no_grad():
+        llb = model.expected_loglik(X, yd[:, idx], idx=idx, with_lgamma=False)[0]
+    assert float(llb) == pytest.approx(c["loglik_b"], rel=1e-4)     # train_hybrid_batched's y log r - r form
+
+
 def test_api_forward_returns_reference_shapes():
     """pY is a real Poisson over the (E, D, N) rate; with the replayed noise its rate sums to the reference's."""
     import torch.distributions.normal as tdn

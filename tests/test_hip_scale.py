@@ -137,9 +137,7 @@ def test_config5_multi_panel_fp64_against_oracle():
 def test_fp32_at_reference_default_jitter(M, small_Lu):
     """fp32, RBF, lengthscale 5 on |x| <= 100, the reference's DEFAULT jitter 1e-4 (gp.py:150, 236): the path must
     either meet north_star's 1e-3 against the fp64 oracle or raise LinAlgError like torch's fp32 Cholesky does --
-    never return silently wrong moments.  The outcome is recorded under gpurun_out/ (DESIGN §2 quotes it)."""
-    import json
-    import os
+    never return silently wrong moments.  The outcome is recorded under $GPZ_TEST_RECORD_DIR when set (DESIGN §2 quotes it)."""
     from gpzoo_amd.synthetic import make_config
     c = make_config(2, N=4000, M=M, L=2)
     c["lengthscale"] = torch.full_like(c["lengthscale"], 5.0)
@@ -162,13 +160,8 @@ def test_fp32_at_reference_default_jitter(M, small_Lu):
         torch.testing.assert_close(out["mean"].double().cpu(), mean, rtol=1e-3, atol=1e-3 * float(mean.abs().max()))
         torch.testing.assert_close(out["scale"].double().cpu(), scale, rtol=1e-3, atol=0)
     finally:
-        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-        try:
-            os.makedirs(d, exist_ok=True)
-            with open(os.path.join(d, "fp32_default_jitter.jsonl"), "a") as f:
-                f.write(json.dumps(rec) + "\n")
-        except OSError:
-            pass
+        from helpers import record
+        record("fp32_default_jitter.jsonl", rec, append=True)
 
 
 def test_config3_scaled():

@@ -71,7 +71,7 @@ def test_neighbour_table_at_slideseq_coordinates_matches_reference(tag):
     ranks torch.cdist's fp32 matmul-expansion distances (error up to 0.06 there), so gpz_knn reproduces that
     arithmetic for the ordering (csrc/vnngp.hip, knn_kernel<.., MM>).  What can still differ: torch's CPU fp32 sqrt
     is not correctly rounded and its argsort is not stable, so two candidates whose reference distances tie may swap.
-    The count of differing rows is recorded (gpurun_out/vnngp_scale_f32.json) and bounded."""
+    The count of differing rows is recorded ($GPZ_TEST_RECORD_DIR/vnngp_scale_f32.json when set) and bounded."""
     import json
     from gpzoo_amd import _lib, ops
     from gpzoo_amd.ops import KernelSpec
@@ -97,13 +97,8 @@ def test_neighbour_table_at_slideseq_coordinates_matches_reference(tag):
     scale_err = float(((out["scale"].cpu() - c["scale"]).abs() / c["scale"]).max())
     rec = dict(N=int(X.shape[0]), M=int(Z.shape[0]), K=K, rows_differing=rows_diff, rows_with_different_set=set_diff,
                rows_explained_by_reference_ties=explained, mean_max_abs_err=mean_err, scale_max_rel_err=scale_err)
-    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    try:
-        os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, f"vnngp_scale_{tag}.json"), "w") as f:
-            json.dump(rec, f)
-    except OSError:
-        pass
+    from helpers import record
+    record(f"vnngp_scale_{tag}.json", rec)
     assert rows_diff == explained, rec                  # every difference sits on a tie of the reference's own keys
     assert rows_diff <= 0.01 * X.shape[0], rec
     assert (mean_err <= 2e-3 and scale_err <= 2e-3) if tag == "f32" else (mean_err <= 1e-8 and scale_err <= 1e-8), rec
@@ -185,6 +180,51 @@ def test_backward_against_oracle_autograd_with_clamped_points(frozen):
         close(res[2][:, 0], sig.grad, "grad_sigma")
         close(res[2][:, 1], ell.grad, "grad_lengthscale")
         close(res[3], Z.grad, "grad_Z")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_caller_table_with_repeated_neighbours(dtype):
+    """A caller-supplied neighbour table may name an inducing point twice (the reference's gathers and its inverse of
+    little_Kzz + jitter I accept that, gp.py:66-77).  The fixed-order gather then adds lane after lane instead of one lane
+    per column: forward and every gradient against torch autograd over the oracle on the same table, and bitwise equal
+    between two runs."""
+    from gpzoo_amd import _lib, ops
+    from gpzoo_amd.ops import KernelSpec
+    from oracle import svgp_oracle as O
+    N, M, K, L = 1500, 120, 9, 2
+    f64 = torch.float64
+    g = torch.Generator().manual_seed(5)
+    X = (torch.rand(N, 2, generator=g, dtype=f64) - 0.5) * 30
+    Z = ((torch.rand(M, 2, generator=g, dtype=f64) - 0.5) * 30).requires_grad_()
+    sig = (0.6 + 0.3 * torch.rand(L, generator=g, dtype=f64)).requires_grad_()
+    ell = (2.0 + 3 * torch.rand(L, generator=g, dtype=f64)).requires_grad_()
+    mu = torch.randn(L, M, generator=g, dtype=f64).requires_grad_()
+    Lu = (0.05 * torch.randn(L, M, M, generator=g, dtype=f64) - 1.0 * torch.eye(M, dtype=f64)).requires_grad_()
+    a = torch.randn(L, N, generator=g, dtype=f64)
+    b = torch.randn(L, N, generator=g, dtype=f64)
+    idx = torch.argsort(torch.cdist(X, Z.detach()), dim=1)[:, :K].clone()
+    idx[::3, K - 1] = idx[::3, 0]                  # a pair
+    idx[1::7, 4] = idx[1::7, 2]; idx[1::7, 6] = idx[1::7, 2]    # a triple
+    idx[5::11, :] = idx[5::11, :1]                 # every slot the same inducing point
+    jitter = 1e-2
+    mean, scale, _, _, _ = O.vnngp_moments(X, Z, sig, ell, mu, Lu, jitter, K, idx=idx)
+    ((a * mean).sum() + (b * scale).sum()).backward()
+    c = lambda t: t.detach().to(dtype).cuda()
+    spec = KernelSpec(_lib.KERNEL_RBF, c(sig), c(ell), True)
+    out = ops.vnngp_forward(spec, c(X), c(Z), c(mu), c(Lu), jitter, K, idx=idx.cuda())
+    rt = 1e-7 if dtype == f64 else 2e-3
+    torch.testing.assert_close(out["mean"].double().cpu(), mean.detach(), rtol=rt, atol=rt * float(mean.abs().max()))
+    torch.testing.assert_close(out["scale"].double().cpu(), scale.detach(), rtol=rt, atol=rt * 1e-2)
+    runs = [ops.vnngp_backward(spec, c(X), c(Z), c(mu), c(Lu), jitter, K, idx.cuda(), c(a), c(b), kernel_grads=True)
+            for _ in range(2)]
+    for x, y in zip(*runs):
+        assert torch.equal(x, y)
+    res = runs[0]
+    def close(got, ref, name):
+        torch.testing.assert_close(got.double().cpu(), ref, rtol=rt, atol=rt * float(ref.abs().max()), msg=lambda m: f"{name}: {m}")
+    close(res[0], mu.grad, "grad_mu"); close(res[1], Lu.grad, "grad_Lu")
+    close(res[2][:, 0], sig.grad, "grad_sigma"); close(res[2][:, 1], ell.grad, "grad_lengthscale")
+    close(res[3], Z.grad, "grad_Z")
 
 
 def test_vnngp_trains():

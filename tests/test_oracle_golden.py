@@ -122,3 +122,42 @@ def test_oracle_reproduces_the_reference_on_config2_as_stated():
     idx = torch.from_numpy(z["f64_idx"])
     torch.testing.assert_close(mean[:, idx], torch.from_numpy(z["f64_mean"]), rtol=1e-9, atol=1e-11)
     torch.testing.assert_close(scale[:, idx], torch.from_numpy(z["f64_scale"]), rtol=1e-9, atol=1e-11)
+
+
+def _poisson_fixture(name):
+    import os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    t = {k: (torch.from_numpy(z[k]) if z[k].ndim else float(z[k])) for k in z.files}
+    L, N = t["mu"].shape[0], t["X"].shape[0]
+    _, mean, scale = O.elbo_eval("rbf", True, t["X"], torch.zeros(L, N), t["Z"], t["sigma"], t["lengthscale"], t["mu"],
+                                 t["Lu_raw"], 1e-2, 1.0)
+    return t, mean, scale
+
+
+@pytest.mark.parametrize("name", ["poisson_nsf2_f32", "poisson_hybrid_nsf2_f32"])
+def test_oracle_poisson_objective(name):
+    """The sampled Poisson objective of the reference's loops (replayed rsample noise) from the oracle's q(F)."""
+    sp = torch.nn.functional.softplus
+    t, mean, scale = _poisson_fixture(name)
+    eps, W = t["eps1"], sp(t["W"])
+    if "W2" in t:
+        mean, scale = torch.cat([mean, t["mean2"]]), torch.cat([scale, sp(t["scale2"])])
+        eps, W = torch.cat([eps, t["eps2"]], dim=1), torch.cat([W, sp(t["W2"])], dim=1)
+    ll = O.poisson_expected_loglik(mean, scale, eps, W, sp(t["V"]), t["y"])
+    assert float(ll) == pytest.approx(t["loglik"], rel=2e-5)
+
+
+def test_oracle_hybrid_exact_objective():
+    """Hybrid_NSF_Exact: the (D,N) closed-form rate and both loop objectives (mean over the gene axis) as the reference
+    itself computed them (make_golden.py hybrid_exact_case)."""
+    sp = torch.nn.functional.softplus
+    t, mean, scale = _poisson_fixture("poisson_hybrid_nsf_exact_f32")
+    args = (mean, scale, t["mean2"], sp(t["scale2"]), sp(t["W"]), sp(t["W2"]))
+    ll, rate = O.hybrid_exact_loglik(*args, sp(t["V"]), t["y"])
+    torch.testing.assert_close(rate, t["rate"], rtol=2e-4, atol=1e-5)
+    assert float(ll) == pytest.approx(t["loglik"], rel=2e-5)
+    idx = t["idx_b"].long()
+    llb, _ = O.hybrid_exact_loglik(mean[:, idx], scale[:, idx], t["mean2"][:, idx], sp(t["scale2"])[:, idx], sp(t["W"]),
+                                   sp(t["W2"]), sp(t["V"])[idx], t["y"][:, idx], with_lgamma=False)
+    assert float(llb) == pytest.approx(t["loglik_b"], rel=2e-5)

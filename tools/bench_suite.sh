@@ -20,20 +20,20 @@ print("  value %.4f %s | %.2f ms/step | %s %.1f TF (frac %.3f; sclk %.0f MHz: fr
 PY
 }
 echo "== config 3 (default): N=200k M=2048 L=32 Matern-3/2 fp32, with forward+backward"
-python3 bench.py --no-cpu-baseline --with-backward > /tmp/b.log 2>/dev/null; one /tmp/b.log
+python3 bench.py --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 2: N=50k M=512 L=8 RBF fp32, with forward+backward"
-python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline --with-backward > /tmp/b.log 2>/dev/null; one /tmp/b.log
+python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 2 on the fill + tile kernels (GPZ_SVGP_PRODUCTS=tiles; the line above is the panel kernel: fill and both products in one launch, kfill 0)"
-GPZ_SVGP_PRODUCTS=tiles python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+GPZ_SVGP_PRODUCTS=tiles python3 bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== N=200k M=256 L=32 Matern-3/2 fp32: the panel kernel (the library's choice for M <= 512); then the tile kernels (GPZ_SVGP_PRODUCTS=tiles)"
-python3 bench.py --N 200000 --M 256 --L 32 --steps 8 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
-GPZ_SVGP_PRODUCTS=tiles python3 bench.py --N 200000 --M 256 --L 32 --steps 8 --warmup 3 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+python3 bench.py --N 200000 --M 256 --L 32 --steps 8 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/b.log 2>/dev/null; one /tmp/b.log
+GPZ_SVGP_PRODUCTS=tiles python3 bench.py --N 200000 --M 256 --L 32 --steps 8 --warmup 3 --no-cpu-baseline --no-extra-legs > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 5: MGGP 4 groups, N=200k M=2048 fp64, L=32 on one GPU"
-python3 bench.py --config 5 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+python3 bench.py --config 5 --no-cpu-baseline --no-extra-legs > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 5 as sharded over 8 GPUs: 4 latents per GPU"
-python3 bench.py --config 5 --L 4 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+python3 bench.py --config 5 --L 4 --no-cpu-baseline --no-extra-legs > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== config 4 on one GPU: L=256"
-python3 bench.py --L 256 --steps 1 --warmup 1 --no-cpu-baseline > /tmp/b.log 2>/dev/null; one /tmp/b.log
+python3 bench.py --L 256 --steps 1 --warmup 1 --no-cpu-baseline --no-extra-legs > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== minibatch training step (N_b=7000, M=3000, L=20, fp32): tools/minibatch_step.py"
 python3 tools/minibatch_step.py 2>/dev/null | grep step
 echo "== Poisson NSF minibatch step: tools/poisson_step.py (E = 3, then E = 20 in one call)"
@@ -54,7 +54,7 @@ python3 tools/coop_trace.py 32 2048 1 2>/dev/null | grep -v "    D("
 python3 tools/coop_trace.py 8 512 1 2>/dev/null | grep -v "    D("
 python3 tools/coop_trace.py 20 3072 1 2>/dev/null | grep -v "    D("
 echo "== config 3 with the launch-per-step factor path, for comparison"
-GPZ_FACTOR_PATH=launches python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 > /tmp/b.log 2>/dev/null; one /tmp/b.log
+GPZ_FACTOR_PATH=launches python3 bench.py --no-cpu-baseline --no-extra-legs --steps 5 --warmup 2 > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== minibatch step with the launch-per-step factor path"
 GPZ_FACTOR_PATH=launches python3 tools/minibatch_step.py 2>/dev/null | grep step
 echo "== python bench.py --gpus 2 as typed (two ranks on this one GPU, gloo rendezvous: a rehearsal, not a scaling number)"
