@@ -114,13 +114,14 @@ def train_leg(ops, spec, g, c, extra, chunk, reps=2) -> dict:
         for _ in range(reps):
             ev0.record()
             handoff = ops.FactorCache()
-            o = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
-                                 chunk=chunk, want_Lu=False, retain_wt=1.0 / 3, cache=handoff, **extra)
-            gmean = (o["mean"] - g["y"]) / c["noise_sd"] ** 2      # d(-ELBO)/dmean of the Gaussian closed form
-            gscale = o["scale"] / c["noise_sd"] ** 2                 # d(-ELBO)/dscale
-            ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], gmean,
-                              gscale, o["scale"], chunk=chunk, kernel_grads=kg, wt_cache=o.pop("wt_cache", None),
-                              cache=handoff, trust_cache=True, trust_qu=True, **extra)
+            with ops.deferred_info():          # as gpzoo.utilities.train* do: `info` is read once, behind the backward's launches
+                o = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"],
+                                     chunk=chunk, want_Lu=False, retain_wt=1.0 / 3, cache=handoff, **extra)
+                gmean = (o["mean"] - g["y"]) / c["noise_sd"] ** 2      # d(-ELBO)/dmean of the Gaussian closed form
+                gscale = o["scale"] / c["noise_sd"] ** 2                 # d(-ELBO)/dscale
+                ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], c["jitter"], c["whitened"], gmean,
+                                  gscale, o["scale"], chunk=chunk, kernel_grads=kg, wt_cache=o.pop("wt_cache", None),
+                                  cache=handoff, trust_cache=True, trust_qu=True, **extra)
             ev1.record()
             torch.cuda.synchronize()
             out[mode] = ev0.elapsed_time(ev1)

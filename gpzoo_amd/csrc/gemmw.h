@@ -40,16 +40,21 @@ struct WideArgs {
 bool wide_product_supported(int64_t Mp, int64_t ncp);
 int wide_product_launch(const WideArgs& a, hipStream_t s);
 
-// C (L, Mp, Mp) += A (L, Mp, K) * diag(w) * B (L, Mp, K)^T, lower 128-tiles only (the tiles on the diagonal are written
-// whole), fp32: the backward pass's gradient accumulation over an N-chunk (A == B: H += W diag(gv2) W^T).  w (L, K): column
-// weights, or null.  gate: device word -- when it is zero the launch leaves C alone (the rarely needed correction for
+// C (L, Mp, Mp) += A (L, Mp, K) * diag(w) * B (L, Mp, K)^T, lower 128-tiles only, fp32: the backward pass's gradient
+// accumulation over an N-chunk (A == B: H += W diag(gv2) W^T).  w (L, K): column weights, or null.  The blocks on the
+// diagonal are written whole, except for the symmetric product (A == B with weights): there only their 16 x 16
+// sub-tiles on and below the diagonal are computed and written (36 of 64; the caller mirrors the triangle).  gate: device word -- when it is zero the launch leaves C alone (the rarely needed correction for
 // columns at the variance clamp), or null.
 bool wide_nt_supported(int64_t Mp, int64_t K);
 // With few tiles (small M, few latents) the k extent is cut into pieces that run side by side and are added up in a fixed
 // order; `scratch`: wide_nt_scratch_floats(Mp, K, L) floats (0: never cut), or null: one workgroup per tile walks all of k.
 int wide_nt_pieces(int64_t Mp, int64_t K, int L);
 size_t wide_nt_scratch_floats(int64_t Mp, int64_t K, int L);
+// gm (L, K) with A == B and weights: the launch also forms v[l * v_stride + m] = sum_k A[l][m][k] gm[l][k] (fp64; the tiles
+// on the diagonal do it from the fragments they hold) through vpart: wide_nt_vpart_floats(Mp, K, L) floats.
+size_t wide_nt_vpart_floats(int64_t Mp, int64_t K, int L);
 int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s, float* scratch = nullptr,
-                   const float* w = nullptr, const int32_t* gate = nullptr);
+                   const float* w = nullptr, const int32_t* gate = nullptr, const float* gm = nullptr, float* vpart = nullptr,
+                   double* v = nullptr, int64_t v_stride = 0);
 
 }  // namespace gpz

@@ -43,6 +43,7 @@
 
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 // Timing-only diagnostics (WRONG results by construction; tools/ablate_fused.sh builds them next to the real library):
 // -DGPZ_W_ABL=<bits>  1: no covariance arithmetic (the generated B tile holds a coordinate), 2: no tile loads after the
@@ -515,6 +516,10 @@ struct NTParams {
   float* part; int64_t sPart;
   const float* w; int64_t sW;               // column weights (L, K): C += A diag(w) B^T (applied to B's fragments), or null
   const int32_t* gate;                      // device word: the launch does nothing when it is zero (null: always runs)
+  // A gm (WTS only): per (piece, matrix) the product of A's rows with the vector gm (L, K), formed by the tiles on the
+  // diagonal from the A fragments they hold anyway (dLoss/dmuE = W gm: a separate pass over W was a third of this
+  // kernel's time at configs[1]); vpart [S][L][Mp], or null
+  const float* gm; float* vpart;
 };
 
 // TM = 256: 8 waves, two 128-row blocks per tile; TM = 128 (few blocks: at four 128-blocks the 256-row tile computes 12
@@ -600,26 +605,113 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #endif
   };
   // the step's 16 column weights: lane group q owns k = 4q .. 4q+3 of a 16-deep step, so one 16-byte load per lane and
-  // step, issued with the step's tile loads (one step ahead) and waited for with them
+  // step.  ONE register set: a step's weights are consumed at its top (B's fragments are scaled as they are read) and
+  // the next step's are requested right behind that -- the wait for the tile loads at the end of the step covers them.
   const float* wk = WTS ? p.w + b0 * p.sW + (int64_t)piece * p.Ks + 4 * (lane >> 4) : nullptr;
-  f32x4 wv[2];
-  auto w_load = [&](int buf) __attribute__((always_inline)) {
-    if constexpr (WTS) { wv[buf] = *reinterpret_cast<const f32x4*>(wk); wk += BK; }
+  f32x4 wv;
+  auto w_load = [&]() __attribute__((always_inline)) {
+    if constexpr (WTS) { wv = *reinterpret_cast<const f32x4*>(wk); wk += BK; }
   };
+  const int fr_a = (wm * 128 + r) * BK + ((q ^ gperm(r)) * 4);
+  const int nk = (min(p.K, (piece + 1) * p.Ks) - piece * p.Ks) / BK;      // even: K is a multiple of 128, Ks of 32
+  const bool split = p.S > 1;
+  // A block ON the diagonal of the symmetric product A diag(w) A^T (WTS, A == B): only its lower triangle is wanted (the
+  // caller mirrors it), so the wave computes the 16 x 16 sub-tiles (mi, c) with mi >= c only -- 36 of the block's 64.
+  // Wave wn takes the column sub-tiles wn and 7 - wn (8 - wn and wn + 1 row sub-tiles: 9 for every wave, against 16 for a
+  // full 128 x 32 strip) as a code path of its own with compile-time ranges (no MFMA under a run-time branch); the steps and
+  // barriers are those of the other waves.  It also forms its rows' share of A gm (sub-tiles 2 wn, 2 wn + 1) from the A
+  // fragments it reads anyway: no separate pass over A for dLoss/dmuE.
+  const bool diag = WTS && p.A == p.B && db == tj && db < p.nblk;      // wave-uniform
+  if (diag) {
+    auto diag_path = [&](auto wn_c) __attribute__((always_inline)) {
+      constexpr int C0 = decltype(wn_c)::value, C1 = 7 - C0, N0 = 8 - C0, N1 = 8 - C1;
+      const bool rd = p.gm != nullptr;
+      const float* gk = rd ? p.gm + b0 * p.sW + (int64_t)piece * p.Ks + 4 * (lane >> 4) : nullptr;
+      f32x4 gv = f32x4{0, 0, 0, 0};
+      float pv0 = 0.f, pv1 = 0.f;
+      f32x4 a0[N0], a1[N1];
+#pragma unroll
+      for (int i = 0; i < N0; ++i) a0[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < N1; ++i) a1[i] = f32x4{0, 0, 0, 0};
+      const int fb_off = r * BK + ((q ^ gperm(r)) * 4) + (same ? -A_ELEMS : 0);
+      auto step = [&](int buf, bool more) __attribute__((always_inline)) {
+        f32x4 f0 = *reinterpret_cast<const f32x4*>(sB(buf) + fb_off + C0 * 16 * BK);
+        f32x4 f1 = *reinterpret_cast<const f32x4*>(sB(buf) + fb_off + C1 * 16 * BK);
+        f0 *= wv; f1 *= wv;
+        if (more) w_load();
+#pragma unroll
+        for (int mi = C0; mi < 8; ++mi) {
+          const f32x4 fa = *reinterpret_cast<const f32x4*>(sA(buf) + fr_a + mi * 16 * BK);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            a0[mi - C0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], f0[j], a0[mi - C0], 0, 0, 0);
+            if (mi >= C1) a1[mi >= C1 ? mi - C1 : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], f1[j], a1[mi >= C1 ? mi - C1 : 0], 0, 0, 0);
+          }
+          if (mi == 2 * C0 || mi == 2 * C0 + 1) {
+            if (rd) {
+              const f32x4 t = fa * gv;
+              if (mi == 2 * C0) pv0 += (t[0] + t[1]) + (t[2] + t[3]); else pv1 += (t[0] + t[1]) + (t[2] + t[3]);
+            }
+          }
+        }
+        if (more && rd) { gv = *reinterpret_cast<const f32x4*>(gk); gk += BK; }
+      };
+      if (rd) { gv = *reinterpret_cast<const f32x4*>(gk); gk += BK; }
+      stage_load(0);
+      w_load();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int t = 0; t < nk; t += 2) {
+        if (t + 1 < nk) stage_load(1);
+        step(0, t + 1 < nk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < nk) stage_load(0);
+        step(1, t + 2 < nk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (rd) {                    // rows r + 16 mi of the block: sum the four k-slot groups, lanes 0..15 write
+        float* vp = p.vpart + ((int64_t)piece * p.L + b0) * Mp + db * 128;
+        pv0 += __shfl_xor(pv0, 16); pv0 += __shfl_xor(pv0, 32);
+        pv1 += __shfl_xor(pv1, 16); pv1 += __shfl_xor(pv1, 32);
+        if (q == 0) { vp[(2 * C0) * 16 + r] = pv0; vp[(2 * C0 + 1) * 16 + r] = pv1; }
+      }
+      // accumulator (row 4q + g, column r) of sub-tile (mi, c): 64-byte row segments, once per tile
+      float* Cg = (split ? p.part + piece * p.sPart : p.C) + b0 * p.sC + (int64_t)db * 128 * p.ldc + (int64_t)tj * TN;
+      auto put = [&](const f32x4& a, int mi, int c) __attribute__((always_inline)) {
+        float* o = Cg + (int64_t)(mi * 16 + 4 * q) * p.ldc + c * 16 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o[g * p.ldc] = split ? a[g] : o[g * p.ldc] + a[g];
+      };
+#pragma unroll
+      for (int mi = C0; mi < 8; ++mi) put(a0[mi - C0], mi, C0);
+#pragma unroll
+      for (int mi = C1; mi < 8; ++mi) put(a1[mi - C1], mi, C1);
+    };
+    switch (wn) {
+      case 0: diag_path(std::integral_constant<int, 0>{}); break;
+      case 1: diag_path(std::integral_constant<int, 1>{}); break;
+      case 2: diag_path(std::integral_constant<int, 2>{}); break;
+      default: diag_path(std::integral_constant<int, 3>{}); break;
+    }
+    return;
+  }
   f32x4 acc[8][2];
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0, 0, 0, 0};
-  const int fr_a = (wm * 128 + r) * BK + ((q ^ gperm(r)) * 4);
   const int fr_b = (wn * 32 + r) * BK + ((q ^ gperm(r)) * 4) + (same ? -A_ELEMS : 0);
-  auto mma_step = [&](int buf) __attribute__((always_inline)) {
+  auto mma_step = [&](int buf, bool more) __attribute__((always_inline)) {
     f32x4 fb[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       fb[ni] = *reinterpret_cast<const f32x4*>(sB(buf) + fr_b + ni * 16 * BK);
-      if constexpr (WTS) fb[ni] *= wv[buf];
+      if constexpr (WTS) fb[ni] *= wv;
     }
+    if (more) w_load();
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       f32x4 fa[4];
@@ -634,20 +726,19 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             acc[half * 4 + m][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m][j], fb[ni][j], acc[half * 4 + m][ni], 0, 0, 0);
     }
   };
-  const int nk = (min(p.K, (piece + 1) * p.Ks) - piece * p.Ks) / BK;      // even: K is a multiple of 128, Ks of 32
   stage_load(0);
-  w_load(0);
+  w_load();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // (the wave-uniform `active` test sits outside the loops: no MFMA under a run-time branch)
   if (active) {
     for (int t = 0; t < nk; t += 2) {
-      if (t + 1 < nk) { stage_load(1); w_load(1); }
-      mma_step(0);
+      if (t + 1 < nk) stage_load(1);
+      mma_step(0, t + 1 < nk);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (t + 2 < nk) { stage_load(0); w_load(0); }
-      mma_step(1);
+      if (t + 2 < nk) stage_load(0);
+      mma_step(1, t + 2 < nk);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -666,7 +757,6 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   // into pieces, a plain store of this piece's partial tile
   constexpr int LDE = 36;
   float* strip = smem + wave * (32 * LDE);
-  const bool split = p.S > 1;
   float* Cg = (split ? p.part + piece * p.sPart : p.C) + b0 * p.sC + (int64_t)db * 128 * p.ldc + (int64_t)tj * TN + wn * 32;
   const int srow = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
@@ -694,15 +784,26 @@ __global__ __launch_bounds__(TM * 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 
 // C += part[0] + part[1] + ... (ascending: reproducible) over the 128-blocks the product computes (column block <= row block)
 __global__ __launch_bounds__(256) void nt_reduce_kernel(float* __restrict__ C, const float* __restrict__ part, int S, int64_t sPart,
-                                                        int Mp, int64_t total4, const int32_t* __restrict__ gate) {
+                                                        int Mp, int64_t total4, const int32_t* __restrict__ gate, int sym) {
   const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i4 >= total4 || (gate && *gate == 0)) return;
   const int64_t e = i4 * 4;
   const int col = (int)(e % Mp), row = (int)((e / Mp) % Mp);
-  if ((col >> 7) > (row >> 7)) return;
+  // (symmetric product: the blocks on the diagonal hold their lower 16 x 16 sub-tiles only)
+  if ((col >> 7) > (row >> 7) || (sym && (col >> 4) > (row >> 4))) return;
   f32x4 v = *reinterpret_cast<const f32x4*>(C + e);
   for (int s = 0; s < S; ++s) v += *reinterpret_cast<const f32x4*>(part + s * sPart + e);
   *reinterpret_cast<f32x4*>(C + e) = v;
+}
+
+// v[l][m] = sum over the pieces (ascending) of vpart[piece][l][m], in fp64
+__global__ __launch_bounds__(256) void nt_vsum_kernel(const float* __restrict__ vpart, int S, int64_t LM, double* __restrict__ v,
+                                                      int64_t Mp, int64_t v_stride) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= LM) return;
+  double t = 0.0;
+  for (int s = 0; s < S; ++s) t += (double)vpart[s * LM + i];
+  v[(i / Mp) * v_stride + i % Mp] = t;
 }
 
 // ---------------- host side ----------------
@@ -860,16 +961,19 @@ int wide_nt_pieces(int64_t Mp, int64_t K, int L) {
   return (int)std::max<int64_t>(S, 1);
 }
 
+size_t wide_nt_vpart_floats(int64_t Mp, int64_t K, int L) { return (size_t)wide_nt_pieces(Mp, K, L) * L * Mp; }
+
 size_t wide_nt_scratch_floats(int64_t Mp, int64_t K, int L) {
   const int S = wide_nt_pieces(Mp, K, L);
   return S > 1 ? (size_t)S * L * Mp * Mp : 0;
 }
 
 int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t K, int L, hipStream_t s, float* scratch,
-                   const float* w, const int32_t* gate) {
+                   const float* w, const int32_t* gate, const float* gm, float* vpart, double* v, int64_t v_stride) {
   GPZ_REQUIRE(A && B && C && wide_nt_supported(Mp, K) && L > 0, "wide A B^T: bad arguments");
+  GPZ_REQUIRE(!gm || (w && vpart && v && A == B), "wide A B^T: the row products A gm need weights, A == B and their buffers");
   NTParams p;
-  p.w = w; p.sW = K; p.gate = gate;
+  p.w = w; p.sW = K; p.gate = gate; p.gm = gm; p.vpart = vpart;
   p.A = A; p.B = B; p.C = C; p.ld = K; p.sAB = Mp * K; p.ldc = Mp; p.sC = Mp * Mp;
   p.K = (int)K; p.nblk = (int)(Mp / 128); p.mt = (p.nblk + 1) / 2; p.L = L;
   const bool small = nt_small_tiles(p.nblk);
@@ -892,7 +996,12 @@ int wide_nt_launch(const float* A, const float* B, float* C, int64_t Mp, int64_t
   GPZ_LAUNCH_OK();
   if (S > 1) {
     const int64_t total4 = (int64_t)L * Mp * Mp / 4;
-    hipLaunchKernelGGL(nt_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, C, scratch, S, p.sPart, (int)Mp, total4, gate);
+    hipLaunchKernelGGL(nt_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, C, scratch, S, p.sPart, (int)Mp, total4, gate, (int)(w != nullptr && A == B));
+    GPZ_LAUNCH_OK();
+  }
+  if (gm) {
+    const int64_t LM = (int64_t)L * Mp;
+    hipLaunchKernelGGL(nt_vsum_kernel, dim3((unsigned)((LM + 255) / 256)), dim3(256), 0, s, vpart, S, LM, v, Mp, v_stride);
     GPZ_LAUNCH_OK();
   }
   return 0;

@@ -427,6 +427,33 @@ __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ 
   for (size_t i = t0; i < nb; i += step) b[i] = 0u;
 }
 
+// Up to eight buffers zeroed by ONE launch (16-byte stores; sizes in bytes, multiples of 16: every buffer here is carved
+// at 256-byte boundaries and padded to 128 elements).  hipMemsetAsync is a launch of its own per buffer -- about 10 us of
+// host time each, and the backward pass of a small problem started with six of them.
+struct ZeroRanges { void* p[8]; size_t n16[8]; int n; };
+__global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges z) {
+  const size_t t0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+  for (int r = 0; r < z.n; ++r) {
+    uint4* q = static_cast<uint4*>(z.p[r]);
+    for (size_t i = t0; i < z.n16[r]; i += step) q[i] = uint4{0u, 0u, 0u, 0u};
+  }
+}
+struct Zeroer {
+  ZeroRanges z{};
+  size_t total = 0;
+  void add(void* p, size_t bytes) {
+    if (!p || !bytes) return;
+    z.p[z.n] = p; z.n16[z.n] = (bytes + 15) / 16; total += z.n16[z.n]; ++z.n;
+  }
+  int run(hipStream_t s) {
+    if (!z.n) return 0;
+    const unsigned grid = (unsigned)std::min<size_t>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(grid), dim3(256), 0, s, z);
+    GPZ_LAUNCH_OK();
+    return 0;
+  }
+};
+
 template <typename T>
 static int prepare_t(const gpz_svgp_problem* p, const Plan& pl, Buffers<T>& b, hipStream_t s) {
   const bool wh = p->whitened != 0;
@@ -1120,8 +1147,10 @@ template <typename T>
 struct BwdBuffers {
   T *Pc, *H, *G, *G2, *LinvT, *cs; double *mu_part, *mu_sum;
   float* nt_part;                            // fp32, few tiles: pieces of the A B^T accumulations (gemmw.hip, wide_nt_pieces)
+  float* nt_vpart;                           // fp32: per-piece W gm from the same launch
+  T* gmc;                                    // (L, nc) dLoss/dmean of the chunk, zero padded
   // kernel / Z gradients only
-  T *LuN, *Hd, *csc, *csd, *gmc, *PS; double *D1, *D2, *D3, *D4, *D5, *me, *kacc, *sig_direct;
+  T *LuN, *Hd, *csc, *csd, *PS; double *D1, *D2, *D3, *D4, *D5, *me, *kacc, *sig_direct;
   int32_t* any_d;                            // per chunk: does it hold a column at the whitened clamp (weights of Hd)?
   size_t bytes;
 };
@@ -1144,7 +1173,10 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* w
   b.mu_sum = c.take<double>(pl.L * pl.Mp);
   const size_t ntf = sizeof(T) == 4 && wide_nt_supported(pl.Mp, pl.nc) ? wide_nt_scratch_floats(pl.Mp, pl.nc, (int)pl.L) : 0;
   b.nt_part = ntf ? c.take<float>((int64_t)ntf) : nullptr;
-  b.LuN = b.Hd = b.csc = b.csd = b.gmc = b.PS = nullptr;
+  const bool ntw = sizeof(T) == 4 && wide_nt_supported(pl.Mp, pl.nc);
+  b.nt_vpart = ntw ? c.take<float>((int64_t)wide_nt_vpart_floats(pl.Mp, pl.nc, (int)pl.L)) : nullptr;
+  b.gmc = c.take<T>(pl.L * pl.nc);
+  b.LuN = b.Hd = b.csc = b.csd = b.PS = nullptr;
   b.D1 = b.D2 = b.D3 = b.D4 = b.D5 = b.me = b.kacc = b.sig_direct = nullptr;
   b.any_d = nullptr;
   if (full) {
@@ -1153,7 +1185,6 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* w
     b.PS = c.take<T>(mm);
     b.csc = c.take<T>(pl.L * pl.nc);
     b.csd = whitened ? c.take<T>(pl.L * pl.nc) : nullptr;
-    b.gmc = c.take<T>(pl.L * pl.nc);
     b.D1 = c.take<double>(mm);
     b.D2 = c.take<double>(mm);
     b.D3 = c.take<double>(mm);
@@ -1182,17 +1213,24 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   gpz_svgp_problem q = *p;          // forward-only outputs are not produced again
   q.chol = nullptr; q.Lu = nullptr;
   if (int rc = prepare_t<T>(&q, pl, b, s)) return rc;
-  GPZ_HIP_OK(hipMemsetAsync(w.H, 0, sizeof(T) * L * mm, s));
-  GPZ_HIP_OK(hipMemsetAsync(w.G, 0, sizeof(T) * L * mm, s));      // (its tiles above the diagonal are never written)
+  {
+    Zeroer z;
+    z.add(w.H, sizeof(T) * L * mm);
+    z.add(w.G, sizeof(T) * L * mm);          // (its tiles above the diagonal are never written)
+    if (!wh) z.add(w.G2, sizeof(T) * L * mm);
+    if (full) {
+      if (wh) {
+        z.add(w.Hd, sizeof(T) * L * mm);
+        z.add(w.any_d, sizeof(int32_t) * (pl.nchunks + 1));
+      }
+      z.add(w.kacc, sizeof(double) * L * Mp * 8);
+      z.add(w.sig_direct, sizeof(double) * L);
+    }
+    if (int rc = z.run(s)) return rc;
+  }
   const dim3 g32((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32);
   const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
   if (full) {
-    if (wh) {
-      GPZ_HIP_OK(hipMemsetAsync(w.Hd, 0, sizeof(T) * L * mm, s));
-      GPZ_HIP_OK(hipMemsetAsync(w.any_d, 0, sizeof(int32_t) * (pl.nchunks + 1), s));
-    }
-    GPZ_HIP_OK(hipMemsetAsync(w.kacc, 0, sizeof(double) * L * Mp * 8, s));
-    GPZ_HIP_OK(hipMemsetAsync(w.sig_direct, 0, sizeof(double) * L, s));
     // Lu (lower, not transposed) in GEMM precision and Linv^T
     if (wh) {
       hipLaunchKernelGGL((lu_prepare_kernel<T>), g32, dim3(256), 0, s, static_cast<const T*>(p->Lu_raw), M, Mp,
@@ -1256,8 +1294,10 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     // gets a weighted copy of W (in the Pbar buffer, free at this point)
     const bool wide_nt = sizeof(T) == 4 && wide && wide_nt_supported(Mp, ncp);
     auto syrk = [&](const T* wts, T* C, const int32_t* gate) -> int {
-      if (wide_nt) {
-        if constexpr (sizeof(T) == 4) return wide_nt_launch(Wc, Wc, C, Mp, ncp, L32, s, w.nt_part, wts, gate);
+      if (wide_nt) {          // (the main accumulation also forms v = W gm of the chunk, from its diagonal tiles)
+        if constexpr (sizeof(T) == 4)
+          return wide_nt_launch(Wc, Wc, C, Mp, ncp, L32, s, w.nt_part, wts, gate, gate ? nullptr : w.gmc,
+                                gate ? nullptr : w.nt_vpart, gate ? nullptr : w.mu_part + ci * Mp, pl.nchunks * Mp);
       }
       hipLaunchKernelGGL((scale_cols_kernel<T>), dim3((unsigned)((ncp + 255) / 256), (unsigned)Mp, L32), dim3(256), 0, s,
                          (const T*)Wc, wts, Mp, ncp, w.Pc);
@@ -1273,9 +1313,11 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     if (int rc = syrk(w.cs, w.H, nullptr)) return rc;                      // H  += W diag(gv2) W^T
     if (with_hd)
       if (int rc = syrk(w.csd, w.Hd, w.any_d + ci)) return rc;             // Hd += W diag(gv2 (1 - c)) W^T, if any
-    hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, Wc, Mp, ncp,
-                       static_cast<const T*>(g->g_mean), N, n0, w.mu_part, pl.nchunks, ci);
-    GPZ_LAUNCH_OK();
+    if (!wide_nt) {
+      hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, Wc, Mp, ncp,
+                         static_cast<const T*>(g->g_mean), N, n0, w.mu_part, pl.nchunks, ci);
+      GPZ_LAUNCH_OK();
+    }
     if (full) {
       {                  // Pbar = (LuE^T W) diag(gv2)
         bool done = false;
@@ -1418,8 +1460,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     GPZ_LAUNCH_OK();
     hipLaunchKernelGGL((transpose_cast_kernel<T>), g32, dim3(256), 0, s, b.Linv, Mp, w.LinvT, b.fro_part);
     GPZ_LAUNCH_OK();
-    GPZ_HIP_OK(hipMemsetAsync(w.G2, 0, sizeof(T) * L * mm, s));
-    GemmParams<T> g4;
+    GemmParams<T> g4;                  // (G2 was zeroed with the other accumulators: its upper tiles are never written)
     g4.A = w.LinvT; g4.lda = Mp; g4.sA0 = mm;
     g4.B = w.G; g4.ldb = Mp; g4.sB0 = mm;
     g4.C = w.G2; g4.ldc = Mp; g4.sC0 = mm;

@@ -200,7 +200,7 @@ class _FusedGP(nn.Module):
     def _distributions(self, out):
         single = self.mu.dim() == 1
         pick = (lambda t: t[0]) if single else (lambda t: t)
-        qF = distributions.Normal(pick(out["mean"]), pick(out["scale"]))
+        qF = ops.checked_dist(distributions.Normal, pick(out["mean"]), pick(out["scale"]))
         qU = _FusedQU(self.mu, scale_tril=pick(out["Lu"]), validate_args=False)
         if "kl" in out:
             qU._gpz_kl = pick(out["kl"].to(out["Lu"].dtype))
@@ -264,7 +264,7 @@ class _FusedGP(nn.Module):
                                                     self.kernel.lengthscale, gparam, call)
         single = self.mu.dim() == 1
         pick = (lambda t: t[0]) if single else (lambda t: t)
-        qF = distributions.Normal(pick(mean), pick(scale))
+        qF = ops.checked_dist(distributions.Normal, pick(mean), pick(scale))
         # q(U)'s scale_tril is the torch expression of the raw parameter (so that other uses of it differentiate w.r.t.
         # it), evaluated when first asked for: the training loops never do (_FusedQU)
         qU = _FusedQU(self.mu, raw=self.Lu)
@@ -348,7 +348,7 @@ class VNNGP(nn.Module):
             # q(U)'s scale_tril through torch so that other uses of it differentiate w.r.t. the raw parameter
             Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
             Lu = Lu.reshape(-1, Lu.shape[-2], Lu.shape[-1])
-        qF = distributions.Normal(pick(mean), pick(scale))
+        qF = ops.checked_dist(distributions.Normal, pick(mean), pick(scale))
         # valid by construction: skip the O(L M^2) scale_tril validation
         qU = _FusedQU(self.mu, scale_tril=pick(Lu), validate_args=False)
         pU = _FusedPU(torch.zeros_like(self.mu), scale_tril=pick(chol), validate_args=False)
@@ -368,8 +368,8 @@ class GaussianPrior(nn.Module):
         self.scale_pf = 1.0
 
     def _pair(self, mean, raw_scale):
-        qF = distributions.Normal(mean, torch.nn.functional.softplus(raw_scale))
-        pF = distributions.Normal(torch.zeros_like(qF.mean), self.scale_pf * torch.ones_like(qF.scale))
+        qF = ops.checked_dist(distributions.Normal, mean, torch.nn.functional.softplus(raw_scale))
+        pF = ops.checked_dist(distributions.Normal, torch.zeros_like(qF.mean), self.scale_pf * torch.ones_like(qF.scale))
         return qF, pF
 
     def forward(self):
@@ -402,7 +402,7 @@ class WSVGP(_FusedGP):
         mean, scale = _PrecomputedMoments.apply(W, self.kernel.sigma, self.mu, self.Lu)
         Lu = self.Lu.tril(-1) + torch.diag_embed(torch.diagonal(self.Lu, dim1=-2, dim2=-1).exp())
         pick = (lambda t: t[0]) if self.mu.dim() == 1 else (lambda t: t)
-        return distributions.Normal(pick(mean), pick(scale)), _FusedQU(self.mu, scale_tril=Lu, validate_args=False), None
+        return ops.checked_dist(distributions.Normal, pick(mean), pick(scale)), _FusedQU(self.mu, scale_tril=Lu, validate_args=False), None
 
 
 class SVGP(_FusedGP):

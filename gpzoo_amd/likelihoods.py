@@ -14,6 +14,13 @@ import torch.nn as nn
 from torch import distributions
 
 
+def _dist(cls, *args, **kwargs):
+    """A torch distribution whose argument validation (one host sync per constrained argument) moves to the end of an
+    enclosing ``ops.deferred_info()`` block -- the training loops' steps; the plain constructor elsewhere."""
+    from .ops import checked_dist
+    return checked_dist(cls, *args, **kwargs)
+
+
 class GaussianLikelihood(nn.Module):
     """pY = Normal(F, softplus(noise)) with F ~ qF.rsample((E,)); reference likelihoods.py:7-20."""
 
@@ -25,7 +32,7 @@ class GaussianLikelihood(nn.Module):
     def forward(self, X, E=1, verbose=False, **kwargs):
         qF, qU, pU = self.gp(X, verbose=verbose, **kwargs)
         F = qF.rsample((E,))
-        pY = distributions.Normal(F, torch.nn.functional.softplus(self.noise))
+        pY = _dist(distributions.Normal, F, torch.nn.functional.softplus(self.noise))
         return pY, qF, qU, pU
 
 
@@ -40,7 +47,7 @@ class ExactLikelihood(nn.Module):
 
     def forward(self, X, E=1, verbose=False, **kwargs):
         qF, qU, pU = self.gp(X, verbose=verbose, **kwargs)
-        pY = distributions.Normal(qF.mean, torch.nn.functional.softplus(self.noise))
+        pY = _dist(distributions.Normal, qF.mean, torch.nn.functional.softplus(self.noise))
         return pY, qF, qU, pU
 
     def elbo(self, X, y, **kwargs):
@@ -112,7 +119,7 @@ class PNMF(PoissonFactorization):
     def forward(self, E=10, **kwargs):
         qF, pF = self.prior()
         Z = self.get_rate(qF.rsample((E,)))
-        pY = distributions.Poisson(torch.nn.functional.softplus(self.V) * Z)
+        pY = _dist(distributions.Poisson, torch.nn.functional.softplus(self.V) * Z)
         return pY, qF, pF
 
 
@@ -127,13 +134,13 @@ class NSF2(PoissonFactorization):
     def forward(self, X, E=10, verbose=False, **kwargs):
         qF, qU, pU = self.prior(X=X, verbose=verbose, **kwargs)
         Z = self.get_rate(qF.rsample((E,)))
-        pY = distributions.Poisson(torch.nn.functional.softplus(self.V) * Z)
+        pY = _dist(distributions.Poisson, torch.nn.functional.softplus(self.V) * Z)
         return pY, qF, qU, pU
 
     def forward_batched(self, X, idx, E=10, verbose=False, **kwargs):
         qF, qU, pU = self.prior(X=X[idx], verbose=verbose, **kwargs)
         Z = self.get_rate(qF.rsample((E,)))
-        pY = distributions.Poisson(torch.nn.functional.softplus(self.V[idx]) * Z)
+        pY = _dist(distributions.Poisson, torch.nn.functional.softplus(self.V[idx]) * Z)
         return pY, qF, qU, pU
 
     def expected_loglik(self, X, y, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
@@ -162,11 +169,11 @@ class NSF(nn.Module):
 
     def forward(self, X, E=10, verbose=False, **kwargs):
         qF, qU, pU = self.gp(X=X, verbose=verbose, **kwargs)
-        return distributions.Poisson(self._rate(qF, torch.nn.functional.softplus(self.V), E)), qF, qU, pU
+        return _dist(distributions.Poisson, self._rate(qF, torch.nn.functional.softplus(self.V), E)), qF, qU, pU
 
     def forward_batched(self, X, idx, E=10, verbose=False, **kwargs):
         qF, qU, pU = self.gp(X=X[idx], verbose=verbose, **kwargs)
-        return distributions.Poisson(self._rate(qF, torch.nn.functional.softplus(self.V)[idx], E)), qF, qU, pU
+        return _dist(distributions.Poisson, self._rate(qF, torch.nn.functional.softplus(self.V)[idx], E)), qF, qU, pU
 
     def expected_loglik(self, X, y, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
         Xb = X if idx is None else X[idx]
@@ -187,11 +194,11 @@ class MGGP_NSF(NSF):
 
     def forward(self, X, groupsX, E=10, verbose=False):
         qF, qU, pU = self._gp(X, groupsX, verbose)
-        return distributions.Poisson(self._rate(qF, torch.nn.functional.softplus(self.V), E)), qF, qU, pU
+        return _dist(distributions.Poisson, self._rate(qF, torch.nn.functional.softplus(self.V), E)), qF, qU, pU
 
     def forward_batched(self, X, groupsX, idx, E=10, verbose=False):
         qF, qU, pU = self._gp(X[idx], groupsX[idx], verbose)
-        return distributions.Poisson(self._rate(qF, torch.nn.functional.softplus(self.V)[idx], E)), qF, qU, pU
+        return _dist(distributions.Poisson, self._rate(qF, torch.nn.functional.softplus(self.V)[idx], E)), qF, qU, pU
 
     def expected_loglik(self, X, y, groupsX=None, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
         """Fused training-step form; the group ids follow the sampled spots (``groupsX[idx]``, as in
@@ -218,7 +225,7 @@ class Hybrid_NSF2(nn.Module):
 
     def _pY(self, qF1, qF2, V, E):
         Z = self.sf.get_rate(qF1.rsample((E,))) + self.cf.get_rate(qF2.rsample((E,)))
-        return distributions.Poisson(V * Z)
+        return _dist(distributions.Poisson, V * Z)
 
     def forward(self, X, E=10, verbose=False, **kwargs):
         qF1, qU, pU = self.sf.prior(X=X, verbose=verbose, **kwargs)
@@ -253,7 +260,7 @@ class Hybrid_NSF_Exact(Hybrid_NSF2):
 
     def _pY(self, qF1, qF2, V, E):
         Z = self.sf.get_rate(qF1.mean + 0.5 * qF1.scale ** 2) + self.cf.get_rate(qF2.mean + 0.5 * qF2.scale ** 2)
-        return distributions.Poisson(V * Z)
+        return _dist(distributions.Poisson, V * Z)
 
     def expected_loglik(self, X, y, idx=None, E=10, eps=None, with_lgamma=True, **kwargs):
         """The closed-form objective of THIS class as the reference's loops evaluate it -- not the sampled one of
@@ -287,11 +294,11 @@ class Hybrid_NSF(NSF):
 
     def _hybrid(self, qF, mF, raw_scale, V, E):
         scale2 = torch.nn.functional.softplus(raw_scale)
-        qF2 = distributions.Normal(mF, scale2)
+        qF2 = _dist(distributions.Normal, mF, scale2)
         F = torch.exp(torch.cat((qF.rsample((E,)), qF2.rsample((E,))), dim=1))
         Z = torch.matmul(torch.cat((self.W, self.W2), dim=1), F)
-        pF2 = distributions.Normal(torch.zeros_like(mF), torch.ones_like(scale2))
-        return distributions.Poisson(V * Z), qF2, pF2
+        pF2 = _dist(distributions.Normal, torch.zeros_like(mF), torch.ones_like(scale2))
+        return _dist(distributions.Poisson, V * Z), qF2, pF2
 
     def forward(self, X, E=10, verbose=False, **kwargs):
         qF, qU, pU = self.gp(X=X, verbose=verbose, **kwargs)
@@ -311,8 +318,8 @@ class Hybrid_NSF(NSF):
         V = torch.nn.functional.softplus(self.V)
         qF, qU, pU = self.gp(X=Xb, **kwargs)
         scale2 = torch.nn.functional.softplus(rs)
-        qF2 = distributions.Normal(mF, scale2)
-        pF2 = distributions.Normal(torch.zeros_like(mF), torch.ones_like(scale2))
+        qF2 = _dist(distributions.Normal, mF, scale2)
+        pF2 = _dist(distributions.Normal, torch.zeros_like(mF), torch.ones_like(scale2))
         ll = poisson_expected_loglik([qF, qF2], [self.W, self.W2], V if idx is None else V[idx], y, E=E,
                                      with_lgamma=with_lgamma, eps=eps)
         return ll, qF, qU, pU, qF2, pF2

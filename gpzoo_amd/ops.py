@@ -5,7 +5,9 @@ only; every numeric step of the hot path runs in libgpzoo_hip.so.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -226,6 +228,97 @@ def _raise_not_pd(info: torch.Tensor, what: str):
     raise torch.linalg.LinAlgError(
         f"{what}: {prefix}The factorization could not be completed because the input is not "
         f"positive-definite (the leading minor of order {k} is not positive-definite).")
+
+
+class _DeferredInfo:
+    """`info` words of the factorisations launched inside one ``deferred_info()`` block, still on the device."""
+
+    def __init__(self):
+        self.items = []          # (info tensor, what, cache committed on trust or None)
+        self.flags = []          # (0-d bool tensor "arguments valid", callable that raises torch's own error)
+        self.checked = False
+
+    def add(self, info: torch.Tensor, what: str, cache=None):
+        self.items.append((info, what, cache))
+        self.checked = False
+
+    def add_flag(self, ok: torch.Tensor, reraise):
+        self.flags.append((ok, reraise))
+        self.checked = False
+
+    def check(self):
+        """ONE device-to-host sync for everything registered so far; raises what the eager check would have raised
+        (torch.linalg.LinAlgError / IndexError / RuntimeError) for the first failing call, after invalidating every
+        factor cache that was committed on trust."""
+        items, flags = self.items, self.flags
+        self.items, self.flags, self.checked = [], [], True
+        if not items and not flags:
+            return
+        words = [i.reshape(-1) != 0 for i, _, _ in items] + [~f.reshape(1) for f, _ in flags]
+        if not bool(torch.cat(words).any()):
+            return
+        for _, _, cache in items:
+            if cache is not None:
+                cache.invalidate()
+        for info, what, _ in items:        # in call order: a failed factorisation comes before the NaN moments it produced
+            if bool(info.any()):
+                _raise_info(info, what)
+        for ok, reraise in flags:
+            if not bool(ok):
+                reraise()
+
+
+_deferred = threading.local()
+
+
+@contextlib.contextmanager
+def deferred_info():
+    """Inside the block, forward passes do not stop the launch queue to read their factorisation's ``info`` word: it
+    stays on the device and is read ONCE when the block ends (or at ``.check()`` on the yielded object), raising what
+    the call itself would have raised -- torch.linalg.LinAlgError for a Kzz that is not positive-definite (gp.py:213,
+    270, 360).  A training step wraps forward + ``loss.backward()`` in it and puts the optimiser step behind it: the
+    backward pass's launches are queued while the forward still runs (at the notebooks' sizes the eager check costs a
+    drained queue per step: 0.4 ms of a 4 ms step at BASELINE configs[1]), a failed factorisation still raises before
+    the parameters are touched.  What the block computed from a failed factor is garbage, as it would be unreachable
+    eagerly.  Nested blocks register with the innermost one."""
+    d = _DeferredInfo()
+    stack = _deferred.__dict__.setdefault("stack", [])
+    stack.append(d)
+    try:
+        yield d
+    except BaseException:
+        stack.pop()
+        raise
+    stack.pop()
+    d.check()
+
+
+def _deferring():
+    stack = _deferred.__dict__.get("stack")
+    return stack[-1] if stack else None
+
+
+def checked_dist(cls, *args, **kwargs):
+    """``cls(*args, **kwargs)`` -- a torch distribution -- with its argument validation (a device reduction and a HOST
+    SYNC per constrained argument: ``Normal(loc, scale)`` stops the launch queue twice) moved to the end of the enclosing
+    ``deferred_info()`` block: the constraint checks are queued as device flags, read with the block's one sync, and a
+    violation raises what the constructor itself raises (it is re-run with validation on).  Outside a block: the plain
+    constructor."""
+    d = _deferring()
+    if d is None or kwargs.get("validate_args") is False:
+        return cls(*args, **kwargs)
+    from torch import distributions as _D
+    if not _D.Distribution._validate_args:          # validation switched off globally: nothing to defer
+        return cls(*args, **kwargs)
+    dist = cls(*args, validate_args=False, **kwargs)
+    oks = []
+    for name, constraint in dist.arg_constraints.items():
+        if getattr(constraint, "is_dependent", False) or name not in dist.__dict__:
+            continue
+        oks.append(constraint.check(getattr(dist, name)).all())
+    if oks:
+        d.add_flag(torch.stack(oks).all(), lambda: cls(*args, validate_args=True, **kwargs))
+    return dist
 
 
 def freeze_spec(spec: KernelSpec) -> KernelSpec:
@@ -456,10 +549,18 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
     rc = lib.gpz_svgp_forward(C.byref(p), int(chunk), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_svgp_forward")
     out["path"] = lib.gpz_svgp_forward_path(C.byref(p), int(chunk))    # bit 0: wide tiles, bit 1: generated Kzx, 4: panel kernel
+    later = _deferring() if check_info else None
+    if later is not None:
+        # inside deferred_info(): no sync here; the cache is committed on trust and invalidated by the block's check
+        # should the factorisation have failed
+        later.add(info, "linalg.cholesky", cache)
+        check_info = False
     bad = check_info and bool(info.any())       # one device-to-host sync, shared by the cache decision and the raise
     if cache is not None:
         # a factor that failed must not be reused; without the host check the cache stays uncommitted
-        if not check_info or bad:
+        if later is not None:
+            cache.commit()
+        elif not check_info or bad:
             cache.invalidate()
         else:
             cache.commit()
@@ -622,7 +723,10 @@ def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, cla
     ws = _workspace(dev, nbytes)
     rc = lib.gpz_vnngp_forward(C.byref(p), K, _ptr(out["idx"]), _ptr(ws), ws.numel(), _stream(dev))
     _lib.check(rc, "gpz_vnngp_forward")
-    if check_info and bool(info.any()):
+    later = _deferring() if check_info else None
+    if later is not None:
+        later.add(info, "linalg.cholesky")
+    elif check_info and bool(info.any()):
         _raise_info(info, "linalg.cholesky")
     return out
 

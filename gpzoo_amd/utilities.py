@@ -107,15 +107,17 @@ def train(model, optimizer, X, y, device=None, steps=200, E=20, fused=True, sync
     Returns the list of losses: floats, one host sync per step as in the reference (``losses.append(loss.item())``,
     utilities.py:487), or with ``sync_losses=False`` 0-d device tensors converted once at the end -- the same numbers
     without stalling the launch queue every step, which is most of a step at the notebooks' small sizes."""
+    from .ops import deferred_info
     losses = []
     for _ in range(steps):
         optimizer.zero_grad()
-        if fused and hasattr(model, "expected_loglik"):
-            ll, _, qU, pU = model.expected_loglik(X, y, E=E, **kwargs)     # (the hybrids' 6-tuples fail here as in the reference)
-            loss = -(ll - _kl_u(qU, pU))
-        else:
-            loss = _elbo_terms(model, X, y, E, **kwargs)
-        loss.backward()
+        with deferred_info():      # Kzz's `info` is read once, behind the backward pass's launches; a failure raises here
+            if fused and hasattr(model, "expected_loglik"):
+                ll, _, qU, pU = model.expected_loglik(X, y, E=E, **kwargs)     # (the hybrids' 6-tuples fail here as in the reference)
+                loss = -(ll - _kl_u(qU, pU))
+            else:
+                loss = _elbo_terms(model, X, y, E, **kwargs)
+            loss.backward()
         optimizer.step()
         losses.append(loss.item() if sync_losses else loss.detach())
     if not sync_losses and losses:
@@ -130,23 +132,25 @@ def train_batched(model, optimizer, X, y, device=None, steps=200, E=20, batch_si
     expected log-likelihood through ``model.expected_loglik`` (gpz_poisson_nsf: the (E,D,N_b) rate is never
     materialised).  The index draw stays on the device (the reference samples on the host every step).
     Models without ``forward_batched`` (plain GP likelihoods) get ``model(X[idx])`` on the sampled spots."""
+    from .ops import deferred_info
     losses = []
     for _ in range(steps):
         idx = _spots(X, min(batch_size, X.shape[0]))
         optimizer.zero_grad()
-        if not hasattr(model, "forward_batched"):
-            kw = dict(kwargs)
-            if "groupsX" in kw:
-                kw["groupsX"] = kw["groupsX"][idx]
-            loss = _elbo_terms(model, X[idx], y[..., idx], E, **kw)
-        else:
-            if fused and hasattr(model, "expected_loglik"):
-                ll, _, qU, pU = model.expected_loglik(X, y[:, idx], idx=idx, E=E, **kwargs)
+        with deferred_info():
+            if not hasattr(model, "forward_batched"):
+                kw = dict(kwargs)
+                if "groupsX" in kw:
+                    kw["groupsX"] = kw["groupsX"][idx]
+                loss = _elbo_terms(model, X[idx], y[..., idx], E, **kw)
             else:
-                pY, _, qU, pU = model.forward_batched(X=X, idx=idx, E=E, **kwargs)
-                ll = pY.log_prob(y[:, idx]).mean(dim=0).sum()
-            loss = -(ll - _kl_u(qU, pU))
-        loss.backward()
+                if fused and hasattr(model, "expected_loglik"):
+                    ll, _, qU, pU = model.expected_loglik(X, y[:, idx], idx=idx, E=E, **kwargs)
+                else:
+                    pY, _, qU, pU = model.forward_batched(X=X, idx=idx, E=E, **kwargs)
+                    ll = pY.log_prob(y[:, idx]).mean(dim=0).sum()
+                loss = -(ll - _kl_u(qU, pU))
+            loss.backward()
         optimizer.step()
         _clamp_loadings(model, ("W",))
         losses.append(loss.item())
@@ -156,16 +160,18 @@ def train_batched(model, optimizer, X, y, device=None, steps=200, E=20, batch_si
 def train_hybrid(model, optimizer, X, y, device=None, steps=200, E=20, fused=True, **kwargs):
     """Full-batch driver of the hybrid (spatial + non-spatial) models, reference utilities.py:530-558."""
     from torch import distributions
+    from .ops import deferred_info
     losses = []
     for _ in range(steps):
         optimizer.zero_grad()
-        if fused and hasattr(model, "expected_loglik"):
-            ll, _, qU, pU, qF, pF = model.expected_loglik(X, y, E=E, **kwargs)
-        else:
-            pY, _, qU, pU, qF, pF = model(X=X, E=E, **kwargs)
-            ll = pY.log_prob(y).mean(dim=0).sum()
-        loss = -(ll - _kl_u(qU, pU) - torch.sum(distributions.kl_divergence(qF, pF)))
-        loss.backward()
+        with deferred_info():
+            if fused and hasattr(model, "expected_loglik"):
+                ll, _, qU, pU, qF, pF = model.expected_loglik(X, y, E=E, **kwargs)
+            else:
+                pY, _, qU, pU, qF, pF = model(X=X, E=E, **kwargs)
+                ll = pY.log_prob(y).mean(dim=0).sum()
+            loss = -(ll - _kl_u(qU, pU) - torch.sum(distributions.kl_divergence(qF, pF)))
+            loss.backward()
         optimizer.step()
         _clamp_loadings(model)
         losses.append(loss.item())
@@ -176,17 +182,19 @@ def train_hybrid_batched(model, optimizer, X, y, device=None, steps=200, E=20, b
     """Mini-batch driver of the hybrid models, reference utilities.py:497-527: the log-likelihood is
     ``y log(rate) - rate`` (no log y! term), both KL terms are subtracted, W / W2 are clamped at zero."""
     from torch import distributions
+    from .ops import deferred_info
     losses = []
     for _ in range(steps):
         idx = _spots(X, batch_size)
         optimizer.zero_grad()
-        if fused and hasattr(model, "expected_loglik"):
-            ll, _, qU, pU, qF, pF = model.expected_loglik(X, y[:, idx], idx=idx, E=E, with_lgamma=False, **kwargs)
-        else:
-            pY, _, qU, pU, qF, pF = model.forward_batched(X=X, idx=idx, E=E, **kwargs)
-            ll = (y[:, idx] * torch.log(pY.rate) - pY.rate).mean(dim=0).sum()
-        loss = -(ll - _kl_u(qU, pU) - torch.sum(distributions.kl_divergence(qF, pF)))
-        loss.backward()
+        with deferred_info():
+            if fused and hasattr(model, "expected_loglik"):
+                ll, _, qU, pU, qF, pF = model.expected_loglik(X, y[:, idx], idx=idx, E=E, with_lgamma=False, **kwargs)
+            else:
+                pY, _, qU, pU, qF, pF = model.forward_batched(X=X, idx=idx, E=E, **kwargs)
+                ll = (y[:, idx] * torch.log(pY.rate) - pY.rate).mean(dim=0).sum()
+            loss = -(ll - _kl_u(qU, pU) - torch.sum(distributions.kl_divergence(qF, pF)))
+            loss.backward()
         optimizer.step()
         _clamp_loadings(model)
         losses.append(loss.item())
@@ -198,11 +206,14 @@ def train_closure_batched(model, optimizer, X, groupsX, y, device=None, steps=20
     reference utilities.py:561-597."""
     losses = []
 
+    from .ops import deferred_info
+
     def closure(idx):
         optimizer.zero_grad()
-        pY, _, qU, pU = model.forward_batched(X, groupsX, idx, E=E)
-        loss = -(pY.log_prob(y[:, idx]).mean(dim=0).sum() - _kl_u(qU, pU))
-        loss.backward()
+        with deferred_info():
+            pY, _, qU, pU = model.forward_batched(X, groupsX, idx, E=E)
+            loss = -(pY.log_prob(y[:, idx]).mean(dim=0).sum() - _kl_u(qU, pU))
+            loss.backward()
         losses.append(loss.item())
         return loss
 

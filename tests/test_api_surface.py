@@ -229,3 +229,32 @@ def test_reduce_scatter_through_a_c_abi_communicator_alone():
     assert c.calls == [("rs32", torch.float32), ("ar64", torch.float64)]
     with pytest.raises(ValueError, match="float32 or float64"):
         parallel._dist_reduce_scatter(t32.half(), None, c)
+
+
+def test_deferred_argument_validation_raises_torchs_own_error_at_the_end_of_the_block():
+    """ops.checked_dist inside ops.deferred_info(): the distribution is built without its host-synchronising argument
+    checks, the checks are queued, and the end of the block raises what the constructor raises; outside a block it is
+    the plain constructor."""
+    from torch import distributions
+    from gpzoo_amd import ops
+    good = ops.checked_dist(distributions.Normal, torch.zeros(3), torch.ones(3))
+    assert isinstance(good, distributions.Normal) and good._validate_args
+    with pytest.raises(ValueError, match="scale"):
+        ops.checked_dist(distributions.Normal, torch.zeros(3), torch.tensor([1.0, -1.0, 2.0]))
+    with ops.deferred_info() as pend:
+        d = ops.checked_dist(distributions.Normal, torch.zeros(3), torch.ones(3))
+        assert not d._validate_args and len(pend.flags) == 1
+    assert pend.checked
+    reached = []
+    with pytest.raises(ValueError, match="scale"):
+        with ops.deferred_info():
+            ops.checked_dist(distributions.Normal, torch.zeros(3), torch.tensor([1.0, float("nan"), 2.0]))
+            reached.append(1)
+    assert reached == [1]
+    with pytest.raises(ValueError, match="rate"):
+        with ops.deferred_info():
+            ops.checked_dist(distributions.Poisson, torch.tensor([1.0, -2.0]))
+    with pytest.raises(KeyError):                        # an exception of the block's own passes through unchecked
+        with ops.deferred_info():
+            ops.checked_dist(distributions.Normal, torch.zeros(2), -torch.ones(2))
+            raise KeyError("user error")

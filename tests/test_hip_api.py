@@ -137,6 +137,55 @@ def test_not_positive_definite_forward_raises():
         gp(torch.randn(20, 2, dtype=torch.float64).cuda())
 
 
+def test_deferred_info_check_raises_at_the_end_of_the_block_and_changes_no_number():
+    """ops.deferred_info(): inside the block a forward pass does not stop to read its factorisation's info word; the
+    block's end reads all of them once and raises what the call would have raised (LinAlgError, gp.py:270) -- before an
+    optimiser step placed behind the block -- and a factor cache committed on trust is invalidated.  A healthy step
+    gives bitwise the gradients of the eager step; the training loops of gpzoo.utilities run their steps this way."""
+    from gpzoo.gp import WSVGP
+    from gpzoo.kernels import NSF_RBF
+    from gpzoo_amd import ops
+    g = torch.Generator().manual_seed(3)
+    X = (torch.rand(500, 2, generator=g, dtype=torch.float64) * 10).cuda()
+
+    def make(jitter):
+        gp = WSVGP(NSF_RBF(L=2, lengthscale=1.5), dim=2, M=40, jitter=jitter).double()
+        gp.Z = nn.Parameter(X[:40].cpu().clone(), requires_grad=False)
+        gp.mu = nn.Parameter(0.1 * torch.randn(2, 40, generator=g, dtype=torch.float64))
+        gp.Lu = nn.Parameter(0.05 * torch.randn(2, 40, 40, generator=g, dtype=torch.float64))
+        for t in gp.kernel.parameters():
+            t.requires_grad_(False)
+        return gp.cuda()
+
+    gp = make(1e-2)
+    grads = []
+    for deferred in (False, True):
+        gp.zero_grad()
+        if deferred:
+            with ops.deferred_info() as pend:
+                qF, _, _ = gp(X)
+                assert len(pend.items) == 1               # registered, not yet read
+                (qF.mean.sum() + (qF.scale ** 2).sum()).backward()
+            assert pend.checked and not pend.items
+        else:
+            qF, _, _ = gp(X)
+            (qF.mean.sum() + (qF.scale ** 2).sum()).backward()
+        grads.append((gp.mu.grad.clone(), gp.Lu.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    bad = make(-0.9)                                       # indefinite Kzz
+    reached = []
+    with pytest.raises(torch.linalg.LinAlgError, match="not positive-definite"):
+        with ops.deferred_info():
+            bad(X)
+            reached.append("after the forward")           # the call itself no longer raises ...
+        reached.append("behind the block")                # ... the end of the block does
+    assert reached == ["after the forward"]
+    cache = bad.__dict__.get("_factor_cache")
+    assert cache is not None and cache.key is None         # committed on trust inside the block, invalidated by its check
+    with pytest.raises(torch.linalg.LinAlgError):          # and eagerly, outside a block, as before
+        bad(X)
+
+
 @pytest.mark.parametrize("name", ["wsvgp_nsf_rbf_f64", "wsvgp_matern32_f32", "wsvgp_rbf_f64"])
 def test_forward_precomputed(name):
     """WSVGP.forward_precomputed (gp.py:308-322): W = (L^-1 Kzx)^T supplied by the caller."""
