@@ -97,11 +97,12 @@ def parse():
     return ap.parse_args()
 
 
-# N-sized products of L*M^2*N flops (triangular operand counted once) in one training step since round 5:
-# forward Wt = Linv*Kzx and colsum((LuE^T Wt)^2); backward, mu / Lu only: H += Wt diag(gv2) Wt^T (lower tiles) -- ONE
-# product (rounds 1-4: P-bar and W P-bar^T, two); all parameters add P-bar, W-bar = LuE*P-bar - ..., K-bar_x = Linv^T W-bar
-# (the M x M gradient of the factor is algebra on H: DESIGN.md section 5 "Backward").
-TRAIN_PRODUCTS = {"mu_Lu": 3, "all_parameters": 6}
+# N-sized work of one training step since round 5, in units of L*M^2*N flops (a triangular operand counted once):
+# forward Wt = Linv*Kzx and colsum((LuE^T Wt)^2): 2; backward, mu / Lu only: H += Wt diag(gv2) Wt^T (lower tiles): 1
+# (rounds 1-4: P-bar and W P-bar^T, 2); all parameters add K-bar_x = [A1 Wt] diag(gv2) + a3 gm^T with the DENSE M x M
+# matrix A1 = Linv^T (Sw - I): 2 (rounds 1-4: P-bar, W-bar, K-bar_x and a second accumulation, 5).  The M x M gradient of
+# the factor is fp64 algebra on H (DESIGN.md section 5 "Backward").
+TRAIN_PRODUCTS = {"mu_Lu": 3, "all_parameters": 5}
 
 
 def train_leg(ops, spec, g, c, extra, chunk, reps=2) -> dict:

@@ -27,15 +27,18 @@ enum WideEpilogue {
   WIDE_STORE = 2,           // upper A: C = A B                                                                  (backward Kbar_x)
   WIDE_STORE_COLSCALE = 3,  // upper A: C[i][j] = colscale[j] (A B)[i][j]                                        (backward Pbar)
   WIDE_WBAR = 4,            // lower A: C[i][j] = (A B)[i][j] + rowvec[i] colvec[j] - aux[i][j] colscale[j]      (backward Wbar)
+  WIDE_KBAR = 5,            // DENSE A (upper = 2): C[i][j] = colscale[j] (A B)[i][j] + rowvec[i] colvec[j]      (backward Kbar_x in one product)
+  WIDE_ADD_COLSCALE = 6,    // upper A: C[i][j] += colscale[j] (A B)[i][j]; `gate` (a device word): skipped when it is zero
 };
 struct WideArgs {
   const float* A; const float* B; int64_t Mp, ncp; int L;
-  int upper, epilogue;
+  int upper, epilogue;                        // upper: 0 = lower-triangular A, 1 = upper-triangular, 2 = dense
   float* C; const float* mu;                  // mu: WIDE_STORE_STATS
   float* ps_sq; float* ps_mu;                 // [L][Mp/128][ncp]; ps_mu: WIDE_STORE_STATS
   const float* colscale; const float* colvec; // (L, ncp)
   const float* rowvec;                        // (L, Mp)
   const float* aux;                           // (L, Mp, ncp)
+  const int32_t* gate;                        // WIDE_ADD_COLSCALE: device word, the launch does nothing when it is zero (or null)
 };
 bool wide_product_supported(int64_t Mp, int64_t ncp);
 int wide_product_launch(const WideArgs& a, hipStream_t s);

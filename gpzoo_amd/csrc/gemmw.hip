@@ -57,12 +57,14 @@ namespace gpz {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { WB_MEM = 0, WB_GEN = 1 };
-enum { WA_LOWER = 1, WA_UPPER = 2 };
+enum { WA_DENSE = 0, WA_LOWER = 1, WA_UPPER = 2 };
 enum { WE_STORE_STATS = 0,      // C = A B, plus colsum(C^2) and mu^T C per 128-row block        (forward stage 1)
        WE_STATS = 1,            // colsum((A B)^2) per 128-row block only                         (forward stage 2)
        WE_STORE = 2,            // C = A B                                                        (backward: Kbar_x = Linv^T Wbar)
        WE_STORE_COLSCALE = 3,   // C[i][j] = colscale[j] (A B)[i][j]                              (backward: Pbar)
-       WE_WBAR = 4 };           // C[i][j] = (A B)[i][j] + rowvec[i] colvec[j] - aux[i][j] colscale[j]   (backward: Wbar)
+       WE_WBAR = 4,             // C[i][j] = (A B)[i][j] + rowvec[i] colvec[j] - aux[i][j] colscale[j]   (backward: Wbar)
+       WE_KBAR = 5,             // C[i][j] = colscale[j] (A B)[i][j] + rowvec[i] colvec[j]               (backward: Kbar_x, dense A)
+       WE_ADD_COLSCALE = 6 };   // C[i][j] += colscale[j] (A B)[i][j]                                    (its clamp correction)
 
 struct WParams {
   const float* A; int64_t lda, sA0;         // (L, Mp, Mp)
@@ -79,6 +81,7 @@ struct WParams {
   int64_t M;                                // real rows (the rest is padding)
   int L, nblk, mtw, nt, W, strips;          // latents, 128-blocks, row tiles, column tiles, strip width, strips
   int pair, colmajor;                       // WB_MEM: two row tiles per workgroup; dispatch order column tile by column tile
+  const int32_t* gate;                      // device word: the launch does nothing when it is zero (null: always runs)
 };
 
 constexpr int W_BK = 16;
@@ -98,6 +101,7 @@ struct WLds {
 template <int TM, int TN, int BSRC, int ATRI, int EPI, int KIND, int D>
 __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemmw_kernel(const WParams p) {
   constexpr int BK = W_BK;
+  if (p.gate && *p.gate == 0) return;
   constexpr int WMW = TM / 128, WNW = TN / 32;          // waves along rows / columns
   constexpr int NW = WMW * WNW;                         // waves: 8 (128 x 256, from memory) or 16 (512 x 128, generated)
   static_assert(NW == 8 || NW == 16, "8 or 16 waves of 128 x 32");
@@ -382,6 +386,8 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
     __builtin_amdgcn_s_barrier();
     if (!active) {
       idle_until(nk);
+    } else if constexpr (ATRI == WA_DENSE) {
+      full_until(nk);
     } else if constexpr (ATRI == WA_LOWER) {
       full_until(n_a);
       diagonal(diagonal, i0{});
@@ -462,10 +468,10 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
         for (int ni = 0; ni < 2; ++ni) cs[ni] = p.colscale[b0 * p.sCs + ccol0 + ni * 16 + r];
       }
       f32x4 sc = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
-      if constexpr (EPI == WE_WBAR) {
+      if constexpr (EPI == WE_WBAR || EPI == WE_KBAR || EPI == WE_ADD_COLSCALE)
         sc = *reinterpret_cast<const f32x4*>(p.colscale + b0 * p.sCs + ccol0 + c4);
+      if constexpr (EPI == WE_WBAR || EPI == WE_KBAR)
         cv = *reinterpret_cast<const f32x4*>(p.colvec + b0 * p.sCs + ccol0 + c4);
-      }
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
@@ -475,12 +481,13 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
         __builtin_amdgcn_wave_barrier();
         f32x4 w[2];
         float rv[2];
-        if constexpr (EPI == WE_WBAR) {       // every operand of the pass is loaded before its first store (stores may alias)
+        if constexpr (EPI == WE_WBAR || EPI == WE_KBAR || EPI == WE_ADD_COLSCALE) {   // every operand of the pass is loaded before its first store (stores may alias)
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
             const int64_t row = mi * 16 + it * 8 + srow;
-            w[it] = *reinterpret_cast<const f32x4*>(p.aux + b0 * p.sC0 + (row0 + row) * p.ldc + ccol0 + c4);
-            rv[it] = p.rowvec[b0 * p.sRv + row0 + row];
+            if constexpr (EPI == WE_WBAR) w[it] = *reinterpret_cast<const f32x4*>(p.aux + b0 * p.sC0 + (row0 + row) * p.ldc + ccol0 + c4);
+            if constexpr (EPI == WE_ADD_COLSCALE) w[it] = *reinterpret_cast<const f32x4*>(Cg + (int64_t)row * p.ldc + c4);
+            if constexpr (EPI != WE_ADD_COLSCALE) rv[it] = p.rowvec[b0 * p.sRv + row0 + row];
           }
         }
 #pragma unroll
@@ -490,6 +497,14 @@ __global__ __launch_bounds__(64 * (TM / 128) * (TN / 32)) __attribute__((amdgpu_
           if constexpr (EPI == WE_WBAR) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] + rv[it] * cv[e] - w[it][e] * sc[e];
+          }
+          if constexpr (EPI == WE_KBAR) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + rv[it] * cv[e];
+          }
+          if constexpr (EPI == WE_ADD_COLSCALE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = w[it][e] + v[e] * sc[e];
           }
           *reinterpret_cast<f32x4*>(Cg + (int64_t)(mi * 16 + row) * p.ldc + c4) = v;
         }
@@ -880,6 +895,7 @@ static int wide_product_launch_t(const WideArgs& a, hipStream_t s) {
   p.mu = a.mu; p.sMu = a.Mp;
   p.ps_sq = a.ps_sq; p.ps_mu = a.ps_mu; p.ncols = a.ncp; p.M = a.Mp;
   p.colscale = a.colscale; p.colvec = a.colvec; p.sCs = a.ncp; p.rowvec = a.rowvec; p.sRv = a.Mp; p.aux = a.aux;
+  p.gate = a.gate;
   p.L = a.L; p.nblk = (int)(a.Mp / 128); p.mtw = (int)((a.Mp + TM - 1) / TM); p.nt = (int)((a.ncp + TN - 1) / TN);
   // strips of (nearly) equal width, at most 4096 columns: an XCD takes every 8th (latent, strip) unit.  Measured at
   // config 3 with 128-column tiles (evaluation ms, stage 1 / stage 2 TF): 8 tiles 391.0, 141.1 / 145.7 (L2 -> fabric
@@ -925,6 +941,12 @@ static int wide_product_launch_t(const WideArgs& a, hipStream_t s) {
     case WIDE_WBAR:
       GPZ_REQUIRE(!a.upper && a.C && a.colscale && a.colvec && a.rowvec && a.aux, "wide product: the W-bar epilogue needs its operands");
       GPZ_WM(WA_LOWER, WE_WBAR);
+    case WIDE_KBAR:
+      GPZ_REQUIRE(a.upper == 2 && a.C && a.colscale && a.colvec && a.rowvec, "wide product: the K-bar epilogue is the dense product and needs its vectors");
+      GPZ_WM(WA_DENSE, WE_KBAR);
+    case WIDE_ADD_COLSCALE:
+      GPZ_REQUIRE(a.upper == 1 && a.C && a.colscale, "wide product: the accumulating column-scaled store is the upper-triangular product");
+      GPZ_WM(WA_UPPER, WE_ADD_COLSCALE);
     default: break;
   }
 #undef GPZ_WM

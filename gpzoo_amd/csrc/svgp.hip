@@ -813,7 +813,8 @@ static int precomputed_t(const void* W, const void* sigma, const void* mu, const
 //   Q = sum Wbar W^T = LuE (Pbar W^T) - W diag(gv2 c) W^T + muE (W gm)^T = (Sw - I) H + Hd + muE v^T,
 // Sw = LuE LuE^T, Hd = W diag(gv2 (1 - c)) W^T (c = 0 on the columns whose whitened prior term sits at its clamp, gp.py:287;
 // zero everywhere else, so Hd is accumulated only in chunks that hold such a column), v = W gm -- M x M algebra in
-// fp64 on the same H instead of a third N-sized accumulation: 6 units instead of 7 for the all-parameter step.
+// fp64 on the same H instead of a third N-sized accumulation; and Kbar_x itself is ONE dense product per chunk,
+// [A1 W] diag(gv2) + a3 gm^T with A1 = Linv^T (Sw - I) (see the pass below): 5 units instead of 7 for the all-parameter step.
 template <typename T>
 __global__ void colscale_kernel(const T* __restrict__ g_scale, const T* __restrict__ scale, int64_t N, int64_t n0,
                                 int64_t ncp, int whitened, double clamp_min, T* __restrict__ out,
@@ -1098,6 +1099,27 @@ __global__ __launch_bounds__(256) void mu_grad_linv_kernel(const double* __restr
   }
 }
 
+// out[l][a] = sum_{i >= a} Linv[l][i][a] * v[l][i]  (Linv^T v) for a < M, zero in the padding; out (L, Mp)
+template <typename T>
+__global__ __launch_bounds__(256) void linvT_vec_kernel(const double* __restrict__ v, const double* __restrict__ Linv,
+                                                       int64_t Mp, int64_t M, T* __restrict__ out) {
+  __shared__ double sh[8][33];
+  const int l = blockIdx.y, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t a = (int64_t)blockIdx.x * 32 + tx;
+  const double* Lb = Linv + (int64_t)l * Mp * Mp;
+  double t = 0.0;
+  if (a < M)
+    for (int64_t i = a + ty; i < M; i += 8) t = fma(Lb[i * Mp + a], v[(int64_t)l * Mp + i], t);
+  sh[ty][tx] = t;
+  __syncthreads();
+  if (ty == 0 && a < Mp) {
+    double r = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r += sh[q][tx];
+    out[(int64_t)l * Mp + a] = (T)r;
+  }
+}
+
 // zero the strict upper triangle of (L,Mp,Mp)
 template <typename T>
 __global__ void tril_kernel(T* __restrict__ G, int64_t Mp) {
@@ -1150,7 +1172,7 @@ struct BwdBuffers {
   float* nt_vpart;                           // fp32: per-piece W gm from the same launch
   T* gmc;                                    // (L, nc) dLoss/dmean of the chunk, zero padded
   // kernel / Z gradients only
-  T *LuN, *Hd, *csc, *csd, *PS; double *D1, *D2, *D3, *D4, *D5, *me, *kacc, *sig_direct;
+  T *LuN, *Hd, *csc, *csd, *PS, *A1, *a3; double *D1, *D2, *D3, *D4, *D5, *me, *kacc, *sig_direct;
   int32_t* any_d;                            // per chunk: does it hold a column at the whitened clamp (weights of Hd)?
   size_t bytes;
 };
@@ -1176,13 +1198,15 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* w
   const bool ntw = sizeof(T) == 4 && wide_nt_supported(pl.Mp, pl.nc);
   b.nt_vpart = ntw ? c.take<float>((int64_t)wide_nt_vpart_floats(pl.Mp, pl.nc, (int)pl.L)) : nullptr;
   b.gmc = c.take<T>(pl.L * pl.nc);
-  b.LuN = b.Hd = b.csc = b.csd = b.PS = nullptr;
+  b.LuN = b.Hd = b.csc = b.csd = b.PS = b.A1 = b.a3 = nullptr;
   b.D1 = b.D2 = b.D3 = b.D4 = b.D5 = b.me = b.kacc = b.sig_direct = nullptr;
   b.any_d = nullptr;
   if (full) {
     b.LuN = c.take<T>(mm);
     b.Hd = whitened ? c.take<T>(mm) : nullptr;
     b.PS = c.take<T>(mm);
+    b.A1 = c.take<T>(mm);
+    b.a3 = c.take<T>(pl.L * pl.Mp);
     b.csc = c.take<T>(pl.L * pl.nc);
     b.csd = whitened ? c.take<T>(pl.L * pl.nc) : nullptr;
     b.D1 = c.take<double>(mm);
@@ -1241,6 +1265,41 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     GPZ_LAUNCH_OK();
     hipLaunchKernelGGL((transpose_cast_kernel<T>), g32, dim3(256), 0, s, b.Linv, Mp, w.LinvT, (double*)w.D1);
     GPZ_LAUNCH_OK();
+    // What Kbar_x = Linv^T Wbar needs once per pass.  Wbar = LuE Pbar - W diag(gv2 c) + muE gm^T with Pbar = LuE^T W diag(gv2)
+    // is (Sw - I) W D + W (D - Dc) + muE gm^T (Sw = LuE LuE^T, D = diag(gv2), Dc = diag(gv2 c)), so
+    //   Kbar_x = [A1 W] D + [Linv^T W] (D - Dc) + a3 gm^T,   A1 = Linv^T (Sw - I) (dense M x M),  a3 = Linv^T muE:
+    // ONE dense product per chunk (2 L M^2 N flop) where rounds 1-4 ran three triangular ones (Pbar, Wbar, Kbar_x: 3 L M^2 N);
+    // D - Dc is zero except on columns at the whitened clamp, whose term runs only in chunks that hold one.
+    const double* LuE64 = b.LuW;
+    if (wh) {
+      hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.LuN, w.D4, L * mm, 0);
+      GPZ_LAUNCH_OK();
+      LuE64 = w.D4;
+      hipLaunchKernelGGL((mu_widen_kernel<T>), dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s,
+                         static_cast<const T*>(p->mu), M, Mp, w.me);
+    } else {
+      hipLaunchKernelGGL((linv_mu_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Linv,
+                         static_cast<const T*>(p->mu), Mp, M, w.me);
+    }
+    GPZ_LAUNCH_OK();
+    {
+      GemmParams<double> d;
+      auto dg = [&](const double* A, const double* B, double* C, int flags) -> int {
+        d.A = A; d.lda = Mp; d.sA0 = mm; d.B = B; d.ldb = Mp; d.sB0 = mm; d.C = C; d.ldc = Mp; d.sC0 = mm;
+        d.nb0 = L32; d.mt = d.nt = (int)pl.nblk; d.K = (int)Mp; d.flags = flags;
+        return gemm_launch(d, EPI_STORE, s);
+      };
+      if (int rc = dg(LuE64, LuE64, w.D2, GF_A_LOWER | GF_B_UPPER | GF_B_TRANS)) return rc;            // D2 = Sw
+      hipLaunchKernelGGL(minus_identity_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.D2, Mp);   // D2 = Sw - I (kept for Q below)
+      GPZ_LAUNCH_OK();
+      hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Linv, Mp, w.D1);                 // D1 = Linv^T
+      GPZ_LAUNCH_OK();
+      if (int rc = dg(w.D1, w.D2, w.D3, GF_A_UPPER)) return rc;                                          // D3 = A1
+      hipLaunchKernelGGL((cast_kernel<T>), dim3(2048), dim3(256), 0, s, w.D3, w.A1, L * mm);
+      GPZ_LAUNCH_OK();
+      hipLaunchKernelGGL((linvT_vec_kernel<T>), dim3((unsigned)(Mp / 32), L32), dim3(256), 0, s, w.me, b.Linv, Mp, M, w.a3);
+      GPZ_LAUNCH_OK();
+    }
   }
   const int64_t esz = sizeof(T);
   const bool have_wt = p->wt_cache != nullptr && p->wt_cache_valid != 0;
@@ -1319,45 +1378,31 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       GPZ_LAUNCH_OK();
     }
     if (full) {
-      {                  // Pbar = (LuE^T W) diag(gv2)
-        bool done = false;
-        if constexpr (sizeof(T) == 4) {
-          if (wide) {
-            WideArgs wa = {};
-            wa.A = b.LuT; wa.B = Wc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 1; wa.epilogue = WIDE_STORE_COLSCALE;
-            wa.C = w.Pc; wa.colscale = w.cs;
-            if (int rc = wide_product_launch(wa, s)) return rc;
-            done = true;
-          }
-        }
-        if (!done) {
-          GemmParams<T> g2;
-          g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
-          g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
-          g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
-          g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-          g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
-          if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
-        }
-      }
-      // Wbar = Lu Pbar - W diag(gv2 c) + mu gm^T            (into the Kzx buffer, no longer needed)
       bool done = false;
       if constexpr (sizeof(T) == 4) {
-        if (wide) {
-          WideArgs wa = {};
-          wa.A = w.LuN; wa.B = w.Pc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 0; wa.epilogue = WIDE_WBAR;
-          wa.C = b.Kc; wa.colscale = w.csc; wa.colvec = w.gmc; wa.rowvec = b.muE; wa.aux = Wc;
-          if (int rc = wide_product_launch(wa, s)) return rc;
-          // Kbar_x = Linv^T Wbar                                 (into the Pbar buffer)
-          WideArgs wb = {};
-          wb.A = w.LinvT; wb.B = b.Kc; wb.Mp = Mp; wb.ncp = ncp; wb.L = L32; wb.upper = 1; wb.epilogue = WIDE_STORE;
-          wb.C = w.Pc;
-          if (int rc = wide_product_launch(wb, s)) return rc;
+        if (wide) {      // Kbar_x = [A1 W] diag(gv2) + a3 gm^T in one dense product       (into the Pbar buffer)
+          WideArgs wk = {};
+          wk.A = w.A1; wk.B = Wc; wk.Mp = Mp; wk.ncp = ncp; wk.L = L32; wk.upper = 2; wk.epilogue = WIDE_KBAR;
+          wk.C = w.Pc; wk.colscale = w.cs; wk.colvec = w.gmc; wk.rowvec = w.a3;
+          if (int rc = wide_product_launch(wk, s)) return rc;
+          if (with_hd) { // ... += [Linv^T W] diag(gv2 (1 - c)): only in a chunk with a column at the whitened clamp
+            WideArgs wc = {};
+            wc.A = w.LinvT; wc.B = Wc; wc.Mp = Mp; wc.ncp = ncp; wc.L = L32; wc.upper = 1; wc.epilogue = WIDE_ADD_COLSCALE;
+            wc.C = w.Pc; wc.colscale = w.csd; wc.gate = w.any_d + ci;
+            if (int rc = wide_product_launch(wc, s)) return rc;
+          }
           done = true;
         }
       }
-      if (!done) {
-        GemmParams<T> g4;
+      if (!done) {       // the 128 x 128-tile kernels: Pbar, Wbar, Kbar_x as three triangular products
+        GemmParams<T> g2;  // Pbar = (LuE^T W) diag(gv2)
+        g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+        g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+        g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
+        g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+        g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
+        if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
+        GemmParams<T> g4;  // Wbar = Lu Pbar - W diag(gv2 c) + mu gm^T            (into the Kzx buffer, no longer needed)
         g4.A = w.LuN; g4.lda = Mp; g4.sA0 = mm;
         g4.B = w.Pc; g4.ldb = ncp; g4.sB0 = Mp * ncp;
         g4.C = b.Kc; g4.ldc = ncp; g4.sC0 = Mp * ncp;
@@ -1365,8 +1410,7 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
         g4.super_cols = sched_plain.cols; g4.colscale = w.csc; g4.colvec = w.gmc; g4.sCs = ncp; g4.rowvec = b.muE; g4.sRv = Mp;
         g4.aux = Wc; g4.ncols = ncp;
         if (int rc = gemm_launch(g4, EPI_WBAR, s)) return rc;
-        // Kbar_x = Linv^T Wbar                                   (into the Pbar buffer)
-        GemmParams<T> g5;
+        GemmParams<T> g5;  // Kbar_x = Linv^T Wbar                                   (into the Pbar buffer)
         g5.A = w.LinvT; g5.lda = Mp; g5.sA0 = mm;
         g5.B = b.Kc; g5.ldb = ncp; g5.sB0 = Mp * ncp;
         g5.C = w.Pc; g5.ldc = ncp; g5.sC0 = Mp * ncp;
@@ -1412,28 +1456,13 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     // GL = sum_chunks Kbar_x W^T = Linv^T Q,  Q = (Sw - I) H + Hd + muE v^T   (fp64; v = W gm, before the KL is folded in)
     hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.H, w.D1, L * mm, 0);      // D1 = H
     GPZ_LAUNCH_OK();
-    const double* LuE64 = b.LuW;
-    if (wh) {
-      hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.LuN, w.D4, L * mm, 0);
-      GPZ_LAUNCH_OK();
-      LuE64 = w.D4;
-    }
-    if (int rc = dgemm(LuE64, LuE64, w.D2, GF_A_LOWER | GF_B_UPPER | GF_B_TRANS)) return rc;               // D2 = Sw
-    hipLaunchKernelGGL(minus_identity_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.D2, Mp);
-    GPZ_LAUNCH_OK();
-    if (int rc = dgemm(w.D2, w.D1, w.D3, 0)) return rc;                                                      // D3 = (Sw - I) H
+    if (int rc = dgemm(w.D2, w.D1, w.D3, 0)) return rc;                                                      // D3 = (Sw - I) H  (D2: before the chunks)
     if (wh) {
       hipLaunchKernelGGL((mirror_lower_kernel<T>), g32, dim3(256), 0, s, w.Hd, Mp);
       GPZ_LAUNCH_OK();
       hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.Hd, w.D3, L * mm, 1);   //    + Hd
       GPZ_LAUNCH_OK();
-      hipLaunchKernelGGL((mu_widen_kernel<T>), dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s,
-                         static_cast<const T*>(p->mu), M, Mp, w.me);
-    } else {
-      hipLaunchKernelGGL((linv_mu_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Linv,
-                         static_cast<const T*>(p->mu), Mp, M, w.me);
     }
-    GPZ_LAUNCH_OK();
     hipLaunchKernelGGL(rank1_update_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)(M < 1024 ? M : 1024), L32),
                        dim3(256), 0, s, w.D3, Mp, M, w.me, w.mu_sum);                                        //    + muE v^T
     GPZ_LAUNCH_OK();
