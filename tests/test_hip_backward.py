@@ -248,6 +248,50 @@ def test_kernel_and_Z_gradients_match_autograd(cfg, kind):
         torch.testing.assert_close((gth[:, 2].cpu() * 2 * c["group_diff"]), leaf["group_diff"].grad, **tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_all_parameter_gradients_with_columns_at_the_whitened_clamp(dtype):
+    """gp.py:287 clamp(Kxx - sum W^2, min=0): no gradient flows through a clamped prior term.  A negative jitter (Kzz
+    stays positive-definite: short lengthscales on scattered points) puts sigma^2 - colsum(Wt^2) below zero at the data
+    points that coincide with inducing points, so those columns carry the weights gv2 (1 - c) of the correction terms
+    (Hd in dLoss/dL, [Linv^T W] diag(gv2 (1 - c)) in Kbar_x), which run only in chunks that hold such a column (every
+    other whitened test takes the gated-off side).  Two chunks; every gradient against torch autograd over the oracle."""
+    from gpzoo_amd import ops
+    from gpzoo_amd.configs import spec_for_config
+    from gpzoo_amd.synthetic import make_config
+    from oracle import svgp_oracle as O
+    N, M, L = 3000, 150, 3
+    c = make_config(2, N=N, M=M, L=L, dtype=torch.float64)
+    c["sigma"] = torch.tensor([0.8, 1.0, 1.3], dtype=torch.float64)
+    c["lengthscale"] = torch.tensor([3.0, 3.5, 4.0], dtype=torch.float64)
+    c["Z"] = c["X"][300:300 + M].clone()                          # inducing points ARE data points (as the configuration draws them)
+    jitter = -0.02                                                # (the smallest eigenvalue of Kzz is 0.046 here)
+    g = {k: (v.to(dtype).cuda() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in c.items()}
+    spec, extra = spec_for_config(g)
+    chunk = 2048
+    out = ops.svgp_forward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], jitter, True, chunk=chunk, **extra)
+    gen = torch.Generator().manual_seed(12)
+    gm = torch.randn(L, N, generator=gen, dtype=torch.float64)
+    gs = torch.randn(L, N, generator=gen, dtype=torch.float64)
+    gmu, gLu, gth, gZ = ops.svgp_backward(spec, g["X"], g["Z"], g["mu"], g["Lu_raw"], jitter, True, gm.to(dtype).cuda(),
+                                          gs.to(dtype).cuda(), out["scale"], kernel_grads=True, chunk=chunk, **extra)
+    leaf = {k: c[k].clone().requires_grad_(True) for k in ("Z", "sigma", "lengthscale", "mu", "Lu_raw")}
+    Kzx = O.kernel_matrix("nsf_rbf", leaf["Z"], c["X"], leaf["sigma"], leaf["lengthscale"])
+    Kzz = O.kernel_matrix("nsf_rbf", leaf["Z"], leaf["Z"], leaf["sigma"], leaf["lengthscale"]) + jitter * torch.eye(M, dtype=torch.float64)
+    Kxx = (leaf["sigma"] ** 2)[:, None].expand(-1, N)
+    with torch.no_grad():
+        Wt = torch.linalg.solve_triangular(torch.linalg.cholesky(Kzz), Kzx, upper=False)
+        at_clamp = (Kxx - (Wt ** 2).sum(1)) <= 0
+    assert int(at_clamp.sum()) >= L * M                           # every coincident column, in every latent
+    mean, scale, _, _ = O.wsvgp_moments(Kxx, Kzx, Kzz, leaf["mu"], leaf["Lu_raw"])
+    ((mean * gm).sum() + (scale * gs).sum()).backward()
+    rt = 1e-6 if dtype == torch.float64 else 2e-3
+    def close(got, ref, name):
+        torch.testing.assert_close(got.double().cpu(), ref, rtol=rt, atol=rt * float(ref.abs().max()), msg=lambda m: f"{name}: {m}")
+    close(gmu, leaf["mu"].grad, "mu"); close(gLu, leaf["Lu_raw"].grad, "Lu")
+    close(gth[:, 0], leaf["sigma"].grad, "sigma"); close(gth[:, 1], leaf["lengthscale"].grad, "lengthscale")
+    close(gZ, leaf["Z"].grad, "Z")
+
+
 @pytest.mark.parametrize("name", [n for n in golden_cases() if n != "cfg1_f64"])
 def test_hyperparameter_gradients_match_reference(name):
     """Everything trainable at once (mu, Lu, Z, sigma, lengthscale, group_diff_param): loss.backward()
