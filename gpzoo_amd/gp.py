@@ -227,6 +227,8 @@ class _FusedGP(nn.Module):
         args = (spec, X, self.Z.detach().clone())
         factor_deps = [self.Z, self.kernel.sigma, self.kernel.lengthscale] + ([gparam] if gparam is not None else [])
         cargs = {} if any(t.requires_grad for t in factor_deps) else self._cache_args(spec, X)
+        if cargs and torch.cuda.is_current_stream_capturing():
+            cargs = {}          # a captured step cannot stop for the cross-call cache's content check: it factors per replay
         if not cargs:
             # cache_factor = False, or Z / kernel hyper-parameters are being trained (the optimiser changes them every
             # step: a cross-call cache could never hit and its content check costs a host sync per call): nothing is

@@ -246,12 +246,20 @@ class _DeferredInfo:
         self.flags.append((ok, reraise))
         self.checked = False
 
-    def check(self):
+    def any_bad(self) -> Optional[torch.Tensor]:
+        """0-d bool device tensor: some registered info word is non-zero or some argument check failed (no sync)."""
+        words = [i.reshape(-1) != 0 for i, _, _ in self.items] + [~f.reshape(1) for f, _ in self.flags]
+        return torch.cat(words).any() if words else None
+
+    def check(self, keep: bool = False):
         """ONE device-to-host sync for everything registered so far; raises what the eager check would have raised
         (torch.linalg.LinAlgError / IndexError / RuntimeError) for the first failing call, after invalidating every
-        factor cache that was committed on trust."""
+        factor cache that was committed on trust.  ``keep``: the registrations stay (a captured graph writes the same
+        tensors at every replay)."""
         items, flags = self.items, self.flags
-        self.items, self.flags, self.checked = [], [], True
+        if not keep:
+            self.items, self.flags = [], []
+        self.checked = True
         if not items and not flags:
             return
         words = [i.reshape(-1) != 0 for i, _, _ in items] + [~f.reshape(1) for f, _ in flags]

@@ -99,16 +99,109 @@ def _spots(X, batch_size):
     return torch.multinomial(torch.ones(X.shape[0], device=X.device), num_samples=batch_size, replacement=False)
 
 
-def train(model, optimizer, X, y, device=None, steps=200, E=20, fused=True, sync_losses=True, **kwargs):
+class GraphedStep:
+    """One optimisation step -- ``loss = loss_fn(); loss.backward(); optimizer.step()`` -- captured ONCE as a HIP graph
+    and replayed: at the notebooks' sizes (N ~ 1e3, M ~ 1e2) an eager step is a hundred launches of a few microseconds
+    each and the host cannot issue them as fast as the GPU retires them; a replay is one host call.
+
+    What a capture needs, and how it is met: no host synchronisation inside the step (the factorisation's ``info`` word
+    and the distributions' argument checks are registered as in ``ops.deferred_info()`` and read after the replay:
+    ``check()``); static shapes and the same tensors every step (parameters are updated in place by the optimiser, the
+    graph re-reads them); an optimiser whose step counter lives on the device (``capturable=True`` is switched on here
+    for torch's Adam-family optimisers -- construct the optimiser, then this object, before any eager step of your own);
+    no cross-call factor cache (a captured step factors Kzz at every replay, like the reference).  ``warmup`` eager steps
+    run first on the capture stream (they are real steps: ``first_losses`` holds their losses)."""
+
+    def __init__(self, loss_fn, optimizer, warmup: int = 3):
+        from . import ops
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        dev = params[0].device
+        for g in optimizer.param_groups:
+            if "capturable" in g:
+                g["capturable"] = True
+        for st in optimizer.state.values():
+            if torch.is_tensor(st.get("step")) and st["step"].device != dev:
+                st["step"] = st["step"].to(dev)
+        self.optimizer, self.pending = optimizer, ops._DeferredInfo()
+        self.first_losses = []
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):        # allocator, library workspaces and optimiser state of this stream
+                optimizer.zero_grad(set_to_none=True)
+                with ops.deferred_info():
+                    loss = loss_fn()
+                    loss.backward()
+                optimizer.step()
+                self.first_losses.append(loss.detach().clone())
+            optimizer.zero_grad(set_to_none=True)
+            self.graph = torch.cuda.CUDAGraph()
+            stack = ops._deferred.__dict__.setdefault("stack", [])
+            stack.append(self.pending)
+            try:
+                with torch.cuda.graph(self.graph, stream=side):
+                    loss = loss_fn()
+                    loss.backward()
+                    optimizer.step()
+                    self.loss = loss.detach()
+                    bad = self.pending.any_bad()
+                    self.bad = bad if bad is not None else torch.zeros((), dtype=torch.bool, device=dev)
+                    # what one device-to-host copy per step brings back: the loss and "something needs a look"
+                    self.status = torch.stack([self.loss.double(), self.bad.double()])
+            finally:
+                stack.pop()
+        cur.wait_stream(side)
+
+    def __call__(self) -> torch.Tensor:
+        """Replay the step; returns the (static) loss tensor of the replayed step -- clone it to keep it."""
+        self.graph.replay()
+        return self.loss
+
+    def check(self) -> float:
+        """One sync: the loss of the last replay as a float; raises what the eager step would have raised
+        (torch.linalg.LinAlgError for a Kzz that is not positive-definite, torch's ValueError for invalid distribution
+        arguments) -- AFTER that step's parameter update, which is the one difference from the eager loop."""
+        loss, bad = self.status.tolist()
+        if bad:
+            self.pending.check(keep=True)
+        return loss
+
+
+def train(model, optimizer, X, y, device=None, steps=200, E=20, fused=True, sync_losses=True, graph=False, **kwargs):
     """Full-batch optimisation loop with the reference's signature (utilities.py:471-493).  The
     forward and the gradients run on the fused HIP path; the optimiser step is torch's.
     ``fused``: Poisson factor models evaluate ``pY.log_prob(y).mean(0).sum()`` through ``model.expected_loglik``
     (gpz_poisson_nsf: the (E,D,N) rate is never materialised), as the mini-batch loops below do.
     Returns the list of losses: floats, one host sync per step as in the reference (``losses.append(loss.item())``,
     utilities.py:487), or with ``sync_losses=False`` 0-d device tensors converted once at the end -- the same numbers
-    without stalling the launch queue every step, which is most of a step at the notebooks' small sizes."""
+    without stalling the launch queue every step, which is most of a step at the notebooks' small sizes.
+    ``graph``: the step is captured once as a HIP graph and replayed (``GraphedStep``: same objective, same updates;
+    the optimiser is switched to ``capturable``; errors surface after the failing step's update instead of before)."""
     from .ops import deferred_info
     losses = []
+    if graph and steps > 0:
+        def loss_fn():
+            if fused and hasattr(model, "expected_loglik"):
+                ll, _, qU, pU = model.expected_loglik(X, y, E=E, **kwargs)
+                return -(ll - _kl_u(qU, pU))
+            return _elbo_terms(model, X, y, E, **kwargs)
+        warm = min(3, steps)
+        step = GraphedStep(loss_fn, optimizer, warmup=warm)
+        dev_losses = list(step.first_losses[:steps])
+        bad = None
+        for _ in range(steps - warm):
+            loss = step()
+            if sync_losses:
+                dev_losses.append(step.check())
+            else:
+                dev_losses.append(loss.clone())
+                bad = step.bad.clone() if bad is None else bad | step.bad
+        if bad is not None and bool(bad):
+            step.pending.check(keep=True)
+        tens = [v for v in dev_losses if torch.is_tensor(v)]
+        vals = iter(torch.stack([t.double() for t in tens]).tolist()) if tens else iter(())
+        return [next(vals) if torch.is_tensor(v) else v for v in dev_losses]
     for _ in range(steps):
         optimizer.zero_grad()
         with deferred_info():      # Kzz's `info` is read once, behind the backward pass's launches; a failure raises here

@@ -186,6 +186,47 @@ def test_deferred_info_check_raises_at_the_end_of_the_block_and_changes_no_numbe
         bad(X)
 
 
+@pytest.mark.parametrize("cls_name,trainable_kernel", [("WSVGP", False), ("SVGP", True)])
+def test_training_step_as_a_hip_graph_follows_the_eager_loop(cls_name, trainable_kernel):
+    """gpzoo.utilities.train(graph=True): forward + loss.backward() + Adam captured once (GraphedStep) and replayed --
+    no host synchronisation inside the step, parameters updated in place.  Same model, same initial state: the losses of
+    the replayed steps follow the eager loop's (Adam's capturable form rounds its bias corrections differently: 1e-7
+    after a dozen fp64 steps), with frozen and with trainable Z / kernel hyper-parameters; a Kzz that is not positive-definite still raises
+    torch.linalg.LinAlgError."""
+    import gpzoo.gp as G
+    from gpzoo.kernels import NSF_RBF
+    from gpzoo.likelihoods import ExactLikelihood
+    from gpzoo.utilities import train
+    g = torch.Generator().manual_seed(21)
+    X = (torch.rand(600, 2, generator=g, dtype=torch.float64) * 12).cuda()
+    y = torch.randn(2, 600, generator=g, dtype=torch.float64).cuda()
+
+    def make(jitter=1e-2):
+        gg = torch.Generator().manual_seed(22)
+        gp = getattr(G, cls_name)(NSF_RBF(L=2, lengthscale=1.5), dim=2, M=48, jitter=jitter).double()
+        gp.Z = nn.Parameter(X[:48].cpu().clone(), requires_grad=trainable_kernel)
+        gp.mu = nn.Parameter(0.1 * torch.randn(2, 48, generator=gg, dtype=torch.float64))
+        gp.Lu = nn.Parameter(0.05 * torch.randn(2, 48, 48, generator=gg, dtype=torch.float64))
+        for t in gp.kernel.parameters():
+            t.requires_grad_(trainable_kernel)
+        return ExactLikelihood(gp, noise=0.5).double().cuda()
+
+    runs = []
+    for graph in (False, True):
+        model = make()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+        runs.append((train(model, opt, X, y, steps=12, E=1, graph=graph), [p.detach().clone() for p in model.parameters()]))
+    (le, pe), (lg, pg) = runs
+    assert len(lg) == 12 and lg[-1] < lg[0]
+    torch.testing.assert_close(torch.tensor(lg), torch.tensor(le), rtol=2e-5, atol=0)
+    for a, b in zip(pe, pg):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)      # (Adam divides by sqrt(v): entries with a vanishing gradient amplify rounding)
+    bad = make(jitter=-0.9)
+    opt = torch.optim.Adam([p for p in bad.parameters() if p.requires_grad], lr=1e-2)
+    with pytest.raises(torch.linalg.LinAlgError, match="not positive-definite"):
+        train(bad, opt, X, y, steps=6, E=1, graph=True)
+
+
 @pytest.mark.parametrize("name", ["wsvgp_nsf_rbf_f64", "wsvgp_matern32_f32", "wsvgp_rbf_f64"])
 def test_forward_precomputed(name):
     """WSVGP.forward_precomputed (gp.py:308-322): W = (L^-1 Kzx)^T supplied by the caller."""
