@@ -45,7 +45,7 @@ class SvgpGrads(C.Structure):
     _fields_ = [("g_mean", C.c_void_p), ("g_scale", C.c_void_p), ("scale", C.c_void_p),
                 ("grad_mu", C.c_void_p), ("grad_Lu_raw", C.c_void_p),
                 ("grad_theta", C.c_void_p), ("grad_Z", C.c_void_p), ("g_chol", C.c_void_p),
-                ("g_kl", C.c_void_p)]
+                ("g_kl", C.c_void_p), ("point_order", C.c_void_p)]
 
 
 _SIGNATURES = {
@@ -80,6 +80,7 @@ _SIGNATURES = {
     "gpz_knn": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                           C.c_void_p]),
     "gpz_vnngp_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int32]),
+    "gpz_vnngp_state_bytes": (C.c_size_t, [C.POINTER(SvgpProblem)]),
     "gpz_vnngp_forward": (C.c_int, [C.POINTER(SvgpProblem), C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gpz_vnngp_backward_workspace_bytes": (C.c_size_t, [C.POINTER(SvgpProblem), C.c_int32]),
     "gpz_vnngp_backward": (C.c_int, [C.POINTER(SvgpProblem), C.POINTER(SvgpGrads), C.c_int32, C.c_void_p, C.c_void_p,

@@ -30,6 +30,12 @@
 
 #include <algorithm>
 
+// Timing-only diagnostics of vnngp_gather_kernel (WRONG results by construction; SRC=vnngp tools/ablate_fused.sh):
+// -DGPZ_VN_ABL=<bits>  1: no LDS row updates, 2: no record / index loads, 4: rows neither zeroed nor written out.
+#ifndef GPZ_VN_ABL
+#define GPZ_VN_ABL 0
+#endif
+
 namespace gpz {
 
 struct KgradArgs {   // kgrad.hip
@@ -211,10 +217,17 @@ struct VnnBwdArgs {
   double* kacc;                 // (L,Mp,8)   dz0..3, dsigma, dlengthscale (kgrad.hip layout), or null
   T* rec;                       // [L*N][3K + 2], in the problem's precision: per point w[K], v[K], kx[K], gm, gcov CONTIGUOUS -- what vnngp_gather_kernel
                                 // reads per entry (from the [column][point] scratch every value is a 64-byte sector of its own)
-  const int32_t* inv;           // (N*K) entries n * K + p grouped by the inducing point they name, ascending inside a group
+  const int32_t* inv;           // (N*K) entries n * 32 + p grouped by the inducing point they name, ascending inside a group
   const int32_t* start;         // (M + 1) group boundaries in inv
   const int32_t* dup;           // one word: non-zero when some point names an inducing point twice (caller-supplied tables
                                 // only; gpz_knn's lists are distinct by construction), or null
+  // The backward pass works on the points in the caller's `point_order` (position n' holds point order[n']; null:
+  // identity): thread n' of the point kernel, record n', entry n' K + p.  Along a space-filling curve the points that name
+  // one inducing point sit next to each other, so the gather's reads of their records -- random 128-byte reads in the
+  // original order, what bounded it -- become runs of neighbouring records.
+  const int64_t* order;
+  const int32_t* idxp;          // (N,K) neighbour table in that order, int32
+  const T* Xp;                  // (N,d) points in that order
 };
 
 template <typename T>
@@ -224,7 +237,9 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_kernel(VnnBwdArgs<T> b) {
   const int64_t total = (int64_t)a.L * a.N;
   if (t >= total) return;
   const int l = (int)(t / a.N);
-  const int64_t n = t - (int64_t)l * a.N;
+  const int64_t np = t - (int64_t)l * a.N;                     // position in the pass's order
+  const int64_t n = b.order ? b.order[np] : np;                // the point itself
+  const int64_t tn = (int64_t)l * a.N + n;
   const int K = a.K;
   const int64_t* id = a.idx + n * K;
   double* A = a.scratch + t;
@@ -234,9 +249,9 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_kernel(VnnBwdArgs<T> b) {
   double* v = sw + (int64_t)K * total;
   double mean, cov;
   vnn_point_solve<T>(a, total, l, n, id, A, kx, w, sw, mean, cov);
-  const double gm = (double)b.g_mean[t];
+  const double gm = (double)b.g_mean[tn];
   // scale = sqrt(clamp(cov, min)): no gradient through a clamped variance (gp.py:117)
-  const double gcov = (cov > a.clamp_min) ? 0.5 * (double)b.g_scale[t] / sqrt(cov) : 0.0;
+  const double gcov = (cov > a.clamp_min) ? 0.5 * (double)b.g_scale[tn] / sqrt(cov) : 0.0;
   // dLoss/dW with W free, then through W = A^{-1} k:  v = A^{-1} gW,  dk = v - gcov W,  dA = -v W^T
   for (int p = 0; p < K; ++p)
     v[p * total] = gm * (double)a.mu[(int64_t)l * a.M + id[p]] + gcov * (2.0 * sw[p * total] - kx[p * total]);
@@ -377,13 +392,15 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_reg_kernel(VnnBwdArgs<T> 
   const int64_t total = (int64_t)a.L * a.N;
   if (t >= total) return;
   const int l = (int)(t / a.N);
-  const int64_t n = t - (int64_t)l * a.N;
+  const int64_t np = t - (int64_t)l * a.N;                     // position in the pass's order
+  const int64_t n = b.order ? b.order[np] : np;                // the point itself
+  const int64_t tn = (int64_t)l * a.N + n;
   const int K = a.K;
   double A[KT * (KT + 1) / 2], kx[KT], w[KT], sw[KT], v[KT], mean, cov;
   int64_t id[KT];
   vnn_point_solve_reg<T, KT>(a, l, n, a.idx + n * K, A, kx, w, sw, id, mean, cov);
-  const double gm = (double)b.g_mean[t];
-  const double gcov = (cov > a.clamp_min) ? 0.5 * (double)b.g_scale[t] / sqrt(cov) : 0.0;
+  const double gm = (double)b.g_mean[tn];
+  const double gcov = (cov > a.clamp_min) ? 0.5 * (double)b.g_scale[tn] / sqrt(cov) : 0.0;
 #pragma unroll
   for (int p = 0; p < KT; ++p)
     v[p] = p < K ? gm * (double)a.mu[(int64_t)l * a.M + id[p]] + gcov * (2.0 * sw[p] - kx[p]) : 0.0;
@@ -432,7 +449,19 @@ __global__ __launch_bounds__(256) void vnngp_point_bwd_reg_kernel(VnnBwdArgs<T> 
 // earlier blocks + entries of its group earlier in its own block.
 constexpr int VNN_IB = 1024;
 
-__global__ __launch_bounds__(256) void vnn_inv_hist_kernel(const int64_t* __restrict__ idx, int64_t NK, int64_t M,
+// the neighbour table and the points in the pass's order: idxp[n'][p] = idx[order[n']][p] (int32), Xp[n'] = X[order[n']]
+template <typename T>
+__global__ __launch_bounds__(256) void vnn_permute_kernel(const int64_t* __restrict__ idx, const T* __restrict__ X,
+                                                         const int64_t* __restrict__ order, int64_t N, int K, int d,
+                                                         int32_t* __restrict__ idxp, T* __restrict__ Xp) {
+  const int64_t np = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (np >= N) return;
+  const int64_t n = order ? order[np] : np;
+  for (int p = 0; p < K; ++p) idxp[np * K + p] = (int32_t)idx[n * K + p];
+  for (int k = 0; k < d; ++k) Xp[np * d + k] = X[n * d + k];
+}
+
+__global__ __launch_bounds__(256) void vnn_inv_hist_kernel(const int32_t* __restrict__ idx, int64_t NK, int64_t M,
                                                           int32_t* __restrict__ H) {
   const int64_t b = blockIdx.x;
   for (int i = threadIdx.x; i < VNN_IB; i += 256) {
@@ -441,18 +470,27 @@ __global__ __launch_bounds__(256) void vnn_inv_hist_kernel(const int64_t* __rest
   }
 }
 
-// one thread per inducing point: H[b][m] <- entries of m in blocks < b; count[m] = total
+// one WAVE per inducing point: H[b][m] <- entries of m in blocks < b; count[m] = total.  64 blocks per trip with a
+// shuffle scan (a thread per point walked the B = N K / 1024 blocks one dependent load after the other: 95 us at N = 40 000)
 __global__ __launch_bounds__(256) void vnn_inv_scan_kernel(int32_t* __restrict__ H, int64_t B, int64_t M,
                                                           int32_t* __restrict__ count) {
-  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   int32_t run = 0;
-  for (int64_t b = 0; b < B; ++b) {
-    const int32_t c = H[b * M + m];
-    H[b * M + m] = run;
-    run += c;
+  for (int64_t b0 = 0; b0 < B; b0 += 64) {
+    const int64_t b = b0 + lane;
+    const int32_t c = b < B ? H[b * M + m] : 0;
+    int32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (b < B) H[b * M + m] = run + inc - c;
+    run += __shfl(inc, 63);
   }
-  count[m] = run;
+  if (lane == 0) count[m] = run;
 }
 
 // one block: start[m] = sum of count[0..m), start[M] = N K
@@ -474,14 +512,14 @@ __global__ __launch_bounds__(256) void vnn_inv_start_kernel(const int32_t* __res
   for (int64_t m = lo; m < hi; ++m) { start[m] = run; run += count[m]; }
 }
 
-__global__ __launch_bounds__(256) void vnn_inv_fill_kernel(const int64_t* __restrict__ idx, int64_t NK, int64_t M,
+__global__ __launch_bounds__(256) void vnn_inv_fill_kernel(const int32_t* __restrict__ idx, int64_t NK, int64_t M,
                                                           const int32_t* __restrict__ H, const int32_t* __restrict__ start,
-                                                          int32_t* __restrict__ inv) {
+                                                          int32_t* __restrict__ inv, int K) {
   __shared__ int32_t key[VNN_IB];
   const int64_t b = blockIdx.x;
   for (int i = threadIdx.x; i < VNN_IB; i += 256) {
     const int64_t e = b * VNN_IB + i;
-    key[i] = e < NK ? (int32_t)idx[e] : -1;
+    key[i] = e < NK ? idx[e] : -1;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < VNN_IB; i += 256) {
@@ -489,7 +527,8 @@ __global__ __launch_bounds__(256) void vnn_inv_fill_kernel(const int64_t* __rest
     if (m < 0) continue;
     int32_t r = 0;
     for (int j = 0; j < i; ++j) r += key[j] == m;
-    inv[start[m] + H[b * M + m] + r] = (int32_t)(b * VNN_IB + i);
+    const int32_t e = (int32_t)(b * VNN_IB + i), n = e / K;
+    inv[start[m] + H[b * M + m] + r] = n * 32 + (e - n * K);        // (point, slot) packed: K <= 32
   }
 }
 
@@ -508,10 +547,20 @@ __global__ __launch_bounds__(256) void vnn_dup_kernel(const int64_t* __restrict_
   if (dup) atomicOr(flag, 1);
 }
 
+__device__ __forceinline__ float vnn_readlane(float v, int i) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+}
+__device__ __forceinline__ double vnn_readlane(double v, int i) {
+  const long long bits = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), i);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), i);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // One wave per (inducing point ip, latent l): walks the entries that name ip in ascending order and forms, with the two
 // rows resident in LDS, row ip of T_S and T_K, gmu[ip] and the dz part of kacc -- the sums the point kernel used to
 // scatter with atomics.  The dsigma / dlengthscale totals of a latent go through vnn_theta_sum_kernel.
-template <typename T>
+template <typename T, bool WIDE, bool KG>       // WIDE: records of more than 64 values (K > 20); KG: kernel / Z gradients too
 __global__ __launch_bounds__(64) void vnngp_gather_kernel(VnnBwdArgs<T> b) {
   extern __shared__ double vnn_rows[];       // [2][Mp]
   const VnnArgs<T>& a = b.f;
@@ -520,7 +569,8 @@ __global__ __launch_bounds__(64) void vnngp_gather_kernel(VnnBwdArgs<T> b) {
   const int64_t total = (int64_t)a.L * a.N;
   double* rowS = vnn_rows;
   double* rowK = vnn_rows + a.Mp;
-  for (int64_t j = lane; j < 2 * a.Mp; j += 64) vnn_rows[j] = 0.0;
+  if (!(GPZ_VN_ABL & 4))
+    for (int64_t j = lane; j < (KG ? 2 : 1) * a.Mp; j += 64) vnn_rows[j] = 0.0;
   __syncthreads();
   const int R = 3 * K + 2;                    // record: w[K], v[K], kx[K], gm, gcov
   const double el = (double)a.ell[l], il2 = 1.0 / (el * el);
@@ -534,79 +584,108 @@ __global__ __launch_bounds__(64) void vnngp_gather_kernel(VnnBwdArgs<T> b) {
   // all issued before the first use, the updates are applied in entry order -- the sums are the same sums in the same
   // order.  One entry per trip was bound by exactly that latency: 400 entries x 2 us per wave, 2.8 ms per backward at
   // N = 40 000, M = 1000, L = 10, K = 10.
+  // A point's record (3K + 2 values: w, v, kx, gm, gcov) arrives as ONE load per entry, a value per lane, and the values an
+  // update needs are broadcast from the lanes that hold them (w[q] is already in lane q).  Loaded value by value -- seven
+  // mostly wave-uniform loads per entry -- the kernel was bound by the rate at which a CU issues vector memory
+  // instructions, not by where the records lie: laying them out along a Morton curve changed nothing until this did.
   constexpr int U = 8;
+  const double zl = (KG && lane < a.d) ? (double)a.Z[ip * a.d + lane] : 0.0;
+  auto pick = [&](T lo, T hi, int i) -> double {          // record value i (wave-uniform) out of the two lane vectors
+    if constexpr (!WIDE) return (double)vnn_readlane(lo, i);
+    return (double)(i < 64 ? vnn_readlane(lo, i) : vnn_readlane(hi, i - 64));
+  };
+  // Three trips in flight: the entries (inv) of trip i + 2 and the records of trip i + 1 are requested before trip i's
+  // updates run -- entry -> point -> record are two dependent levels of global latency, and with the 16 KB of rows a CU
+  // holds ten of these waves: unpipelined, a trip cost both round trips plus its updates.
+  struct Ent { int64_t n[U]; int pp[U]; };
+  struct Rec { T r0[U], r1[U]; int32_t iq[U]; double xd[U]; };
+  auto load_ent = [&](int32_t eb, Ent& E) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t e = eb + u < e1 ? b.inv[eb + u] : -1;       // (point << 5) | slot
+      E.n[u] = e < 0 ? 0 : e >> 5;
+      E.pp[u] = e < 0 ? -1 : e & 31;
+    }
+  };
+  auto load_rec = [&](const Ent& E, Rec& Q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const T* rec = b.rec + ((int64_t)l * a.N + ((GPZ_VN_ABL & 2) ? 0 : E.n[u])) * R;
+      Q.r0[u] = lane < R ? rec[lane] : (T)0;
+      Q.r1[u] = (WIDE && lane + 64 < R) ? rec[lane + 64] : (T)0;
+      Q.iq[u] = lane < K ? b.idxp[E.n[u] * K + lane] : 0;
+      Q.xd[u] = (KG && lane < a.d) ? (double)b.Xp[E.n[u] * a.d + lane] : 0.0;
+    }
+  };
+  Ent e_cur, e_nxt, e_nx2;
+  Rec q_cur, q_nxt;
+  load_ent(e0, e_cur);
+  load_ent(e0 + U, e_nxt);
+  load_rec(e_cur, q_cur);
   for (int32_t eb = e0; eb < e1; eb += U) {
-    int64_t n[U], t[U], iq[U];
-    int pp[U];
-    double gm[U], gcov[U], wp[U], vp[U], wq[U], vq[U], kxp[U], xd[U];
+    load_ent(eb + 2 * U, e_nx2);
+    load_rec(e_nxt, q_nxt);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int32_t e = eb + u < e1 ? b.inv[eb + u] : -1;
-      n[u] = e < 0 ? 0 : e / K;
-      pp[u] = e < 0 ? -1 : e - (int32_t)n[u] * K;
-      t[u] = (int64_t)l * a.N + n[u];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = pp[u] < 0 ? 0 : pp[u];
-      const T* rec = b.rec + t[u] * R;
-      gm[u] = (double)rec[3 * K]; gcov[u] = (double)rec[3 * K + 1];
-      wp[u] = (double)rec[p]; vp[u] = (double)rec[K + p];
-      const int q = lane <= p ? lane : 0;
-      iq[u] = a.idx[n[u] * K + q];
-      wq[u] = (double)rec[q];
-      vq[u] = b.gK ? (double)rec[K + q] : 0.0;
-      kxp[u] = b.kacc ? (double)rec[2 * K + p] : 0.0;
-      xd[u] = (b.kacc && lane < a.d) ? (double)a.X[n[u] * a.d + lane] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = pp[u];
-      if (p < 0) continue;                      // past the group's end (wave-uniform)
-      if (!serial) {
+      if (e_cur.pp[u] < 0) continue;            // past the group's end (wave-uniform)
+      const int p = __builtin_amdgcn_readfirstlane(e_cur.pp[u]);
+      const T r0 = q_cur.r0[u], r1 = q_cur.r1[u];
+      const double gm = pick(r0, r1, 3 * K), gcov = pick(r0, r1, 3 * K + 1);
+      const double wp = pick(r0, r1, p), vp = pick(r0, r1, K + p);
+      const double wq = (double)r0;                                         // lane q < K holds w[q]
+      const double vq = KG ? (double)__shfl(r0, (K + lane) & 63) : 0.0;     // ... and fetches v[q] from lane K + q
+      const int32_t iq = q_cur.iq[u];
+      if (GPZ_VN_ABL & 1) {
+        gmu += gcov * wq + vq * (double)iq;
+      } else if (!serial) {
         if (lane <= p) {                        // one unordered pair (p, q <= p) per lane: distinct columns of the rows
           const int q = lane;
-          if (gcov[u] != 0.0) rowS[iq[u]] += (p == q ? 0.5 : 1.0) * gcov[u] * wp[u] * wq[u];
-          if (b.gK) rowK[iq[u]] += p == q ? -vp[u] * wq[u] : -(vp[u] * wq[u] + vq[u] * wp[u]);
+          if (gcov != 0.0) rowS[iq] += (p == q ? 0.5 : 1.0) * gcov * wp * wq;
+          if constexpr (KG) rowK[iq] += p == q ? -vp * wq : -(vp * wq + vq * wp);
         }
       } else {
         for (int q = 0; q <= p; ++q)
           if (lane == q) {
-            if (gcov[u] != 0.0) rowS[iq[u]] += (p == q ? 0.5 : 1.0) * gcov[u] * wp[u] * wq[u];
-            if (b.gK) rowK[iq[u]] += p == q ? -vp[u] * wq[u] : -(vp[u] * wq[u] + vq[u] * wp[u]);
+            if (gcov != 0.0) rowS[iq] += (p == q ? 0.5 : 1.0) * gcov * wp * wq;
+            if constexpr (KG) rowK[iq] += p == q ? -vp * wq : -(vp * wq + vq * wp);
           }
       }
-      if (lane == 0) gmu += gm[u] * wp[u];
-      if (b.kacc && lane < a.d) {
-        const double gk = (vp[u] - gcov[u] * wp[u]) * kxp[u];
-        dz += gk * (xd[u] - (double)a.Z[ip * a.d + lane]) * il2;      // dk/dz = k (x - z) / l^2
+      if (lane == 0) gmu += gm * wp;
+      if (KG && lane < a.d) {
+        const double kxp = pick(r0, r1, 2 * K + p);
+        const double gk = (vp - gcov * wp) * kxp;
+        dz += gk * (q_cur.xd[u] - zl) * il2;      // dk/dz = k (x - z) / l^2
       }
       // (two entries of one trip can name the same column through different points: the LDS updates of entry u are
       // complete before entry u + 1 reads the row -- one wave, program order)
     }
+    e_cur = e_nxt; e_nxt = e_nx2; q_cur = q_nxt;
   }
   __syncthreads();
   double* gS = b.gS + ((int64_t)l * a.Mp + ip) * a.Mp;
+  if (GPZ_VN_ABL & 4) { if (lane == 0) b.gmu[(int64_t)l * a.Mp + ip] = gmu + dz; return; }
   for (int64_t j = lane; j < a.Mp; j += 64) gS[j] = rowS[j];
-  if (b.gK) {
+  if constexpr (KG) {
     double* gK = b.gK + ((int64_t)l * a.Mp + ip) * a.Mp;
     for (int64_t j = lane; j < a.Mp; j += 64) gK[j] = rowK[j];
   }
   if (lane == 0) b.gmu[(int64_t)l * a.Mp + ip] = gmu;
-  if (b.kacc && lane < a.d) b.kacc[((int64_t)l * a.Mp + ip) * 8 + lane] = dz;
+  if (KG && lane < a.d) b.kacc[((int64_t)l * a.Mp + ip) * 8 + lane] = dz;
 }
 
-// kacc[l][row 0][4, 5] = sum over the points of a latent of dsigma, dlengthscale (fixed order: strided partial sums, tree)
+// kacc[l][row 0][4, 5] = sum over the points of a latent of dsigma, dlengthscale (fixed order: 64 strided partial sums per
+// latent and quantity, then their tree; one block per latent walked 2 N doubles alone: 0.13 ms at N = 40 000)
+constexpr int VNN_TS = 64;
 template <typename T>
-__global__ __launch_bounds__(256) void vnn_theta_sum_kernel(VnnBwdArgs<T> b) {
+__global__ __launch_bounds__(256) void vnn_theta_part_kernel(VnnBwdArgs<T> b, double* __restrict__ part) {
   __shared__ double sh[256];
   const VnnArgs<T>& a = b.f;
-  const int l = blockIdx.x, K = a.K;
+  const int l = blockIdx.y, sgm = blockIdx.x, K = a.K;
   const int64_t total = (int64_t)a.L * a.N;
   const double* ex = a.scratch + (int64_t)(K * K + 4 * K) * total;
   for (int q = 0; q < 2; ++q) {
     double v = 0.0;
-    for (int64_t n = threadIdx.x; n < a.N; n += 256) v += ex[(2 + q) * total + (int64_t)l * a.N + n];
+    for (int64_t n = (int64_t)sgm * 256 + threadIdx.x; n < a.N; n += (int64_t)VNN_TS * 256) v += ex[(2 + q) * total + (int64_t)l * a.N + n];
     __syncthreads();
     sh[threadIdx.x] = v;
     __syncthreads();
@@ -614,7 +693,17 @@ __global__ __launch_bounds__(256) void vnn_theta_sum_kernel(VnnBwdArgs<T> b) {
       if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
       __syncthreads();
     }
-    if (threadIdx.x == 0) b.kacc[(int64_t)l * a.Mp * 8 + 4 + q] = sh[0];
+    if (threadIdx.x == 0) part[((int64_t)l * 2 + q) * VNN_TS + sgm] = sh[0];
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(64) void vnn_theta_sum_kernel(VnnBwdArgs<T> b, const double* __restrict__ part) {
+  const VnnArgs<T>& a = b.f;
+  const int l = blockIdx.x, lane = threadIdx.x;
+  for (int q = 0; q < 2; ++q) {
+    double v = part[((int64_t)l * 2 + q) * VNN_TS + lane];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0) b.kacc[(int64_t)l * a.Mp * 8 + 4 + q] = v;
   }
 }
 
@@ -650,8 +739,31 @@ struct VnnPlan {
   double *Linv, *Tmp, *LuE, *muE;                       // KL(qU || pU): L^{-1}, L^{-1} Lu, L^{-1} mu
   uint32_t* fsync;                                       // tickets and flags of the one-launch Cholesky (csrc/coop.hip)
   double *gmu, *gS, *gK, *kacc, *G, *D1, *D2, *rec; void* PS;  // backward only
-  int32_t *inv, *istart, *ihist, *itmp, *idup;           // backward only: the inverted neighbour table and its scratch
+  int32_t *inv, *istart, *ihist, *itmp, *idup, *idxp;    // backward only: the inverted neighbour table and its scratch
+  void* Xp; double* tpart;
 };
+
+// What a forward pass hands to the backward pass of the same call (gpz_svgp_problem.factor_cache, gpz_vnngp_state_bytes):
+// Kzz + jitter I, its Cholesky factor and the inverses of its diagonal blocks, Lu and S = Lu Lu^T in fp64, and -- written
+// when the forward evaluates KL(qU || pU) -- Linv, LuE = Linv Lu, muE = Linv mu.  A backward pass that finds
+// factor_cache_valid bit 0 (the factor, Lu, S) / bit 2 (the KL operands) set reads them instead of forming them again:
+// 1.4 ms of a 10 ms forward + backward at N = 40 000, M = 1000, L = 10.
+struct VnnState { double *Kzz, *Kfac, *Dinv, *LuD, *S, *Linv, *LuE, *muE; size_t bytes; };
+static VnnState vnn_state(const gpz_svgp_problem* p, void* mem) {
+  VnnState st;
+  const int64_t L = p->k.n_latent, Mp = pad_up(p->M), mm = L * Mp * Mp;
+  Carver c(mem);
+  st.Kzz = c.take<double>(mm);
+  st.Kfac = c.take<double>(mm);
+  st.Dinv = c.take<double>(L * (Mp / 128) * 128 * 128);
+  st.LuD = c.take<double>(mm);
+  st.S = c.take<double>(mm);
+  st.Linv = c.take<double>(mm);
+  st.LuE = c.take<double>(mm);
+  st.muE = c.take<double>(L * Mp);
+  st.bytes = c.used();
+  return st;
+}
 
 // M is a few thousand at most on this path: every mode carves the same (generous) set of M x M buffers
 static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws, int bwd = 0) {
@@ -659,27 +771,41 @@ static VnnPlan vnn_plan(const gpz_svgp_problem* p, int K, bool own_idx, void* ws
   pl.L = p->k.n_latent; pl.N = p->N; pl.M = p->M; pl.Mp = pad_up(p->M); pl.K = K;
   const int64_t mm = pl.L * pl.Mp * pl.Mp;
   Carver c(ws);
-  pl.Kzz = c.take<double>(mm);
-  pl.Kfac = c.take<double>(mm);
-  pl.Dinv = c.take<double>(pl.L * (pl.Mp / 128) * 128 * 128);
-  pl.LuD = c.take<double>(mm);
-  pl.S = c.take<double>(mm);
+  if (p->factor_cache) {            // the persistent pieces live in the caller's hand-off buffer
+    const VnnState st = vnn_state(p, p->factor_cache);
+    pl.Kzz = st.Kzz; pl.Kfac = st.Kfac; pl.Dinv = st.Dinv; pl.LuD = st.LuD; pl.S = st.S;
+  } else {
+    pl.Kzz = c.take<double>(mm);
+    pl.Kfac = c.take<double>(mm);
+    pl.Dinv = c.take<double>(pl.L * (pl.Mp / 128) * 128 * 128);
+    pl.LuD = c.take<double>(mm);
+    pl.S = c.take<double>(mm);
+  }
   pl.scratch = c.take<double>((int64_t)(K * K + (bwd ? 4 : 2) * K + (bwd ? 4 : 0)) * pl.L * pl.N);
   pl.idx = own_idx ? c.take<int64_t>(pl.N * K) : nullptr;
-  pl.Linv = c.take<double>(mm);
   pl.Tmp = c.take<double>(mm / 2 + 64);
-  pl.LuE = c.take<double>(mm);
-  pl.muE = c.take<double>(pl.L * pl.Mp);
+  if (p->factor_cache) {
+    const VnnState st = vnn_state(p, p->factor_cache);
+    pl.Linv = st.Linv; pl.LuE = st.LuE; pl.muE = st.muE;
+  } else {
+    pl.Linv = c.take<double>(mm);
+    pl.LuE = c.take<double>(mm);
+    pl.muE = c.take<double>(pl.L * pl.Mp);
+  }
   pl.fsync = c.take<uint32_t>(coop_sync_words(pl.Mp, pl.L));
   pl.gmu = pl.gS = pl.gK = pl.kacc = pl.G = pl.D1 = pl.D2 = pl.rec = nullptr;
   pl.PS = nullptr;
-  pl.inv = pl.istart = pl.ihist = pl.itmp = pl.idup = nullptr;
+  pl.inv = pl.istart = pl.ihist = pl.itmp = pl.idup = pl.idxp = nullptr;
+  pl.Xp = nullptr; pl.tpart = nullptr;
   if (bwd) {
     const int64_t NK = pl.N * K, IB = (NK + VNN_IB - 1) / VNN_IB;
     pl.inv = c.take<int32_t>(NK);
     pl.istart = c.take<int32_t>(pl.M + 2);
     pl.itmp = c.take<int32_t>(pl.M + 2);
     pl.idup = c.take<int32_t>(16);
+    pl.idxp = c.take<int32_t>(NK);
+    pl.Xp = c.take<double>(pl.N * 4);
+    pl.tpart = c.take<double>(pl.L * 2 * VNN_TS);
     pl.ihist = c.take<int32_t>(IB * pl.M);
     pl.rec = c.take<double>((int64_t)(3 * K + 2) * pl.L * pl.N);
     pl.gmu = c.take<double>(pl.L * pl.Mp);
@@ -721,23 +847,30 @@ static int vnn_prepare(const gpz_svgp_problem* p, VnnPlan& pl, const int64_t* id
   const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, N = pl.N, mm = Mp * Mp;
   const int L32 = (int)L;
   const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
-  if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, nullptr, nullptr, pl.Kzz, Mp, mm, p->jitter, 1, GPZ_F64, s))
-    return rc;
-  GPZ_HIP_OK(hipMemcpyAsync(pl.Kfac, pl.Kzz, sizeof(double) * L * mm, hipMemcpyDeviceToDevice, s));
-  if (int rc = potrf_padded(pl.Kfac, Mp, Mp, mm, L, M, pl.Dinv, p->info, s, true, pl.fsync)) return rc;
+  const bool handed = p->factor_cache && (p->factor_cache_valid & 1);      // this call's forward left them in the buffer
+  if (handed) {
+    GPZ_HIP_OK(hipMemsetAsync(p->info, 0, sizeof(int32_t) * L, s));
+  } else {
+    if (int rc = kfill_padded(&p->k, p->Z, M, Mp, p->Z, M, Mp, p->d, nullptr, nullptr, pl.Kzz, Mp, mm, p->jitter, 1, GPZ_F64, s))
+      return rc;
+    GPZ_HIP_OK(hipMemcpyAsync(pl.Kfac, pl.Kzz, sizeof(double) * L * mm, hipMemcpyDeviceToDevice, s));
+    if (int rc = potrf_padded(pl.Kfac, Mp, Mp, mm, L, M, pl.Dinv, p->info, s, true, pl.fsync)) return rc;
+  }
   if (p->chol) {
     hipLaunchKernelGGL((vnn_chol_out_kernel<T>), dim3((unsigned)((M + 255) / 256), (unsigned)M, L32), dim3(256), 0, s,
                        pl.Kfac, Mp, M, static_cast<T*>(p->chol));
     GPZ_LAUNCH_OK();
   }
-  // S = Lu Lu^T on the fp64 MFMA path
-  hipLaunchKernelGGL((vnn_lu_kernel<T>), gm, dim3(256), 0, s, static_cast<const T*>(p->Lu_raw), M, Mp, pl.LuD,
-                     static_cast<T*>(p->Lu));
-  GPZ_LAUNCH_OK();
-  GemmParams<double> g;
-  g.A = pl.LuD; g.lda = Mp; g.sA0 = mm; g.B = pl.LuD; g.ldb = Mp; g.sB0 = mm; g.C = pl.S; g.ldc = Mp; g.sC0 = mm;
-  g.nb0 = L32; g.mt = g.nt = (int)(Mp / 128); g.K = (int)Mp; g.flags = GF_A_LOWER | GF_B_UPPER | GF_B_TRANS;
-  if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
+  if (!handed) {
+    // S = Lu Lu^T on the fp64 MFMA path
+    hipLaunchKernelGGL((vnn_lu_kernel<T>), gm, dim3(256), 0, s, static_cast<const T*>(p->Lu_raw), M, Mp, pl.LuD,
+                       static_cast<T*>(p->Lu));
+    GPZ_LAUNCH_OK();
+    GemmParams<double> g;
+    g.A = pl.LuD; g.lda = Mp; g.sA0 = mm; g.B = pl.LuD; g.ldb = Mp; g.sB0 = mm; g.C = pl.S; g.ldc = Mp; g.sC0 = mm;
+    g.nb0 = L32; g.mt = g.nt = (int)(Mp / 128); g.K = (int)Mp; g.flags = GF_A_LOWER | GF_B_UPPER | GF_B_TRANS;
+    if (int rc = gemm_launch(g, EPI_STORE, s)) return rc;
+  }
   const int64_t* idx = idx_in;
   if (!idx) {
     if (int rc = knn_t<T>(p->X, N, p->Z, M, p->d, pl.K, pl.idx, s)) return rc;
@@ -1013,8 +1146,8 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
   q.chol = nullptr; q.Lu = nullptr; q.kl = nullptr;
   VnnBwdArgs<T> b;
   if (int rc = vnn_prepare<T>(&q, pl, idx_in, b.f, s)) return rc;
-  if (g_kl || with_chol)             // Linv (and, for the KL, LuE = Linv Lu and muE = Linv mu)
-    if (int rc = vnn_kl_prepare<T>(p, pl, nullptr, s)) return rc;
+  if ((g_kl || with_chol) && !(p->factor_cache && (p->factor_cache_valid & 5) == 5))
+    if (int rc = vnn_kl_prepare<T>(p, pl, nullptr, s)) return rc;   // Linv (and, for the KL, LuE = Linv Lu and muE = Linv mu)
   // rows >= M of the accumulators are padding: zero; rows < M are written whole by the gather below
   GPZ_HIP_OK(hipMemsetAsync(pl.gmu, 0, sizeof(double) * L * Mp, s));
   GPZ_HIP_OK(hipMemsetAsync(pl.gS, 0, sizeof(double) * L * mm, s));
@@ -1023,6 +1156,10 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
     GPZ_HIP_OK(hipMemsetAsync(pl.kacc, 0, sizeof(double) * L * Mp * 8, s));
   }
   b.g_mean = static_cast<const T*>(g->g_mean); b.g_scale = static_cast<const T*>(g->g_scale);
+  b.order = g->point_order; b.idxp = pl.idxp; b.Xp = static_cast<const T*>(pl.Xp);
+  hipLaunchKernelGGL((vnn_permute_kernel<T>), dim3((unsigned)((pl.N + 255) / 256)), dim3(256), 0, s, b.f.idx, b.f.X, b.order,
+                     pl.N, K, p->d, pl.idxp, static_cast<T*>(pl.Xp));
+  GPZ_LAUNCH_OK();
   b.gmu = pl.gmu; b.gS = pl.gS; b.gK = kgrads ? pl.gK : nullptr; b.kacc = kgrads ? pl.kacc : nullptr; b.rec = reinterpret_cast<T*>(pl.rec);
   {
     const dim3 grid((unsigned)((L * pl.N + 255) / 256));
@@ -1037,17 +1174,17 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
     // the neighbour table inverted (stable counting sort of the N K entries by the inducing point they name), then the
     // sums per inducing point in that fixed order
     const int64_t NK = pl.N * K, IB = (NK + VNN_IB - 1) / VNN_IB;
-    GPZ_REQUIRE(NK < (1ll << 31), "gpz_vnngp_backward: N * K = %lld entries exceed the 32-bit neighbour index", (long long)NK);
+    GPZ_REQUIRE(NK < (1ll << 31) && pl.N < (1ll << 26), "gpz_vnngp_backward: N * K = %lld entries exceed the 32-bit neighbour index", (long long)NK);
     GPZ_REQUIRE(2 * Mp * sizeof(double) <= 128 * 1024, "gpz_vnngp_backward: M = %lld inducing points exceed the gather's LDS rows",
                 (long long)M);
     GPZ_HIP_OK(hipMemsetAsync(pl.ihist, 0, sizeof(int32_t) * IB * M, s));
-    hipLaunchKernelGGL(vnn_inv_hist_kernel, dim3((unsigned)IB), dim3(256), 0, s, b.f.idx, NK, M, pl.ihist);
+    hipLaunchKernelGGL(vnn_inv_hist_kernel, dim3((unsigned)IB), dim3(256), 0, s, pl.idxp, NK, M, pl.ihist);
     GPZ_LAUNCH_OK();
-    hipLaunchKernelGGL(vnn_inv_scan_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, pl.ihist, IB, M, pl.itmp);
+    hipLaunchKernelGGL(vnn_inv_scan_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, pl.ihist, IB, M, pl.itmp);
     GPZ_LAUNCH_OK();
     hipLaunchKernelGGL(vnn_inv_start_kernel, dim3(1), dim3(256), 0, s, pl.itmp, pl.istart, M);
     GPZ_LAUNCH_OK();
-    hipLaunchKernelGGL(vnn_inv_fill_kernel, dim3((unsigned)IB), dim3(256), 0, s, b.f.idx, NK, M, pl.ihist, pl.istart, pl.inv);
+    hipLaunchKernelGGL(vnn_inv_fill_kernel, dim3((unsigned)IB), dim3(256), 0, s, pl.idxp, NK, M, pl.ihist, pl.istart, pl.inv, K);
     GPZ_LAUNCH_OK();
     b.inv = pl.inv; b.start = pl.istart; b.dup = nullptr;
     if (idx_in) {                    // a caller's table may repeat a neighbour; the lists of gpz_knn cannot
@@ -1056,21 +1193,22 @@ static int vnngp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, 
       GPZ_LAUNCH_OK();
       b.dup = pl.idup;
     }
-    const size_t lds = 2 * Mp * sizeof(double);
-    if (lds > 64 * 1024) {
-      static bool set[64] = {};
-      int dev = 0;
-      GPZ_HIP_OK(hipGetDevice(&dev));
-      if (!set[dev & 63]) {
-        GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(vnngp_gather_kernel<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        set[dev & 63] = true;
-      }
-    }
-    hipLaunchKernelGGL((vnngp_gather_kernel<T>), dim3((unsigned)M, L32), dim3(64), lds, s, b);
-    GPZ_LAUNCH_OK();
+    const size_t lds = (kgrads ? 2 : 1) * Mp * sizeof(double);      // row of T_S (and of T_K) of the inducing point
+    const bool wide_rec = 3 * K + 2 > 64;
+    auto launch = [&](auto kern) -> int {
+      if (lds > 64 * 1024) GPZ_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      hipLaunchKernelGGL(kern, dim3((unsigned)M, L32), dim3(64), lds, s, b);
+      GPZ_LAUNCH_OK();
+      return 0;
+    };
+    int rc = 0;
+    if (kgrads) rc = wide_rec ? launch(vnngp_gather_kernel<T, true, true>) : launch(vnngp_gather_kernel<T, false, true>);
+    else rc = wide_rec ? launch(vnngp_gather_kernel<T, true, false>) : launch(vnngp_gather_kernel<T, false, false>);
+    if (rc) return rc;
     if (kgrads) {
-      hipLaunchKernelGGL((vnn_theta_sum_kernel<T>), dim3(L32), dim3(256), 0, s, b);
+      hipLaunchKernelGGL((vnn_theta_part_kernel<T>), dim3(VNN_TS, L32), dim3(256), 0, s, b, pl.tpart);
+      GPZ_LAUNCH_OK();
+      hipLaunchKernelGGL((vnn_theta_sum_kernel<T>), dim3(L32), dim3(64), 0, s, b, (const double*)pl.tpart);
       GPZ_LAUNCH_OK();
     }
   }
@@ -1172,6 +1310,11 @@ static int vnn_check(const gpz_svgp_problem* p, int K) {
   GPZ_REQUIRE(p->k.n_latent >= 1 && p->N >= 1 && p->M >= 1 && p->d >= 1 && p->d <= 4, "gpz_vnngp: bad extents");
   GPZ_REQUIRE(K >= 1 && K <= KNN_MAX && K <= p->M, "gpz_vnngp: K=%d unsupported (1..min(%d, M))", K, KNN_MAX);
   return 0;
+}
+
+extern "C" size_t gpz_vnngp_state_bytes(const gpz_svgp_problem* p) {
+  if (!p || p->k.n_latent < 1 || p->M < 1) return 0;
+  return vnn_state(p, nullptr).bytes;
 }
 
 extern "C" size_t gpz_vnngp_workspace_bytes(const gpz_svgp_problem* p, int32_t K) {

@@ -329,6 +329,16 @@ class VNNGP(nn.Module):
         self.mu = nn.Parameter(torch.zeros((M,)))
         self.constraint = constraints.lower_cholesky
 
+    def _point_order(self, X):
+        """Morton order of the data points for the backward pass's records, kept while X is the same tensor (the notebooks
+        train on one X for thousands of steps)."""
+        key = (X.data_ptr(), X._version, tuple(X.shape), X.device)
+        c = self.__dict__.get("_order_cache")
+        if c is None or c[0] != key:
+            c = (key, ops.morton_order(X))
+            self.__dict__["_order_cache"] = c
+        return c[1]
+
     def forward(self, X, verbose=False):
         nlat = 1 if self.mu.dim() == 1 else int(self.mu.shape[0])
         spec = kernel_spec(self.kernel, X, nlat)
@@ -339,12 +349,25 @@ class VNNGP(nn.Module):
             out = ops.vnngp_forward(spec, X, self.Z, self.mu, self.Lu, jitter, K, self._clamp_min)
             mean, scale, Lu, chol, kl = out["mean"], out["scale"], out["Lu"], out["chol"], out["kl"].to(out["mean"].dtype)
         else:
+            # the closures hold private copies of Z and the kernel's tensors (as _FusedGP._forward does): the backward
+            # pass differentiates the problem this forward evaluated and may take its factor, S and KL operands over
+            spec = ops.freeze_spec(spec)
+            Zc = self.Z.detach().clone()
+            kept = {}
+
             def fwd(mu, Lu_raw):
-                return ops.vnngp_forward(spec, X, self.Z, mu, Lu_raw, jitter, K, self._clamp_min)
+                out = ops.vnngp_forward(spec, X, Zc, mu, Lu_raw, jitter, K, self._clamp_min, keep_state=True)
+                kept["state"] = out.pop("state")
+                kept["mu"], kept["Lu"] = mu._version, Lu_raw._version
+                return out
 
             def bwd(mu, Lu_raw, idx, g_mean, g_scale, need_kernel, g_chol, g_kl):
-                return ops.vnngp_backward(spec, X, self.Z, mu, Lu_raw, jitter, K, idx, g_mean, g_scale,
-                                          clamp_min=self._clamp_min, kernel_grads=need_kernel, g_chol=g_chol, g_kl=g_kl)
+                state = kept.pop("state", None)       # good for one backward pass, and only for the tensors it was made from
+                if (mu._version, Lu_raw._version) != (kept.get("mu"), kept.get("Lu")):
+                    state = None
+                return ops.vnngp_backward(spec, X, Zc, mu, Lu_raw, jitter, K, idx, g_mean, g_scale, clamp_min=self._clamp_min,
+                                          kernel_grads=need_kernel, g_chol=g_chol, g_kl=g_kl, state=state,
+                                          point_order=self._point_order(X))
 
             mean, scale, chol, kl = _VNNMoments.apply(*params, dict(forward=fwd, backward=bwd))
             # q(U)'s scale_tril through torch so that other uses of it differentiate w.r.t. the raw parameter

@@ -709,10 +709,27 @@ def knn(X, Z, K: int) -> torch.Tensor:
     return idx
 
 
+def morton_order(X: torch.Tensor) -> torch.Tensor:
+    """(N,) int64 permutation that sorts the rows of X (N,d), d <= 4, along a Z-order (Morton) curve, 16 bits per
+    coordinate, ties in index order: the ``point_order`` of ``vnngp_backward`` -- points that share their nearest
+    inducing points become neighbours in the pass's per-point records."""
+    Xd = X.detach().double()
+    lo = Xd.min(dim=0).values
+    span = (Xd.max(dim=0).values - lo).clamp_min(1e-300)
+    q = ((Xd - lo) / span * 65535.0).round().to(torch.int64)
+    d = X.shape[1]
+    key = torch.zeros(X.shape[0], dtype=torch.int64, device=X.device)
+    for bit in range(16):
+        for k in range(d):
+            key |= ((q[:, k] >> bit) & 1) << (bit * d + k)
+    return torch.argsort(key, stable=True)
+
+
 @_on_device
 def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, clamp_min: float = 5e-2,
-                  check_info: bool = True, idx=None) -> dict:
-    """VNNGP forward (gpz_vnngp_forward): mean, scale (L,N), Lu, chol (L,M,M), idx (N,K)."""
+                  check_info: bool = True, idx=None, keep_state: bool = False) -> dict:
+    """VNNGP forward (gpz_vnngp_forward): mean, scale (L,N), Lu, chol (L,M,M), idx (N,K).  ``keep_state``: also
+    "state", the buffer ``vnngp_backward(state=...)`` of the same call takes the factor, S and the KL operands from."""
     _need_cuda(X, Z, mu, Lu_raw)
     lib = _lib.load()
     keep: list = []
@@ -725,6 +742,9 @@ def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, cla
     out["kl"] = torch.empty(L, dtype=torch.float64, device=dev)      # KL(qU || pU) per latent
     p.kl = out["kl"].data_ptr()
     out["idx"] = knn(X, Z, K) if idx is None else idx
+    if keep_state:
+        out["state"] = torch.empty(lib.gpz_vnngp_state_bytes(C.byref(p)), dtype=torch.uint8, device=dev)
+        p.factor_cache, p.factor_cache_valid = out["state"].data_ptr(), 0
     nbytes = lib.gpz_vnngp_workspace_bytes(C.byref(p), K)
     if nbytes == 0:
         _lib.check(-1, "gpz_vnngp_workspace_bytes")
@@ -741,9 +761,12 @@ def vnngp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, cla
 
 @_on_device
 def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, idx, g_mean, g_scale, *,
-                   clamp_min: float = 5e-2, kernel_grads: bool = False, g_chol=None, g_kl=None):
+                   clamp_min: float = 5e-2, kernel_grads: bool = False, g_chol=None, g_kl=None, state=None,
+                   point_order=None):
     """dLoss/dmu (L,M), dLoss/dLu_raw (L,M,M) of VNNGP (gpz_vnngp_backward); with ``kernel_grads`` also
-    dLoss/d(sigma, lengthscale) (L,2) and dLoss/dZ (M,d), both fp64."""
+    dLoss/d(sigma, lengthscale) (L,2) and dLoss/dZ (M,d), both fp64.  ``state``: what ``vnngp_forward(keep_state=True)``
+    of the SAME inputs returned (consumed: good for one backward pass).  ``point_order`` (N,) int64: a permutation of
+    the points the pass lays its records out in (``morton_order(X)``: the gather then reads runs of neighbouring records)."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale, idx)
     lib = _lib.load()
     keep: list = []
@@ -770,6 +793,16 @@ def vnngp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, K: int, id
         keep.append(gk)
         g.g_kl = gk.data_ptr()
     idx = idx.contiguous()
+    if point_order is not None:
+        po = point_order.detach().to(device=dev, dtype=torch.int64).contiguous()
+        if po.numel() != N:
+            raise ValueError(f"point_order has {po.numel()} entries for {N} points")
+        keep.append(po)
+        g.point_order = po.data_ptr()
+    if state is not None:
+        if state.numel() != lib.gpz_vnngp_state_bytes(C.byref(p)):
+            raise ValueError("state does not belong to this problem")
+        p.factor_cache, p.factor_cache_valid = state.data_ptr(), 5
     nbytes = lib.gpz_vnngp_backward_workspace_bytes(C.byref(p), K)
     if nbytes == 0:
         _lib.check(-1, "gpz_vnngp_backward_workspace_bytes")

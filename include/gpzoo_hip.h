@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPZ_VERSION 211
+#define GPZ_VERSION 212
 
 enum { GPZ_F32 = 0, GPZ_F64 = 1 };
 
@@ -228,6 +228,11 @@ typedef struct gpz_svgp_grads {
    * the factor's gradient, at no extra matrix product: dKL/dLuE = LuE, dKL/dmuE = muE, plus the
    * log-determinant diagonals (whitened: LuE = Lu, muE = mu, the whitened_KL of utilities.py:27-36). */
   const double* g_kl;
+  /* gpz_vnngp_backward only: (N,) int64 permutation of the points, or NULL (identity).  The pass lays its per-point
+   * records out in this order; along a space-filling curve the points that share an inducing point are neighbours in
+   * memory, which is what its fixed-order gather is bound by.  Any permutation gives the same sums up to the order of
+   * their terms (the order is fixed by the permutation: results stay bitwise reproducible). */
+  const int64_t* point_order;
 } gpz_svgp_grads;
 
 size_t gpz_svgp_backward_workspace_bytes(const gpz_svgp_problem* p, int64_t chunk);
@@ -260,6 +265,12 @@ int gpz_knn(const void* X, int64_t N, const void* Z, int64_t M, int32_t d, int32
  * writes mean, scale (L,N), optionally Lu and chol, and info.  idx: (N,K) neighbour lists from
  * gpz_knn, or NULL to compute them here. */
 size_t gpz_vnngp_workspace_bytes(const gpz_svgp_problem* p, int32_t K);
+/* Hand-off from gpz_vnngp_forward to the gpz_vnngp_backward of the same call: with `factor_cache` pointing at
+ * gpz_vnngp_state_bytes(p) bytes (caller owned) the forward leaves Kzz + jitter I, its factor, Lu, S = Lu Lu^T and -- when
+ * it evaluates `kl` -- L^{-1}, L^{-1} Lu, L^{-1} mu there; a backward pass given the same buffer with factor_cache_valid =
+ * 1 (factor, Lu, S) | 4 (the KL operands) reads them instead of forming them again.  The backward pass uses parts of the
+ * buffer as scratch: it is valid for ONE backward.  NULL: every pass forms what it needs in its workspace. */
+size_t gpz_vnngp_state_bytes(const gpz_svgp_problem* p);
 int gpz_vnngp_forward(const gpz_svgp_problem* p, int32_t K, const int64_t* idx, void* ws,
                       size_t ws_bytes, void* stream);
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_string():
     from gpzoo_amd import _lib
     lib = _lib.load()
-    assert lib.gpz_version() == 211          # 210: unknown gpz_svgp_problem.flags bits rejected, gpz_svgp_forward_path; 211: GPZ_SVGP_PANEL_PRODUCTS
+    assert lib.gpz_version() == 212          # 210: unknown gpz_svgp_problem.flags bits rejected, gpz_svgp_forward_path; 211: GPZ_SVGP_PANEL_PRODUCTS; 212: gpz_vnngp_state_bytes
     assert isinstance(lib.gpz_last_error(), bytes)
 
 
@@ -58,7 +58,7 @@ def test_struct_layout_matches_header():
     from gpzoo_amd import _lib
     assert ctypes.sizeof(_lib.KernelDesc) == 56
     assert ctypes.sizeof(_lib.SvgpProblem) == 56 + 16 + 16 + 8 * 6 + 16 + 16 + 8 * 8 + 16 + 16
-    assert ctypes.sizeof(_lib.SvgpGrads) == 72
+    assert ctypes.sizeof(_lib.SvgpGrads) == 80      # 212: + point_order
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -227,6 +227,48 @@ def test_caller_table_with_repeated_neighbours(dtype):
     close(res[3], Z.grad, "grad_Z")
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_backward_with_handed_over_state_and_point_order(dtype):
+    """(1) The forward's factor, S and KL operands handed to the backward pass of the same call (gpz_vnngp_state_bytes)
+    instead of being formed again: bitwise the same gradients.  (2) `point_order` -- the Morton order the module passes,
+    and an arbitrary permutation: the same sums in another fixed order (equal to rounding, and bitwise equal to themselves
+    from run to run)."""
+    from gpzoo_amd import _lib, ops
+    from gpzoo_amd.ops import KernelSpec
+    N, M, K, L = 4000, 200, 10, 3
+    g = torch.Generator().manual_seed(31)
+    X = ((torch.rand(N, 2, generator=g, dtype=dtype) - 0.5) * 60).cuda()
+    Z = ((torch.rand(M, 2, generator=g, dtype=dtype) - 0.5) * 60).cuda()
+    sig = (0.6 + 0.3 * torch.rand(L, generator=g, dtype=dtype)).cuda()
+    ell = (3.0 + 3 * torch.rand(L, generator=g, dtype=dtype)).cuda()
+    mu = torch.randn(L, M, generator=g, dtype=dtype).cuda()
+    Lu = (0.05 * torch.randn(L, M, M, generator=g, dtype=dtype) - 1.0 * torch.eye(M, dtype=dtype)).cuda()
+    a = torch.randn(L, N, generator=g, dtype=dtype).cuda()
+    b = torch.randn(L, N, generator=g, dtype=dtype).cuda()
+    gkl = torch.ones(L, dtype=torch.float64).cuda()
+    spec = KernelSpec(_lib.KERNEL_RBF, sig, ell, True)
+
+    def run(with_state, order):
+        out = ops.vnngp_forward(spec, X, Z, mu, Lu, 1e-2, K, keep_state=with_state)
+        return ops.vnngp_backward(spec, X, Z, mu, Lu, 1e-2, K, out["idx"], a, b, kernel_grads=True, g_kl=gkl,
+                                  state=out.get("state"), point_order=order)
+    base = run(False, None)
+    for x, y in zip(base, run(True, None)):
+        assert torch.equal(x, y)
+    mort = ops.morton_order(X)
+    assert torch.equal(torch.sort(mort).values, torch.arange(N, device="cuda"))
+    perm = torch.randperm(N, generator=g).cuda()
+    rt = 1e-10 if dtype == torch.float64 else 2e-4
+    for order in (mort, perm):
+        r1, r2 = run(True, order), run(True, order)
+        for x, y, z in zip(base, r1, r2):
+            assert torch.equal(y, z)
+            torch.testing.assert_close(y, x, rtol=rt, atol=rt * float(x.abs().max()))
+    # a Morton order keeps spatial neighbours close in the sequence: mean jump between consecutive points far below random
+    jump = lambda o: float((X[o][1:] - X[o][:-1]).norm(dim=1).mean())
+    assert jump(mort) < 0.2 * jump(perm)
+
+
 def test_vnngp_trains():
     """A few Adam steps on the Gaussian ELBO lower the loss (the notebooks' training loop shape)."""
     from torch import distributions
