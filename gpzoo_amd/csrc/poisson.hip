@@ -77,6 +77,16 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __bui
 //         a y tile through L2), wave gs every 4th 16-gene group of gene slice s for the 64 spots of the block.  Column sub-tile c of its 16 x 64 tile is the spots 4r + c, so a lane's four
 //         accumulator tiles hold four CONSECUTIVE spots of a gene row: y arrives as one 16-byte load per row (256
 //         contiguous bytes per gene row and wave).  Emits log-lik, dV and dexpF partial slabs (no atomics).
+// Factor counts of the form 16 j + 1 ... 16 j + 4 (KS = 4 j + 1 k-steps; the notebooks' NSF models run 20 factors) pad
+// their last 1 .. 4 factor rows to a whole 16-row MFMA tile in the gradient products -- 16 of 52 MFMAs per 16 x 64 tile, 12
+// of their 16 rows zeros.  Pass B forms those rows on the vector pipe instead (TAIL: 64 multiply-adds per lane and tile
+// as packed ones, partial sums combined across the lane groups once at the end): 0.478 -> 0.42 ms at D = 17 702, N_b = 7000,
+// E = 3.  The same in pass A was measured and NOT kept: that pass already issues 4.3 vector instructions per MFMA (log,
+// reciprocal and the Poisson terms per element), the extra ones cost more issue time than the 16 MFMAs they replace
+// (0.60 -> 0.86 ms with the operands single-buffered to make room for them, 0.72 ms for the single-buffering alone).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 template <int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void spot_mfma_kernel(PoissonArgs a, int GS) {
   constexpr int LT16 = (KS + 3) / 4;          // 16-row tiles of the factor axis
@@ -290,6 +300,8 @@ __global__ __launch_bounds__(256) void lgamma_sum_kernel(PoissonArgs a) {
 //         registers for the whole sweep.
 template <int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void gene_mfma_kernel(PoissonArgs a, int SN) {
+  constexpr bool TAIL = (KS % 4) == 1;                               // the last 1 .. 4 factors on the vector pipe (see pass A)
+  constexpr int LTM = TAIL ? KS / 4 : (KS + 3) / 4, LTA = LTM > 0 ? LTM : 1, L0 = 16 * LTM;
   constexpr int LT16 = (KS + 3) / 4, LP = 16 * LT16, PF = 68;      // factor rows staged (zero padded), row pitch
   extern __shared__ float smem_p[];
   // Samples go through LDS in groups of EG <= PEG: the spot tile's y stays in registers across the groups, so y is
@@ -315,9 +327,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     const int l = 4 * ks + q;
     wb[ks] = (dok && l < a.Lt) ? a.W[dcol * a.Lt + l] : 0.f;
   }
-  f32x4 dwt[LT16];
+  f32x4 dwt[LTA];
 #pragma unroll
-  for (int lt = 0; lt < LT16; ++lt) dwt[lt] = f32x4{0, 0, 0, 0};
+  for (int lt = 0; lt < LTA; ++lt) dwt[lt] = f32x4{0, 0, 0, 0};
+  f32x2 tw[4];                                  // TAIL: [factor L0 + t]: two partial sums over this lane's spots of gene r
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tw[t] = f32x2{0.f, 0.f};
   const int arow = 16 * (r >> 2) + (r & 3);     // A row r of sub-tile c is spot 16 (r >> 2) + 4c + (r & 3) of the tile
   // exp(F) and V tiles arrive by LDS-DMA (one 256-byte row of 64 spots per wave instruction, no registers), double
   // buffered: (tile, sample group) s + 1 travels while s is computed.  Reads past the end of a row's valid spots return
@@ -404,21 +419,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         // dW^T[factor][gene] += sum over the tile's spots: k-step (c, g) pairs G^T's register g of sub-tile c (spot
         // 16q + 4c + g) with A[row = factor 16 lt + r][k slot q] = expF[factor][that spot]
 #pragma unroll
-        for (int lt = 0; lt < LT16; ++lt)
+        for (int lt = 0; lt < LTM; ++lt)
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const f32x4 fa = *reinterpret_cast<const f32x4*>(fe + (16 * lt + r) * PF + 16 * q + 4 * c);
 #pragma unroll
             for (int g = 0; g < 4; ++g) dwt[lt] = mfma4(fa[g], z[c][g], dwt[lt]);
           }
+        if constexpr (TAIL) {
+          // the last four factors: G^T's registers (spots 16q + 4c + g of gene r) times exp(F)[L0 + t][those spots]
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x4 fv = *reinterpret_cast<const f32x4*>(fe + (L0 + t) * PF + 16 * q + 4 * c);
+              tw[t] = pkfma(f32x2{z[c][0], z[c][1]}, f32x2{fv[0], fv[1]}, tw[t]);
+              tw[t] = pkfma(f32x2{z[c][2], z[c][3]}, f32x2{fv[2], fv[3]}, tw[t]);
+            }
+        }
       }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) yv[c] = yn[c];
   }
+  if constexpr (TAIL) {       // factor L0 + t of gene r: sum the spot groups (lanes r, r + 16, ...), lanes q == 0 write
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = (tw[t][0] + tw[t][1]) * inv_e;
+      v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      if (q == 0 && dok && L0 + t < a.Lt) a.dW_slab[((int64_t)blockIdx.y * a.D + dcol) * a.Lt + L0 + t] = v;
+    }
+  }
   if (dok) {
 #pragma unroll
-    for (int lt = 0; lt < LT16; ++lt)
+    for (int lt = 0; lt < LTM; ++lt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int l = 16 * lt + 4 * q + g;
