@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("GPZ_HIP_LIB") or os.path.join(HERE, "libgpzoo_hip.so"
 GPZ_F32, GPZ_F64 = 0, 1
 KERNEL_RBF, KERNEL_MATERN32, KERNEL_MGGP_RBF, KERNEL_DISTANCE = 0, 1, 2, 3
 SVGP_MATERIALIZE_KZX, SVGP_NARROW_TILES, SVGP_GENERATE_KZX, SVGP_PANEL_PRODUCTS = 1, 2, 4, 8      # gpz_svgp_problem.flags (include/gpzoo_hip.h)
+SVGP_BACKWARD_ALGEBRA, SVGP_BACKWARD_CLASSIC = 16, 32
 PROF_SLOTS = ("kfill", "stage1", "stage2", "potrf_trailing", "potrf_all", "trtri", "finalize", "_unused")
 
 

@@ -926,8 +926,8 @@ __global__ __launch_bounds__(256) void tril_transpose_kernel(const double* __res
 }
 
 // Lbar = -tril(GL) (+ tril(upstream dLoss/dchol)) in fp64
-template <typename T>
-__global__ void lbar_kernel(const double* __restrict__ GL, int64_t Mp, int64_t M, const T* __restrict__ g_chol,
+template <typename T, typename TG>
+__global__ void lbar_kernel(const TG* __restrict__ GL, int64_t Mp, int64_t M, const T* __restrict__ g_chol,
                             const double* __restrict__ E, double* __restrict__ Lbar,
                             const double* __restrict__ g_kl = nullptr, const double* __restrict__ Lc = nullptr) {
   const int l = blockIdx.z;
@@ -935,7 +935,7 @@ __global__ void lbar_kernel(const double* __restrict__ GL, int64_t Mp, int64_t M
   if (j >= Mp) return;
   double v = 0.0;
   if (j <= i) {
-    v = -GL[(int64_t)l * Mp * Mp + i * Mp + j];
+    v = -(double)GL[(int64_t)l * Mp * Mp + i * Mp + j];
     if (E) v -= E[(int64_t)l * Mp * Mp + i * Mp + j];
     if (g_chol && i < M) v += (double)g_chol[(int64_t)l * M * M + i * M + j];
     if (g_kl && i == j && i < M) v += g_kl[l] / Lc[(int64_t)l * Mp * Mp + i * Mp + i];   // d(sum log diag L)/dL
@@ -1172,7 +1172,7 @@ struct BwdBuffers {
   float* nt_vpart;                           // fp32: per-piece W gm from the same launch
   T* gmc;                                    // (L, nc) dLoss/dmean of the chunk, zero padded
   // kernel / Z gradients only
-  T *LuN, *Hd, *csc, *csd, *PS, *A1, *a3; double *D1, *D2, *D3, *D4, *D5, *me, *kacc, *sig_direct;
+  T *LuN, *Hd, *GL, *SwI, *csc, *csd, *PS, *A1, *a3; double *D1, *D2, *D3, *D4, *me, *kacc, *sig_direct;
   int32_t* any_d;                            // per chunk: does it hold a column at the whitened clamp (weights of Hd)?
   size_t bytes;
 };
@@ -1198,13 +1198,15 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* w
   const bool ntw = sizeof(T) == 4 && wide_nt_supported(pl.Mp, pl.nc);
   b.nt_vpart = ntw ? c.take<float>((int64_t)wide_nt_vpart_floats(pl.Mp, pl.nc, (int)pl.L)) : nullptr;
   b.gmc = c.take<T>(pl.L * pl.nc);
-  b.LuN = b.Hd = b.csc = b.csd = b.PS = b.A1 = b.a3 = nullptr;
-  b.D1 = b.D2 = b.D3 = b.D4 = b.D5 = b.me = b.kacc = b.sig_direct = nullptr;
+  b.LuN = b.Hd = b.GL = b.SwI = b.csc = b.csd = b.PS = b.A1 = b.a3 = nullptr;
+  b.D1 = b.D2 = b.D3 = b.D4 = b.me = b.kacc = b.sig_direct = nullptr;
   b.any_d = nullptr;
   if (full) {
     b.LuN = c.take<T>(mm);
     b.Hd = whitened ? c.take<T>(mm) : nullptr;
     b.PS = c.take<T>(mm);
+    b.GL = c.take<T>(mm);
+    b.SwI = c.take<T>(mm);
     b.A1 = c.take<T>(mm);
     b.a3 = c.take<T>(pl.L * pl.Mp);
     b.csc = c.take<T>(pl.L * pl.nc);
@@ -1212,8 +1214,7 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* w
     b.D1 = c.take<double>(mm);
     b.D2 = c.take<double>(mm);
     b.D3 = c.take<double>(mm);
-    b.D4 = c.take<double>(mm);
-    b.D5 = c.take<double>(mm);
+    b.D4 = whitened ? nullptr : c.take<double>(mm);
     b.me = c.take<double>(pl.L * pl.Mp);
     b.kacc = c.take<double>(pl.L * pl.Mp * 8);
     b.sig_direct = c.take<double>(pl.L);
@@ -1221,6 +1222,44 @@ static BwdBuffers<T> carve_bwd(const Plan& pl, bool whitened, bool full, void* w
   }
   b.bytes = c.used();
   return b;
+}
+
+// T-precision helpers of the M x M tail
+// R[i][j] += Hd[i][j] + u[i] v[j]   (lower triangle incl. the diagonal tiles; Hd may be null)
+template <typename TR, typename T>
+__global__ __launch_bounds__(256) void q_finish_kernel(TR* __restrict__ R, const T* __restrict__ Hd, int64_t Mp, int64_t M,
+                                                      const double* __restrict__ u, const double* __restrict__ v) {
+  const int l = blockIdx.z;
+  const int64_t i = blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp || (j >> 7) > (i >> 7)) return;
+  const int64_t o = (int64_t)l * Mp * Mp + i * Mp + j;
+  double r = (double)R[o];
+  if (Hd) r += (double)Hd[o];
+  if (i < M && j < M) r += u[(int64_t)l * Mp + i] * v[(int64_t)l * Mp + j];
+  R[o] = (TR)r;
+}
+template <typename T>
+__global__ void minus_identity_t_kernel(T* __restrict__ A, int64_t Mp) {
+  const int l = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < Mp) A[(int64_t)l * Mp * Mp + i * (Mp + 1)] -= (T)1;
+}
+
+// Which form the N-sized work takes (see the comment at the head of this section).  The algebra form trades N-sized
+// products for M x M ones: per pass, in units of L M^2 N and of 2 L M^3 flop,
+//   mu / Lu only      classic 2 (Pbar, W Pbar^T)            algebra 1 (H) + 1/3 (H LuE)                 -> algebra iff N >= 0.75 M
+//   all parameters    classic 5 (+ Wbar, Kbar_x, Kbar_x W^T) algebra 3 (H, dense Kbar_x) + 2 (Sw, A1, Q, GL, H LuE) -> iff N >= 2.2 M
+//                     (un-whitened fp32 models run those four M x M products in fp64 -- their sigma / lengthscale gradients
+//                     are sums with heavy cancellation through Linv: 5e-4 of the fp64 value in fp32 against 1e-4 for the
+//                     classic form, measured at N = 3000, M = 1024 -- at half the rate: iff N >= 4.4 M)
+// (the notebooks' benchmark model trains Z and the lengthscale on N = 1037 spots with M up to 1000 inducing points:
+// classic; the Slide-seq minibatches, N_b = 7000, M = 3000, frozen hyper-parameters: algebra).
+static bool backward_algebra(int64_t N, int64_t Mp, bool full, int flags, bool f64_algebra) {
+  static const int env = [] { const char* e = getenv("GPZ_SVGP_BACKWARD"); return !e ? 0 : !strcmp(e, "algebra") ? 1 : !strcmp(e, "classic") ? 2 : 0; }();
+  if (flags & GPZ_SVGP_BACKWARD_ALGEBRA) return true;
+  if (flags & GPZ_SVGP_BACKWARD_CLASSIC) return false;
+  if (env) return env == 1;
+  return full ? 10 * N >= (f64_algebra ? 44 : 22) * Mp : 4 * N >= 3 * Mp;
 }
 
 template <typename T>
@@ -1234,19 +1273,22 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   GPZ_REQUIRE(ws_bytes >= w.bytes, "gpz_svgp_backward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
   const int64_t L = pl.L, M = pl.M, Mp = pl.Mp, N = pl.N, mm = Mp * Mp;
   const int L32 = (int)L;
+  const bool alg64 = sizeof(T) == 4 && !wh;            // fp32, un-whitened: the M x M products of the algebra form in fp64
+  const bool alg = backward_algebra(N, Mp, full, p->flags, alg64);
   gpz_svgp_problem q = *p;          // forward-only outputs are not produced again
   q.chol = nullptr; q.Lu = nullptr;
   if (int rc = prepare_t<T>(&q, pl, b, s)) return rc;
   {
     Zeroer z;
-    z.add(w.H, sizeof(T) * L * mm);
+    if (alg) z.add(w.H, sizeof(T) * L * mm);
     z.add(w.G, sizeof(T) * L * mm);          // (its tiles above the diagonal are never written)
     if (!wh) z.add(w.G2, sizeof(T) * L * mm);
     if (full) {
-      if (wh) {
+      if (alg && wh) {
         z.add(w.Hd, sizeof(T) * L * mm);
         z.add(w.any_d, sizeof(int32_t) * (pl.nchunks + 1));
       }
+      if (!alg) z.add(w.GL, sizeof(T) * L * mm);
       z.add(w.kacc, sizeof(double) * L * Mp * 8);
       z.add(w.sig_direct, sizeof(double) * L);
     }
@@ -1254,6 +1296,12 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
   }
   const dim3 g32((unsigned)(Mp / 32), (unsigned)(Mp / 32), L32);
   const dim3 gm((unsigned)((Mp + 255) / 256), (unsigned)Mp, L32);
+  auto tgemm = [&](const T* A, const T* B, T* C, int flags) -> int {
+    GemmParams<T> d;
+    d.A = A; d.lda = Mp; d.sA0 = mm; d.B = B; d.ldb = Mp; d.sB0 = mm; d.C = C; d.ldc = Mp; d.sC0 = mm;
+    d.nb0 = L32; d.mt = d.nt = (int)pl.nblk; d.K = (int)Mp; d.flags = flags;
+    return gemm_launch(d, EPI_STORE, s);
+  };
   if (full) {
     // Lu (lower, not transposed) in GEMM precision and Linv^T
     if (wh) {
@@ -1265,38 +1313,49 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     GPZ_LAUNCH_OK();
     hipLaunchKernelGGL((transpose_cast_kernel<T>), g32, dim3(256), 0, s, b.Linv, Mp, w.LinvT, (double*)w.D1);
     GPZ_LAUNCH_OK();
-    // What Kbar_x = Linv^T Wbar needs once per pass.  Wbar = LuE Pbar - W diag(gv2 c) + muE gm^T with Pbar = LuE^T W diag(gv2)
-    // is (Sw - I) W D + W (D - Dc) + muE gm^T (Sw = LuE LuE^T, D = diag(gv2), Dc = diag(gv2 c)), so
-    //   Kbar_x = [A1 W] D + [Linv^T W] (D - Dc) + a3 gm^T,   A1 = Linv^T (Sw - I) (dense M x M),  a3 = Linv^T muE:
-    // ONE dense product per chunk (2 L M^2 N flop) where rounds 1-4 ran three triangular ones (Pbar, Wbar, Kbar_x: 3 L M^2 N);
-    // D - Dc is zero except on columns at the whitened clamp, whose term runs only in chunks that hold one.
-    const double* LuE64 = b.LuW;
-    if (wh) {
-      hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.LuN, w.D4, L * mm, 0);
-      GPZ_LAUNCH_OK();
-      LuE64 = w.D4;
+    // muE in fp64 (whitened: mu itself): the rank-1 terms of Kbar_x / Q and, un-whitened, of E below
+    if (wh)
       hipLaunchKernelGGL((mu_widen_kernel<T>), dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s,
                          static_cast<const T*>(p->mu), M, Mp, w.me);
-    } else {
+    else
       hipLaunchKernelGGL((linv_mu_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, b.Linv,
                          static_cast<const T*>(p->mu), Mp, M, w.me);
-    }
     GPZ_LAUNCH_OK();
-    {
-      GemmParams<double> d;
-      auto dg = [&](const double* A, const double* B, double* C, int flags) -> int {
-        d.A = A; d.lda = Mp; d.sA0 = mm; d.B = B; d.ldb = Mp; d.sB0 = mm; d.C = C; d.ldc = Mp; d.sC0 = mm;
-        d.nb0 = L32; d.mt = d.nt = (int)pl.nblk; d.K = (int)Mp; d.flags = flags;
-        return gemm_launch(d, EPI_STORE, s);
-      };
-      if (int rc = dg(LuE64, LuE64, w.D2, GF_A_LOWER | GF_B_UPPER | GF_B_TRANS)) return rc;            // D2 = Sw
-      hipLaunchKernelGGL(minus_identity_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.D2, Mp);   // D2 = Sw - I (kept for Q below)
-      GPZ_LAUNCH_OK();
-      hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Linv, Mp, w.D1);                 // D1 = Linv^T
-      GPZ_LAUNCH_OK();
-      if (int rc = dg(w.D1, w.D2, w.D3, GF_A_UPPER)) return rc;                                          // D3 = A1
-      hipLaunchKernelGGL((cast_kernel<T>), dim3(2048), dim3(256), 0, s, w.D3, w.A1, L * mm);
-      GPZ_LAUNCH_OK();
+    if (alg) {
+      // What Kbar_x = Linv^T Wbar needs once per pass.  Wbar = LuE Pbar - W diag(gv2 c) + muE gm^T with Pbar = LuE^T W diag(gv2)
+      // is (Sw - I) W D + W (D - Dc) + muE gm^T (Sw = LuE LuE^T, D = diag(gv2), Dc = diag(gv2 c)), so
+      //   Kbar_x = [A1 W] D + [Linv^T W] (D - Dc) + a3 gm^T,   A1 = Linv^T (Sw - I) (dense M x M),  a3 = Linv^T muE:
+      // ONE dense product per chunk (2 L M^2 N flop) where the classic form runs three triangular ones (Pbar, Wbar, Kbar_x);
+      // D - Dc is zero except on columns at the whitened clamp, whose term runs only in chunks that hold one.  The M x M
+      // products run in the problem's precision (the classic form accumulates the same quantities in it).
+      if (alg64) {
+        // Sw - I (kept in D2 for Q) and A1 in fp64, then cast
+        GemmParams<double> d;
+        auto dg = [&](const double* A, const double* B, double* C, int flags) -> int {
+          d.A = A; d.lda = Mp; d.sA0 = mm; d.B = B; d.ldb = Mp; d.sB0 = mm; d.C = C; d.ldc = Mp; d.sC0 = mm;
+          d.nb0 = L32; d.mt = d.nt = (int)pl.nblk; d.K = (int)Mp; d.flags = flags;
+          return gemm_launch(d, EPI_STORE, s);
+        };
+        const double* LuE64 = b.LuW;
+        if (wh) {
+          hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.LuN, w.D3, L * mm, 0);
+          GPZ_LAUNCH_OK();
+          LuE64 = w.D3;
+        }
+        if (int rc = dg(LuE64, LuE64, w.D2, GF_A_LOWER | GF_B_UPPER | GF_B_TRANS)) return rc;
+        hipLaunchKernelGGL(minus_identity_kernel, dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.D2, Mp);
+        GPZ_LAUNCH_OK();
+        hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Linv, Mp, w.D1);
+        GPZ_LAUNCH_OK();
+        if (int rc = dg(w.D1, w.D2, w.D3, GF_A_UPPER)) return rc;
+        hipLaunchKernelGGL((cast_kernel<T>), dim3(2048), dim3(256), 0, s, w.D3, w.A1, L * mm);
+        GPZ_LAUNCH_OK();
+      } else {
+      if (int rc = tgemm(w.LuN, w.LuN, w.SwI, GF_A_LOWER | GF_B_UPPER | GF_B_TRANS)) return rc;            // Sw
+      hipLaunchKernelGGL((minus_identity_t_kernel<T>), dim3((unsigned)((Mp + 255) / 256), L32), dim3(256), 0, s, w.SwI, Mp);
+      GPZ_LAUNCH_OK();                                                                                     // Sw - I (kept for Q)
+      if (int rc = tgemm(w.LinvT, w.SwI, w.A1, GF_A_UPPER)) return rc;                                     // A1
+      }
       hipLaunchKernelGGL((linvT_vec_kernel<T>), dim3((unsigned)(Mp / 32), L32), dim3(256), 0, s, w.me, b.Linv, Mp, M, w.a3);
       GPZ_LAUNCH_OK();
     }
@@ -1342,37 +1401,69 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
         if (int rc = gemm_launch(g1, full ? EPI_STORE_STATS : EPI_STORE, s)) return rc;
       }
     }
-    const bool with_hd = full && wh;     // columns at the whitened clamp: their weights gv2 (1 - c) and the chunk's flag
+    const bool with_hd = alg && full && wh;   // columns at the whitened clamp: their weights gv2 (1 - c) and the chunk's flag
     hipLaunchKernelGGL((colscale_kernel<T>), dim3((unsigned)((ncp + 255) / 256), L32), dim3(256), 0, s,
                        static_cast<const T*>(g->g_scale), static_cast<const T*>(g->scale), N, n0, ncp, (int)wh,
                        p->var_clamp_min, w.cs, static_cast<const T*>(g->g_mean), (const T*)ps1, (int)pl.nblk,
                        static_cast<const T*>(p->k.sigma), w.csc, w.gmc, with_hd ? w.csd : (T*)nullptr,
                        with_hd ? w.any_d + ci : (int32_t*)nullptr);
     GPZ_LAUNCH_OK();
-    // C += W diag(wts) W^T (lower tiles): the wide kernel weights its B fragments itself; the 128 x 128-tile kernel
-    // gets a weighted copy of W (in the Pbar buffer, free at this point)
     const bool wide_nt = sizeof(T) == 4 && wide && wide_nt_supported(Mp, ncp);
-    auto syrk = [&](const T* wts, T* C, const int32_t* gate) -> int {
-      if (wide_nt) {          // (the main accumulation also forms v = W gm of the chunk, from its diagonal tiles)
-        if constexpr (sizeof(T) == 4)
-          return wide_nt_launch(Wc, Wc, C, Mp, ncp, L32, s, w.nt_part, wts, gate, gate ? nullptr : w.gmc,
-                                gate ? nullptr : w.nt_vpart, gate ? nullptr : w.mu_part + ci * Mp, pl.nchunks * Mp);
-      }
-      hipLaunchKernelGGL((scale_cols_kernel<T>), dim3((unsigned)((ncp + 255) / 256), (unsigned)Mp, L32), dim3(256), 0, s,
-                         (const T*)Wc, wts, Mp, ncp, w.Pc);
-      GPZ_LAUNCH_OK();
+    // C += A B^T over the chunk (lower tiles) on the 128 x 128-tile kernel
+    auto nt_generic = [&](const T* A, const T* B, T* C) -> int {
       GemmParams<T> g3;
-      g3.A = w.Pc; g3.lda = ncp; g3.sA0 = Mp * ncp;
-      g3.B = Wc; g3.ldb = ncp; g3.sB0 = Mp * ncp;
+      g3.A = A; g3.lda = ncp; g3.sA0 = Mp * ncp;
+      g3.B = B; g3.ldb = ncp; g3.sB0 = Mp * ncp;
       g3.C = C; g3.ldc = Mp; g3.sC0 = mm;
       g3.nb0 = L32; g3.mt = g3.nt = (int)pl.nblk; g3.K = (int)ncp; g3.flags = GF_B_TRANS | GF_TILES_LOWER;
       g3.alpha = 1; g3.beta = 1;
       return gemm_launch(g3, EPI_STORE, s);
     };
-    if (int rc = syrk(w.cs, w.H, nullptr)) return rc;                      // H  += W diag(gv2) W^T
-    if (with_hd)
-      if (int rc = syrk(w.csd, w.Hd, w.any_d + ci)) return rc;             // Hd += W diag(gv2 (1 - c)) W^T, if any
-    if (!wide_nt) {
+    bool v_done = false;             // dLoss/dmuE's chunk share W gm formed by the accumulation launch itself
+    if (alg) {
+      // C += W diag(wts) W^T (lower tiles): the wide kernel weights its B fragments itself (and its diagonal tiles form
+      // v = W gm); the 128 x 128-tile kernel gets a weighted copy of W (in the Pbar buffer, free at this point)
+      auto syrk = [&](const T* wts, T* C, const int32_t* gate) -> int {
+        if (wide_nt) {
+          if constexpr (sizeof(T) == 4)
+            return wide_nt_launch(Wc, Wc, C, Mp, ncp, L32, s, w.nt_part, wts, gate, gate ? nullptr : w.gmc,
+                                  gate ? nullptr : w.nt_vpart, gate ? nullptr : w.mu_part + ci * Mp, pl.nchunks * Mp);
+        }
+        hipLaunchKernelGGL((scale_cols_kernel<T>), dim3((unsigned)((ncp + 255) / 256), (unsigned)Mp, L32), dim3(256), 0, s,
+                           (const T*)Wc, wts, Mp, ncp, w.Pc);
+        GPZ_LAUNCH_OK();
+        return nt_generic(w.Pc, Wc, C);
+      };
+      if (int rc = syrk(w.cs, w.H, nullptr)) return rc;                      // H  += W diag(gv2) W^T
+      if (with_hd)
+        if (int rc = syrk(w.csd, w.Hd, w.any_d + ci)) return rc;             // Hd += W diag(gv2 (1 - c)) W^T, if any
+      v_done = wide_nt;
+    } else {
+      // classic form: Pbar = (LuE^T W) diag(gv2), then G += W Pbar^T
+      bool done = false;
+      if constexpr (sizeof(T) == 4) {
+        if (wide) {
+          WideArgs wa = {};
+          wa.A = b.LuT; wa.B = Wc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 1; wa.epilogue = WIDE_STORE_COLSCALE;
+          wa.C = w.Pc; wa.colscale = w.cs;
+          if (int rc = wide_product_launch(wa, s)) return rc;
+          done = true;
+        }
+      }
+      if (!done) {
+        GemmParams<T> g2;
+        g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+        g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+        g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
+        g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+        g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
+        if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
+      }
+      if (wide_nt) {
+        if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(Wc, w.Pc, w.G, Mp, ncp, L32, s, w.nt_part)) return rc; }
+      } else if (int rc = nt_generic(Wc, w.Pc, w.G)) return rc;
+    }
+    if (!v_done) {
       hipLaunchKernelGGL((rowdot_kernel<T>), dim3((unsigned)(Mp / 4), L32), dim3(256), 0, s, Wc, Mp, ncp,
                          static_cast<const T*>(g->g_mean), N, n0, w.mu_part, pl.nchunks, ci);
       GPZ_LAUNCH_OK();
@@ -1380,12 +1471,12 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     if (full) {
       bool done = false;
       if constexpr (sizeof(T) == 4) {
-        if (wide) {      // Kbar_x = [A1 W] diag(gv2) + a3 gm^T in one dense product       (into the Pbar buffer)
+        if (wide && alg) {   // Kbar_x = [A1 W] diag(gv2) + a3 gm^T in one dense product       (into the Pbar buffer)
           WideArgs wk = {};
           wk.A = w.A1; wk.B = Wc; wk.Mp = Mp; wk.ncp = ncp; wk.L = L32; wk.upper = 2; wk.epilogue = WIDE_KBAR;
           wk.C = w.Pc; wk.colscale = w.cs; wk.colvec = w.gmc; wk.rowvec = w.a3;
           if (int rc = wide_product_launch(wk, s)) return rc;
-          if (with_hd) { // ... += [Linv^T W] diag(gv2 (1 - c)): only in a chunk with a column at the whitened clamp
+          if (with_hd) {     // ... += [Linv^T W] diag(gv2 (1 - c)): only in a chunk with a column at the whitened clamp
             WideArgs wc = {};
             wc.A = w.LinvT; wc.B = Wc; wc.Mp = Mp; wc.ncp = ncp; wc.L = L32; wc.upper = 1; wc.epilogue = WIDE_ADD_COLSCALE;
             wc.C = w.Pc; wc.colscale = w.csd; wc.gate = w.any_d + ci;
@@ -1393,15 +1484,28 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
           }
           done = true;
         }
+        if (wide && !alg) {  // Wbar = Lu Pbar - W diag(gv2 c) + mu gm^T (into the Kzx buffer), Kbar_x = Linv^T Wbar (Pbar buffer)
+          WideArgs wa = {};
+          wa.A = w.LuN; wa.B = w.Pc; wa.Mp = Mp; wa.ncp = ncp; wa.L = L32; wa.upper = 0; wa.epilogue = WIDE_WBAR;
+          wa.C = b.Kc; wa.colscale = w.csc; wa.colvec = w.gmc; wa.rowvec = b.muE; wa.aux = Wc;
+          if (int rc = wide_product_launch(wa, s)) return rc;
+          WideArgs wb = {};
+          wb.A = w.LinvT; wb.B = b.Kc; wb.Mp = Mp; wb.ncp = ncp; wb.L = L32; wb.upper = 1; wb.epilogue = WIDE_STORE;
+          wb.C = w.Pc;
+          if (int rc = wide_product_launch(wb, s)) return rc;
+          done = true;
+        }
       }
-      if (!done) {       // the 128 x 128-tile kernels: Pbar, Wbar, Kbar_x as three triangular products
-        GemmParams<T> g2;  // Pbar = (LuE^T W) diag(gv2)
-        g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
-        g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
-        g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
-        g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
-        g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
-        if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
+      if (!done) {       // the 128 x 128-tile kernels: (Pbar), Wbar, Kbar_x as triangular products
+        if (alg) {       // (the algebra form has no Pbar yet)
+          GemmParams<T> g2;
+          g2.A = b.LuT; g2.lda = Mp; g2.sA0 = mm;
+          g2.B = Wc; g2.ldb = ncp; g2.sB0 = Mp * ncp;
+          g2.C = w.Pc; g2.ldc = ncp; g2.sC0 = Mp * ncp;
+          g2.nb0 = L32; g2.mt = (int)pl.nblk; g2.nt = nt; g2.K = (int)Mp; g2.flags = GF_A_UPPER | GF_GROUP_COLS;
+          g2.super_cols = sched_plain.cols; g2.colscale = w.cs; g2.sCs = ncp; g2.ncols = ncp;
+          if (int rc = gemm_launch(g2, EPI_STORE_COLSCALE, s)) return rc;
+        }
         GemmParams<T> g4;  // Wbar = Lu Pbar - W diag(gv2 c) + mu gm^T            (into the Kzx buffer, no longer needed)
         g4.A = w.LuN; g4.lda = Mp; g4.sA0 = mm;
         g4.B = w.Pc; g4.ldb = ncp; g4.sB0 = Mp * ncp;
@@ -1418,8 +1522,12 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
         g5.super_cols = sched_plain.cols;
         if (int rc = gemm_launch(g5, EPI_STORE, s)) return rc;
       }
-      // kernel hyper-parameter and Z gradients from Kbar_x  (dLoss/dL needs no accumulation over the chunk: GL = Linv^T Q
-      // is M x M algebra on H, below)
+      if (!alg) {        // classic form: GL += Kbar_x W^T (lower tiles); the algebra form gets GL from H below
+        if (wide_nt) {
+          if constexpr (sizeof(T) == 4) { if (int rc = wide_nt_launch(w.Pc, Wc, w.GL, Mp, ncp, L32, s, w.nt_part)) return rc; }
+        } else if (int rc = nt_generic(w.Pc, Wc, w.GL)) return rc;
+      }
+      // kernel hyper-parameter and Z gradients from Kbar_x
       KgradArgs ka;
       ka.Kbar = w.Pc; ka.ld = ncp; ka.stride = Mp * ncp; ka.Z = p->Z; ka.X = Xc;
       ka.gZ = p->gZ; ka.gX = p->gX ? p->gX + n0 : nullptr;
@@ -1441,34 +1549,32 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
     d.nb0 = L32; d.mt = d.nt = (int)pl.nblk; d.K = (int)Mp; d.flags = flags;
     return gemm_launch(d, EPI_STORE, s);
   };
-  // dLoss/dLuE = tril(H LuE): H made symmetric, then one M x M product (LuT = LuE^T is the forward's stage-2 operand)
-  hipLaunchKernelGGL((mirror_lower_kernel<T>), g32, dim3(256), 0, s, w.H, Mp);
-  GPZ_LAUNCH_OK();
-  {
-    GemmParams<T> gh;
-    gh.A = w.H; gh.lda = Mp; gh.sA0 = mm;
-    gh.B = b.LuT; gh.ldb = Mp; gh.sB0 = mm;
-    gh.C = w.G; gh.ldc = Mp; gh.sC0 = mm;
-    gh.nb0 = L32; gh.mt = gh.nt = (int)pl.nblk; gh.K = (int)Mp; gh.flags = GF_B_TRANS | GF_B_LOWER | GF_TILES_LOWER;
-    if (int rc = gemm_launch(gh, EPI_STORE, s)) return rc;
-  }
-  if (full) {
-    // GL = sum_chunks Kbar_x W^T = Linv^T Q,  Q = (Sw - I) H + Hd + muE v^T   (fp64; v = W gm, before the KL is folded in)
-    hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.H, w.D1, L * mm, 0);      // D1 = H
+  if (alg) {
+    // dLoss/dLuE = tril(H LuE): H made symmetric, then one M x M product (LuT = LuE^T is the forward's stage-2 operand)
+    hipLaunchKernelGGL((mirror_lower_kernel<T>), g32, dim3(256), 0, s, w.H, Mp);
     GPZ_LAUNCH_OK();
-    if (int rc = dgemm(w.D2, w.D1, w.D3, 0)) return rc;                                                      // D3 = (Sw - I) H  (D2: before the chunks)
-    if (wh) {
-      hipLaunchKernelGGL((mirror_lower_kernel<T>), g32, dim3(256), 0, s, w.Hd, Mp);
-      GPZ_LAUNCH_OK();
-      hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.Hd, w.D3, L * mm, 1);   //    + Hd
-      GPZ_LAUNCH_OK();
+    if (int rc = tgemm(w.H, b.LuT, w.G, GF_B_TRANS | GF_B_LOWER | GF_TILES_LOWER)) return rc;
+    if (full) {
+      // GL = sum_chunks Kbar_x W^T = Linv^T Q,  Q = (Sw - I) H + Hd + muE v^T (v = W gm, before the KL is folded in).  dLoss/dL
+      // needs GL's lower triangle only, which needs Q's lower tiles only (Linv^T is upper triangular).
+      if (alg64) {
+        hipLaunchKernelGGL((widen_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)w.H, w.D1, L * mm, 0);
+        GPZ_LAUNCH_OK();
+        if (int rc = dgemm(w.D2, w.D1, w.D3, GF_TILES_LOWER)) return rc;                             // D3 = (Sw - I) H   (lower tiles)
+        hipLaunchKernelGGL((q_finish_kernel<double, T>), gm, dim3(256), 0, s, w.D3, (const T*)nullptr, Mp, M,
+                           (const double*)w.me, (const double*)w.mu_sum);                            //    + muE v^T
+        GPZ_LAUNCH_OK();
+        hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Linv, Mp, w.D1);
+        GPZ_LAUNCH_OK();
+        if (int rc = dgemm(w.D1, w.D3, w.D4, GF_A_UPPER | GF_TILES_LOWER)) return rc;                // D4 = GL (lower tiles)
+      } else {
+        if (int rc = tgemm(w.SwI, w.H, w.PS, GF_TILES_LOWER)) return rc;                             // PS = (Sw - I) H   (lower tiles)
+        hipLaunchKernelGGL((q_finish_kernel<T, T>), gm, dim3(256), 0, s, w.PS, wh ? (const T*)w.Hd : (const T*)nullptr, Mp, M,
+                           (const double*)w.me, (const double*)w.mu_sum);                            //    + Hd + muE v^T
+        GPZ_LAUNCH_OK();
+        if (int rc = tgemm(w.LinvT, w.PS, w.GL, GF_A_UPPER | GF_TILES_LOWER)) return rc;             // GL (lower tiles)
+      }
     }
-    hipLaunchKernelGGL(rank1_update_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)(M < 1024 ? M : 1024), L32),
-                       dim3(256), 0, s, w.D3, Mp, M, w.me, w.mu_sum);                                        //    + muE v^T
-    GPZ_LAUNCH_OK();
-    hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Linv, Mp, w.D1);                       // D1 = Linv^T
-    GPZ_LAUNCH_OK();
-    if (int rc = dgemm(w.D1, w.D3, w.D5, GF_A_UPPER)) return rc;                                             // D5 = GL
   }
   const double* g_kl = g->g_kl;
   if (g_kl && !wh) {
@@ -1517,8 +1623,12 @@ static int svgp_backward_t(const gpz_svgp_problem* p, const gpz_svgp_grads* g, i
       if (int rc = dgemm(w.D1, w.D2, w.D3, GF_A_UPPER)) return rc;                                // D3 = E
       E = w.D3;
     }
-    hipLaunchKernelGGL((lbar_kernel<T>), gm, dim3(256), 0, s, w.D5, Mp, M, static_cast<const T*>(g->g_chol), E, w.D2,
-                       wh ? nullptr : g_kl, b.Kzz);
+    if (alg && alg64)
+      hipLaunchKernelGGL((lbar_kernel<T, double>), gm, dim3(256), 0, s, (const double*)w.D4, Mp, M, static_cast<const T*>(g->g_chol), E, w.D2,
+                         wh ? nullptr : g_kl, b.Kzz);
+    else
+      hipLaunchKernelGGL((lbar_kernel<T, T>), gm, dim3(256), 0, s, (const T*)w.GL, Mp, M, static_cast<const T*>(g->g_chol), E, w.D2,
+                         wh ? nullptr : g_kl, b.Kzz);
     GPZ_LAUNCH_OK();                                                                              // D2 = Lbar
     hipLaunchKernelGGL(tril_transpose_kernel, g32, dim3(256), 0, s, b.Kzz, Mp, w.D1);            // D1 = L^T
     GPZ_LAUNCH_OK();
@@ -1650,7 +1760,8 @@ static int check_problem(const gpz_svgp_problem* p) {
   GPZ_REQUIRE(p->X && p->Z && p->mu && p->Lu_raw && p->info, "gpz_svgp: null input pointer");
   GPZ_REQUIRE(p->d >= 1 && p->d <= 4, "gpz_svgp: input dimension %d unsupported", p->d);
   if (p->y) GPZ_REQUIRE(p->noise_sd > 0.0, "gpz_svgp: noise_sd must be positive");
-  GPZ_REQUIRE((p->flags & ~(GPZ_SVGP_MATERIALIZE_KZX | GPZ_SVGP_NARROW_TILES | GPZ_SVGP_GENERATE_KZX | GPZ_SVGP_PANEL_PRODUCTS)) == 0,
+  GPZ_REQUIRE((p->flags & ~(GPZ_SVGP_MATERIALIZE_KZX | GPZ_SVGP_NARROW_TILES | GPZ_SVGP_GENERATE_KZX | GPZ_SVGP_PANEL_PRODUCTS |
+                             GPZ_SVGP_BACKWARD_ALGEBRA | GPZ_SVGP_BACKWARD_CLASSIC)) == 0,
               "gpz_svgp: unknown bits in flags (0x%x): the field was `reserved` before ABI 210 -- zero it", p->flags);
   return 0;
 }

@@ -584,12 +584,13 @@ def svgp_forward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bo
 def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: bool, g_mean, g_scale, scale, *,
                   gX=None, gZ=None, clamp_min: float = 1e-6, chunk: int = 0, cache: Optional[FactorCache] = None,
                   kernel_grads: bool = False, g_chol=None, wt_cache=None, g_kl=None, trust_cache: bool = False,
-                  trust_qu: bool = False, narrow_tiles: bool = False):
+                  trust_qu: bool = False, narrow_tiles: bool = False, form: Optional[str] = None):
     """dLoss/dmu (L,M) and dLoss/dLu_raw (L,M,M) (gpz_svgp_backward); with ``kernel_grads`` also
     dLoss/d(sigma, lengthscale, effective group parameter) (L,3) and dLoss/dZ (M,d), both fp64.
     ``wt_cache``: the buffer a forward pass on the same inputs and ``chunk`` returned under "wt_cache".
     ``g_kl`` (L,): upstream gradient of the forward's per-latent ``kl``; its own
-    gradient is folded into the results."""
+    gradient is folded into the results.  ``form``: "algebra" / "classic" / None (the library's choice by N / M): the
+    N-sized work as one weighted symmetric accumulation plus M x M products, or as the products autograd would run."""
     _need_cuda(X, Z, mu, Lu_raw, g_mean, g_scale)
     if X.dim() == 2 and X.shape[0] == 0 and Z.dim() == 2 and Z.shape[0] > 0:
         # empty X (see svgp_forward): one stand-in point with zero upstream gradients leaves the KL / factor terms
@@ -604,6 +605,8 @@ def svgp_backward(spec: KernelSpec, X, Z, mu, Lu_raw, jitter: float, whitened: b
     p.info = info.data_ptr()
     if narrow_tiles:                 # the 128 x 128-tile kernel for the fp32 products (csrc/gemm.hip), as in round 2
         p.flags |= _lib.SVGP_NARROW_TILES
+    if form is not None:
+        p.flags |= {"algebra": _lib.SVGP_BACKWARD_ALGEBRA, "classic": _lib.SVGP_BACKWARD_CLASSIC}[form]
     g = _lib.SvgpGrads()
     gm = g_mean.detach().to(dt).reshape(L, N).contiguous()
     gs = g_scale.detach().to(dt).reshape(L, N).contiguous()

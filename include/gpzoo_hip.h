@@ -146,6 +146,12 @@ int gpz_trsm_lln_batched(const void* Lc, int64_t ldl, int64_t stride_l, void* B,
                                      * library's own choice (flags == 0) in the first case for every M <= 512 and in the
                                      * second for 128 < M <= 512; with this flag wherever it applies; ignored elsewhere
                                      * and next to any of the three flags above. */
+/* gpz_svgp_backward only: which form the N-sized work of the pass takes (0 = the library's choice by N / M; the
+ * gradients agree to rounding).  ALGEBRA: one weighted symmetric accumulation H += W diag(gv2) W^T per chunk (and, with
+ * grad_theta / grad_Z, one dense product for Kbar_x) plus M x M products; CLASSIC: the products autograd would run --
+ * Pbar, W Pbar^T (and Wbar, Kbar_x, Kbar_x W^T). */
+#define GPZ_SVGP_BACKWARD_ALGEBRA 16
+#define GPZ_SVGP_BACKWARD_CLASSIC 32
 
 typedef struct gpz_svgp_problem {
   gpz_kernel_desc k;
