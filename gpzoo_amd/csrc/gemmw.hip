@@ -41,6 +41,7 @@
 #include "cov.h"
 
 
+#include <cmath>
 #include <mutex>
 #include <type_traits>
 #include <utility>
@@ -974,7 +975,21 @@ static int64_t nt_tiles(int64_t nblk) {
 
 int wide_nt_pieces(int64_t Mp, int64_t K, int L) {
   const int64_t tiles = nt_tiles(Mp / 128) * L;
-  if (tiles >= 384) return 1;
+  if (tiles >= 384) {
+    // Enough tiles to fill the chip -- but they all run equally long (same k extent), so the launch takes WHOLE rounds of
+    // the 512 resident workgroups: 2304 tiles (config 3: 16 blocks, L = 32) are 4.5 rounds and run as long as 5.  Cutting k
+    // in two makes them 9.0: pick the cut (<= 4 pieces, >= 128 steps each) whose last round is fullest, charging each extra
+    // piece 1.5 % for its partial tiles' trip through memory.
+    const double r = (double)tiles / 512.0;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int S = 1; S <= 4; ++S) {
+      if (S > 1 && K / S < 2048) break;
+      const double rounds = r * S, cost = std::ceil(rounds - 1e-9) / rounds * (1.0 + 0.015 * (S - 1));
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
+    }
+    return best;
+  }
   // one round of resident workgroups, not a second round with a few stragglers: two 8-wave workgroups per CU, or four of
   // the 4-wave ones (one 128-block per tile)
   int64_t S = (nt_small_tiles(Mp / 128) ? 1024 : 512) / tiles;
