@@ -47,7 +47,7 @@ constexpr size_t CO_LDS_BYTES = CO_SH_OFF + 64;
 static_assert(sizeof(double) * CO_TILE_DOUBLES <= CO_SH_OFF, "tile buffers alias the diagonal block's storage");
 static_assert(sizeof(double) * 128 * 130 <= CO_SH_OFF, "the tile image aliases them too");
 
-struct CoopOrder { uint16_t t[CO_MAX_TASKS]; };    // kind << 12 | i << 6 | j
+struct CoopOrder { uint16_t t[CO_MAX_TASKS]; };    // kind << 12 | i << 6 | j; kind 0: C(i,j), 1: X(i,j), 2: C(j,j-1) + C(j,j), 3: the early part of C(j,j)
 
 struct CoopParams {
   double* A; int64_t lda, sA;          // (batch) padded matrices, factored in place
@@ -56,7 +56,8 @@ struct CoopParams {
   double* XT; int64_t sX;              // (batch, Mp, Mp) scratch: transpose of Linv
   float* Linv32;                       // (batch, Mp, Mp) fp32 copy of Linv written beside it (stride sL), or null
   int32_t* info; int64_t m_real;
-  uint32_t* sync; int64_t sS;          // per matrix: [0] ticket, then flags of C tiles, then flags of X tiles
+  uint32_t* sync; int64_t sS;          // per matrix: [0] ticket, then flags of C tiles, then flags of X tiles (X(j,j):
+                                       // the inverse of diagonal block j is stored, ahead of C(j,j): everything of it is)
   uint32_t* abort_word;
   int nblk, batch, ntasks, gmax;
   unsigned long long timeout_ticks;    // of the 100 MHz s_memrealtime clock
@@ -380,6 +381,54 @@ __device__ __forceinline__ void multiply_image(const Ctx& c, d4 (&acc)[4][2], co
   }
 }
 
+// acc(row, col) = sum_k image[row][k] * image[col][k], K = 128, lower sub-tiles only: the update a freshly computed
+// tile L[j][j-1] -- still the LDS image -- contributes to the diagonal tile below it, without a trip through memory.
+// A wave owns rows 64 WM .. + 63 and the column sub-tiles WN and 7 - WN (the layout multiply_image leaves); sub-tile
+// (row 4 WM + mi, column c) is computed iff row >= c: 9 of 16 on every SIMD.  WM, WN are constants so that the skipped
+// products are absent from the code rather than branched around.  No barrier inside: the image is read-only.
+template <int WM, int WN>
+__device__ __forceinline__ void syrk_image_w(const Ctx& c, d4 (&acc)[4][2]) {
+  constexpr int c0 = WN, c1 = 7 - WN;
+  const double* Ta = lds_tiles() + (WM * 64 + c.r) * TP + 2 * c.q;
+  const double* Tb0 = lds_tiles() + (16 * c0 + c.r) * TP + 2 * c.q;
+  const double* Tb1 = lds_tiles() + (16 * c1 + c.r) * TP + 2 * c.q;
+  zero_acc(acc);
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    d2v a[4][2], b0[2], b1[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        if (4 * WM + mi >= c0) a[mi][kc] = *reinterpret_cast<const d2v*>(Ta + mi * 16 * TP + 16 * kt + 8 * kc);
+      b0[kc] = *reinterpret_cast<const d2v*>(Tb0 + 16 * kt + 8 * kc);
+      if (4 * WM + 3 >= c1) b1[kc] = *reinterpret_cast<const d2v*>(Tb1 + 16 * kt + 8 * kc);
+    }
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          if (4 * WM + mi >= c0) acc[mi][0] = diag::mma(a[mi][kc][j], b0[kc][j], acc[mi][0]);
+          if (4 * WM + mi >= c1) acc[mi][1] = diag::mma(a[mi][kc][j], b1[kc][j], acc[mi][1]);
+        }
+  }
+}
+
+__device__ __forceinline__ void syrk_image(const Ctx& c, d4 (&acc)[4][2]) {
+  switch (__builtin_amdgcn_readfirstlane(c.wave)) {         // wave = 4 wm + wn
+    case 0: syrk_image_w<0, 0>(c, acc); break;
+    case 1: syrk_image_w<0, 1>(c, acc); break;
+    case 2: syrk_image_w<0, 2>(c, acc); break;
+    case 3: syrk_image_w<0, 3>(c, acc); break;
+    case 4: syrk_image_w<1, 0>(c, acc); break;
+    case 5: syrk_image_w<1, 1>(c, acc); break;
+    case 6: syrk_image_w<1, 2>(c, acc); break;
+    default: syrk_image_w<1, 3>(c, acc); break;
+  }
+}
+
 // One matrix of the batch.  The pointers travel to the noinline task functions through memory; stored as generic
 // pointers they would come back as flat_ accesses, so the struct keeps integers and the accessors rebuild global ones.
 struct Mat {
@@ -420,6 +469,33 @@ __device__ __forceinline__ bool accumulate(const Ctx& c, d4 (&acc)[4][2], const 
   return true;
 }
 
+// The diagonal block in S (LDS): factor, invert, store, announce.  Shared by the two tasks that produce tile (j, j).
+__device__ __forceinline__ void finish_diag(const Ctx& c, const Mat& m, int j, double* Ct) {
+  const int nblk = m.nblk;
+  double* S = lds_tiles();
+  const bool trc = c.p->trace != nullptr && c.tid == 0;
+  const unsigned long long td0 = trc ? realtime() : 0ull;
+  diag::prepare(S, c.tid);
+  __syncthreads();
+  diag::factor_block<8>(S, c.tid, m.info(), (int64_t)j * 128, c.p->m_real, 1);
+  const unsigned long long td1 = trc ? realtime() : 0ull;
+  diag::inverse_levels(S, c.tid);
+  if (trc) { lds_scalars()[4] = (int)(td1 - td0); lds_scalars()[5] = (int)(realtime() - td1); }   // (diagnostics: factor, inverse)
+  // What the tiles below and beside this one wait for is the block's INVERSE (they multiply by it; nobody reads L[j][j]
+  // inside the launch): it is stored and announced first, under a flag of its own (the unused diagonal entry of the X
+  // flags), and the factor and the copies of the inverse that only later tasks / the caller read follow behind it --
+  // four 128 KB store sweeps and their drain off the chain of diagonal blocks.
+  store_block_inverse<false>(c, m.Db() + (int64_t)j * 128 * 128, 128);
+  publish(c, m.fX() + j * nblk + j);
+  diag::store_factor<CO_THREADS>(S, Ct, m.lda, c.tid);
+  if (m.Lb()) {
+    store_block_inverse<false>(c, m.Lb() + (int64_t)j * 128 * (m.ldl + 1), m.ldl);
+    store_block_inverse<true>(c, m.Xb() + (int64_t)j * 128 * (m.ldl + 1), m.ldl);
+    if (m.L32_) store_block_inverse_f32(c, m.L32() + (int64_t)j * 128 * (m.ldl + 1), m.ldl);
+  }
+  publish(c, m.fC() + j * nblk + j);
+}
+
 // ---------------- Cholesky tile (j, j): sum, factor + invert in LDS, publish the inverse ----------------
 __device__ __attribute__((noinline)) bool task_chol_diag(const Ctx& c_in, const Mat& m_in, int j) {
   const Ctx c = c_in;               // private copies: values reached through a reference are reloaded behind every
@@ -449,18 +525,104 @@ __device__ __attribute__((noinline)) bool task_chol_diag(const Ctx& c_in, const 
         S[mm * DP + n] = (n <= mm) ? cin[ni][g] - acc[mi][ni][g] : 0.0;
       }
   }
-  diag::prepare(S, c.tid);
+  finish_diag(c, m, j, Ct);
+  return true;
+}
+
+// ---------------- the part of tile (j, j), j >= 2, that does not wait for the chain ----------------
+// A[j][j] <- A[j][j] - sum_{k < j - 1} L[j][k] L[j][k]^T, in place, written through; flag: entry (j - 1, j) of the C flags.
+__device__ __attribute__((noinline)) bool task_chol_presum(const Ctx& c_in, const Mat& m_in, int j) {
+  const Ctx c = c_in;
+  const Mat m = m_in;
+  const int nblk = m.nblk;
+  d4 acc[4][2];
+  zero_acc(acc);
+  const double* Aj = m.Ab() + (int64_t)j * 128 * m.lda;
+  const guint* fj = m.fC() + j * nblk;
+  if (!accumulate(c, acc, Aj, m.lda, Aj, m.lda, j - 1, [&](int k) { return flag_load(fj + k) != 0u; })) return false;
+  double* Cd = m.Ab() + (int64_t)j * 128 * (m.lda + 1);
+  const int row0 = CO_ROW0, col0 = CO_COL0;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        double* e = Cd + (int64_t)(row0 + 16 * mi + 4 * g) * m.lda + col0 + 16 * ni;
+        __hip_atomic_store(e, *e - acc[mi][ni][g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+  publish(c, m.fC() + (j - 1) * nblk + j);
+  return true;
+}
+
+// ---------------- Cholesky tiles (j, j - 1) AND (j, j), j >= 1, by one workgroup ----------------
+// The chain of the factorisation is  D(j-1) -> L[j][j-1] = T inv(L[j-1][j-1])^T -> D(j) = chol(A[j][j] - ... - L[j][j-1] L[j][j-1]^T).
+// As two tasks the second step ended in a store sweep, its drain and a flag, and the third began by polling that flag
+// and pulling the tile back through L2 for a 128 x 128 x 128 product of which half is not needed (16 us on one CU).  Here
+// the tile stays where it was computed -- the LDS image -- and its symmetric update comes from there, lower sub-tiles
+// only (9 us); its stores drain behind those MFMAs and the flag for the other users of L[j][j-1] goes up afterwards.
+// What does not depend on the chain is done before it arrives: T's sum over k < j - 1 stays in the accumulators; the
+// diagonal tile's, over the same k, is a task of its own (task_chol_presum: one workgroup doing both in turn had the
+// second sum start when the first one's last block -- which arrives one column ahead of the chain -- was in).
+__device__ __attribute__((noinline)) bool task_chol_fused(const Ctx& c_in, const Mat& m_in, int j) {
+  const Ctx c = c_in;
+  const Mat m = m_in;
+  const int nblk = m.nblk, jm = j - 1;
+  d4 acc[4][2];
+  const guint *fj = m.fC() + j * nblk, *fjm = m.fC() + jm * nblk;
+  const double* Aj = m.Ab() + (int64_t)j * 128 * m.lda;
+  double* Cd = m.Ab() + (int64_t)j * 128 * (m.lda + 1);
+  double* Co = m.Ab() + (int64_t)j * 128 * m.lda + (int64_t)jm * 128;
+  const int row0 = CO_ROW0, col0 = CO_COL0;
+  zero_acc(acc);
+  if (!accumulate(c, acc, Aj, m.lda, m.Ab() + (int64_t)jm * 128 * m.lda, m.lda, jm,
+                  [&](int k) { return flag_load(fj + k) != 0u && flag_load(fjm + k) != 0u; }))
+    return false;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[mi][ni][g] = Co[(int64_t)(row0 + 16 * mi + 4 * g) * m.lda + col0 + 16 * ni] - acc[mi][ni][g];
+  __syncthreads();                 // every wave is behind its last fragment read of the tile buffers
+  stage_image<false, false>(c, acc, 1.0);
+  const guint* fd = m.fX() + jm * nblk + jm;      // "inv(L[j-1][j-1]) is stored"
+  const int n = wait_ready(c, 0, 1, [&](int) { return flag_load(fd) != 0u; });   // (its barriers publish the image)
+  if (n < 0) return false;
+  multiply_image(c, acc, m.Db() + (int64_t)jm * 128 * 128, 128);
+  __syncthreads();                 // the image has been read by everybody
+  stage_image<false, true>(c, acc, 1.0);
   __syncthreads();
-  diag::factor_block(S, c.tid, m.info(), (int64_t)j * 128, c.p->m_real, 1);
-  diag::store_factor<CO_THREADS>(S, Ct, m.lda, c.tid);
-  diag::inverse_levels(S, c.tid);
-  store_block_inverse<false>(c, m.Db() + (int64_t)j * 128 * 128, 128);
-  if (m.Lb()) {
-    store_block_inverse<false>(c, m.Lb() + (int64_t)j * 128 * (m.ldl + 1), m.ldl);
-    store_block_inverse<true>(c, m.Xb() + (int64_t)j * 128 * (m.ldl + 1), m.ldl);
-    if (m.L32_) store_block_inverse_f32(c, m.L32() + (int64_t)j * 128 * (m.ldl + 1), m.ldl);
+  store_rows(c, Co, m.lda, nullptr);
+  syrk_image(c, acc);              // acc = L[j][j-1] L[j][j-1]^T, lower sub-tiles, while the rows drain
+  publish(c, m.fC() + j * nblk + jm);   // (its barrier: every wave is done with the image, which S now overwrites)
+  // S = (A[j][j] - earlier sums) - acc.  For j >= 2 the earlier sums were subtracted in place by task_chol_presum, long
+  // ago as a rule (its flag: the unused entry (j - 1, j) of the C flags); its stores were written through, read them past
+  // the L1.  Element (mi, ni, g) of syrk_image: row 64 wm + 16 mi + q + 4 g, column 16 (ni ? 7 - wn : wn) + r.
+  if (jm > 0) {
+    const guint* fp = m.fC() + jm * nblk + j;
+    if (wait_ready(c, 0, 1, [&](int) { return flag_load(fp) != 0u; }) < 0) return false;
   }
-  publish(c, m.fC() + j * nblk + j);
+  double* S = lds_tiles();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    double cin[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        cin[ni][g] = __hip_atomic_load(Cd + (int64_t)(row0 + 16 * mi + 4 * g) * m.lda + 16 * (ni ? 7 - c.wn : c.wn) + c.r,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int mm = row0 + 16 * mi + 4 * g, nn = 16 * (ni ? 7 - c.wn : c.wn) + c.r;
+        S[mm * DP + nn] = (nn <= mm) ? cin[ni][g] - acc[mi][ni][g] : 0.0;
+      }
+  }
+  finish_diag(c, m, j, Cd);
   return true;
 }
 
@@ -489,7 +651,8 @@ __device__ __attribute__((noinline)) bool task_chol_off(const Ctx& c_in, const M
         acc[mi][ni][g] = Ct[(int64_t)(row0 + 16 * mi + 4 * g) * m.lda + col0 + 16 * ni] - acc[mi][ni][g];
   __syncthreads();                 // every wave is behind its last fragment read of the tile buffers
   stage_image<false, false>(c, acc, 1.0);
-  const int n = wait_ready(c, 0, 1, [&](int) { return flag_load(fj + j) != 0u; });   // (its barriers publish the image)
+  const guint* fd = m.fX() + j * nblk + j;        // "inv(L[j][j]) is stored" (task_chol_diag)
+  const int n = wait_ready(c, 0, 1, [&](int) { return flag_load(fd) != 0u; });   // (its barriers publish the image)
   if (n < 0) return false;
   const unsigned long long ts1 = trc ? realtime() : 0ull;
   multiply_image(c, acc, m.Db() + (int64_t)j * 128 * 128, 128);
@@ -525,7 +688,8 @@ __device__ __attribute__((noinline)) bool task_inverse(const Ctx& c_in, const Ma
   const unsigned long long ts0 = trc ? realtime() : 0ull;
   __syncthreads();
   stage_image<true, false>(c, acc, -1.0);
-  const int n = wait_ready(c, 0, 1, [&](int) { return flag_load(fi + i) != 0u; });
+  const guint* fd = m.fX() + i * nblk + i;        // "inv(L[i][i]) is stored"
+  const int n = wait_ready(c, 0, 1, [&](int) { return flag_load(fd) != 0u; });
   if (n < 0) return false;
   const unsigned long long ts1 = trc ? realtime() : 0ull;
   multiply_image(c, acc, m.Db() + (int64_t)i * 128 * 128, 128);
@@ -578,7 +742,9 @@ __device__ __forceinline__ bool run_matrix(const Ctx& c, const CoopOrder& ord, i
     lds_scalars()[4] = 0;
     lds_scalars()[5] = 0;
     bool ok;
-    if (kind != 0) ok = task_inverse(c, m, i, j);
+    if (kind == 2) ok = task_chol_fused(c, m, j);
+    else if (kind == 3) ok = task_chol_presum(c, m, j);
+    else if (kind != 0) ok = task_inverse(c, m, i, j);
     else if (i == j) ok = task_chol_diag(c, m, j);
     else ok = task_chol_off(c, m, i, j);
     if (tr && c.tid == 0) { tr[3] = realtime(); tr[4] = (unsigned long long)lds_scalars()[2];
@@ -631,57 +797,84 @@ __global__ __launch_bounds__(CO_THREADS) void coop_factor_kernel(const CoopParam
 
 // ---- the order: a host-side model of the execution above -------------------------------------------------------------
 namespace {
-struct OrderKey { int nblk, G, inv; bool operator<(const OrderKey& o) const { return std::tie(nblk, G, inv) < std::tie(o.nblk, o.G, o.inv); } };
+struct OrderKey { int nblk, G, inv, fused; bool operator<(const OrderKey& o) const { return std::tie(nblk, G, inv, fused) < std::tie(o.nblk, o.G, o.inv, o.fused); } };
 
 // Rough phase times (us) on one CU: a 128^3 fp64 accumulation step, the multiply by a diagonal block's inverse with its
-// park / reload, the diagonal block itself, flag latency, a claim.  Only their ratios matter for the order.
-constexpr double T_OP = 14.5, T_P = 17.0, T_D = 42.0, T_FLAG = 2.0, T_CLAIM = 1.0;
+// park / reload, the symmetric update from the LDS image, the diagonal block up to the flag of its inverse and the
+// stores behind that flag, flag latency, a claim.  Only their ratios matter for the order.
+constexpr double T_OP = 16.0, T_P = 15.0, T_S = 9.0, T_D = 47.0, T_DT = 8.0, T_FLAG = 2.0, T_CLAIM = 1.0;
 
+// What a step waits for: tiles C(i,j) = i * nblk + j, X(i,j) = nblk^2 + i * nblk + j (a diagonal C tile: everything of
+// it), and INV(j) = 2 nblk^2 + j: the inverse of diagonal block j, announced ahead of the rest of C(j,j).
 struct Step { int dep[2]; double dur; };
 
+// kind 0: C(i,j); 1: X(i,j); 2: the fused pair C(j,j-1) + C(j,j); 3: PRE(j), the early sums of C(j,j) -- named by the
+// unused tile id (j-1, j)
 static void steps_of(int kind, int i, int j, int nblk, std::vector<Step>& st) {
-  // task ids: C(i,j) = i * nblk + j, X(i,j) = nblk^2 + i * nblk + j
-  const int X0 = nblk * nblk;
+  const int X0 = nblk * nblk, I0 = 2 * X0;
   st.clear();
-  if (kind == 0) {
+  if (kind == 3) {
+    for (int k = 0; k < j - 1; ++k) st.push_back({{j * nblk + k, -1}, T_OP});
+    st.push_back({{-1, -1}, 3.0});
+  } else if (kind == 2) {
+    for (int k = 0; k < j - 1; ++k) st.push_back({{j * nblk + k, (j - 1) * nblk + k}, T_OP});
+    st.push_back({{I0 + j - 1, -1}, T_P});       // [size - 3]: the tile C(j,j-1) exists behind this step
+    st.push_back({{-1, -1}, T_S});
+    st.push_back({{j >= 2 ? (j - 1) * nblk + j : -1, -1}, T_D});
+  } else if (kind == 0) {
     for (int k = 0; k < j; ++k) st.push_back({{i * nblk + k, i != j ? j * nblk + k : -1}, T_OP});
     if (i == j) st.push_back({{-1, -1}, T_D});
-    else st.push_back({{j * nblk + j, -1}, T_P});
+    else st.push_back({{I0 + j, -1}, T_P});
   } else {
     for (int k = j; k < i; ++k) st.push_back({{i * nblk + k, k > j ? X0 + k * nblk + j : j * nblk + j}, T_OP});
-    st.push_back({{i * nblk + i, -1}, T_P});
+    st.push_back({{I0 + i, -1}, T_P});
   }
 }
 
-static CoopOrder build_order(int nblk, int G, bool inv, int* ntasks_out) {
-  const int X0 = nblk * nblk, NT = 2 * X0;
-  std::vector<char> exists(NT, 0), claimed(NT, 0);
-  std::vector<double> fin(NT, 0.0), bl(NT, 0.0);
+static CoopOrder build_order(int nblk, int G, bool inv, bool fused, int* ntasks_out) {
+  const int X0 = nblk * nblk, I0 = 2 * X0, NT = I0 + nblk;
+  // tasks are named by the tile they finish LAST: the fused task of column j - 1 / row j is C(j,j)
+  std::vector<int> kind(NT, -1), prod(NT, -1);     // of a task id; of a tile / INV id: the task that makes it
+  std::vector<double> avail(NT, 0.0), bl(NT, 0.0);
+  std::vector<char> claimed(NT, 0);
   std::vector<int> all;
   for (int j = 0; j < nblk; ++j)
-    for (int i = j; i < nblk; ++i) { exists[i * nblk + j] = 1; all.push_back(i * nblk + j); }
+    for (int i = j; i < nblk; ++i) {
+      const int t = i * nblk + j;
+      if (fused && i == j + 1) { prod[t] = i * nblk + i; continue; }          // made by the fused task of row i
+      if (fused && i == j && j >= 2) {                                          // its early sums, listed ahead of it
+        const int pre = (j - 1) * nblk + j;
+        kind[pre] = 3; prod[pre] = pre;
+        all.push_back(pre);
+      }
+      kind[t] = (fused && i == j && j >= 1) ? 2 : 0;
+      prod[t] = t;
+      all.push_back(t);
+      if (i == j) prod[I0 + j] = t;
+    }
   if (inv)
     for (int j = 0; j < nblk; ++j)
-      for (int i = j + 1; i < nblk; ++i) { exists[X0 + i * nblk + j] = 1; all.push_back(X0 + i * nblk + j); }
-  auto kind_of = [&](int t) { return t >= X0 ? 1 : 0; };
+      for (int i = j + 1; i < nblk; ++i) { kind[X0 + i * nblk + j] = 1; prod[X0 + i * nblk + j] = X0 + i * nblk + j; all.push_back(X0 + i * nblk + j); }
   auto ij_of = [&](int t, int& i, int& j) { const int u = t % X0; i = u / nblk; j = u % nblk; };
-  // bottom levels: only a tile's last two steps sit on a chain (the earlier ones are accumulated ahead of time)
+  // bottom levels: only a task's last steps sit on a chain (the earlier ones are accumulated ahead of time)
   std::vector<std::vector<int>> succ(NT);
   std::vector<Step> st;
   std::vector<double> last(NT, 0.0);
   for (int t : all) {
     int i, j;
     ij_of(t, i, j);
-    steps_of(kind_of(t), i, j, nblk, st);
-    last[t] = st.back().dur + (st.size() > 1 ? st[st.size() - 2].dur : 0.0);
-    for (const Step& s : st)
-      for (int d : s.dep)
-        if (d >= 0) succ[d].push_back(t);
+    steps_of(kind[t], i, j, nblk, st);
+    const size_t nchain = kind[t] == 2 ? 3 : 2;
+    for (size_t u = st.size() > nchain ? st.size() - nchain : 0; u < st.size(); ++u) last[t] += st[u].dur;
+    for (const Step& sp : st)
+      for (int d : sp.dep)
+        if (d >= 0) succ[prod[d]].push_back(t);
   }
-  // every dependency of a tile precedes it in (column-major C, then column-major X) order: reverse sweep
+  // every dependency of a task precedes it in (column-major C, then column-major X) order -- the fused task of row i,
+  // listed in column i, after column i - 1 whose tiles it needs: reverse sweep
   for (auto it = all.rbegin(); it != all.rend(); ++it) {
     double m = 0.0;
-    for (int s : succ[*it]) m = std::max(m, bl[s]);
+    for (int sc : succ[*it]) m = std::max(m, bl[sc]);
     bl[*it] = last[*it] + m;
   }
   std::vector<double> wfree(G, 0.0);
@@ -693,53 +886,62 @@ static CoopOrder build_order(int nblk, int G, bool inv, int* ntasks_out) {
     const int w = (int)(std::min_element(wfree.begin(), wfree.end()) - wfree.begin());
     const double t0 = wfree[w];
     int best = -1;
-    double best_key0 = 0, best_key1 = 0, best_fin = 0;
+    double best_key0 = 0, best_key1 = 0, best_fin = 0, best_mid = 0;
     for (size_t ci = 0; ci < remaining.size(); ++ci) {
       const int c = remaining[ci];
       int i, j;
       ij_of(c, i, j);
-      steps_of(kind_of(c), i, j, nblk, st);
+      steps_of(kind[c], i, j, nblk, st);
       bool ok = true;
-      double t = t0 + T_CLAIM, work = 0.0;
-      for (const Step& s : st) {
-        for (int d : s.dep)
+      double t = t0 + T_CLAIM, work = 0.0, mid = 0.0;
+      for (size_t u = 0; u < st.size(); ++u) {
+        const Step& sp = st[u];
+        for (int d : sp.dep)
           if (d >= 0) {
-            if (!claimed[d]) { ok = false; break; }
-            t = std::max(t, fin[d] + T_FLAG);
+            if (!claimed[prod[d]]) { ok = false; break; }
+            t = std::max(t, avail[d] + T_FLAG);
           }
         if (!ok) break;
-        t += s.dur;
-        work += s.dur;
+        t += sp.dur;
+        work += sp.dur;
+        if (kind[c] == 2 && u + 3 == st.size()) mid = t;
       }
       if (!ok) continue;
       const double blocked = t - t0 - T_CLAIM - work;
       const double k0 = blocked <= slack ? 0.0 : 1.0, k1 = blocked <= slack ? -bl[c] : blocked;
       if (best < 0 || k0 < best_key0 || (k0 == best_key0 && k1 < best_key1)) {
-        best = (int)ci; best_key0 = k0; best_key1 = k1; best_fin = t;
+        best = (int)ci; best_key0 = k0; best_key1 = k1; best_fin = t; best_mid = mid;
       }
     }
     const int c = remaining[best];
     int i, j;
     ij_of(c, i, j);
-    ord.t[n++] = (uint16_t)((kind_of(c) << 12) | (i << 6) | j);
+    ord.t[n++] = (uint16_t)((kind[c] << 12) | ((kind[c] == 3 ? j : i) << 6) | j);
     claimed[c] = 1;
-    fin[c] = best_fin;
-    wfree[w] = best_fin;
+    if ((kind[c] == 0 || kind[c] == 2) && i == j) {          // a diagonal block: its inverse first, the rest behind it
+      avail[I0 + j] = best_fin;
+      avail[c] = best_fin + T_DT;
+      if (kind[c] == 2) avail[i * nblk + i - 1] = best_mid + T_S;       // (the flag goes up behind the symmetric update)
+      wfree[w] = best_fin + T_DT;
+    } else {
+      avail[c] = best_fin;
+      wfree[w] = best_fin;
+    }
     remaining.erase(remaining.begin() + best);
   }
   *ntasks_out = n;
   return ord;
 }
 
-static const CoopOrder& cached_order(int nblk, int G, bool inv, int* ntasks) {
+static const CoopOrder& cached_order(int nblk, int G, bool inv, bool fused, int* ntasks) {
   static std::map<OrderKey, std::pair<CoopOrder, int>> cache;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
-  const OrderKey key{nblk, G, inv ? 1 : 0};
+  const OrderKey key{nblk, G, inv ? 1 : 0, fused ? 1 : 0};
   auto it = cache.find(key);
   if (it == cache.end()) {
     int n = 0;
-    CoopOrder o = build_order(nblk, G, inv, &n);
+    CoopOrder o = build_order(nblk, G, inv, fused, &n);
     it = cache.emplace(key, std::make_pair(o, n)).first;
   }
   *ntasks = it->second.second;
@@ -796,7 +998,9 @@ int factor_coop(double* A, int64_t Mp, int64_t lda, int64_t stride, int64_t batc
   const int nclus = (int)std::min<int64_t>(batch, 256);
   const int nwg = std::min(256, (nclus * p.gmax + 7) / 8 * 8);
   const int G = std::max(1, nwg / nclus);
-  const CoopOrder& ord = cached_order(nblk, G, Linv != nullptr, &p.ntasks);
+  // GPZ_COOP_UNFUSED: tiles (j, j-1) and (j, j) as two tasks, as in round 4 (A/B timing)
+  static const bool fused = std::getenv("GPZ_COOP_UNFUSED") == nullptr;
+  const CoopOrder& ord = cached_order(nblk, G, Linv != nullptr, fused, &p.ntasks);
   static bool attr_set[64] = {};
   int dev = 0;
   GPZ_HIP_OK(hipGetDevice(&dev));
@@ -821,6 +1025,19 @@ extern "C" int gpz_debug_coop_mute(int i, int j) {
   gpz::g_coop_mute_i = i;
   gpz::g_coop_mute_j = j;
   return 0;
+}
+
+// Diagnostics (host only, no GPU call): the claim order factor_coop would launch with for `nblk` block columns and G
+// workgroups per matrix, as task codes kind << 12 | i << 6 | j (kind 0: C(i,j), 1: X(i,j), 2: C(j,j-1) + C(j,j), 3: the early part of C(j,j)); returns
+// their number.  tests/test_abi.py checks that every order is a linear extension of the tile DAG -- the property the
+// launch's progress rests on.
+extern "C" int gpz_debug_coop_order(int nblk, int G, int inverse, int fused, uint16_t* out, int cap) {
+  if (nblk < 1 || nblk > 63 || G < 1 || !gpz::coop_supported((int64_t)nblk * 128, inverse != 0)) return -1;
+  int n = 0;
+  const gpz::CoopOrder& o = gpz::cached_order(nblk, G, inverse != 0, fused != 0, &n);
+  if (n > cap) return -1;
+  for (int k = 0; k < n; ++k) out[k] = o.t[k];
+  return n;
 }
 
 extern "C" int gpz_debug_coop_trace(void* buf) {

@@ -72,42 +72,68 @@ __device__ __forceinline__ void sqrt_rsqrt(double d, double& sq, double& rs) {
   rs = h + h;
 }
 
-// One wave: right-looking Cholesky of the 32x32 block at offset o.  Lane i (and its twin i+32) holds row i in
-// registers.  Per column the dependent chain is: pivot (v_readlane of the running diagonal), its reciprocal square
-// root (v_rsq_f64 + Newton steps: ~17 dependent fp64 operations, ~200 cycles), the multipliers l_ij = a_ij r.  What
-// the NEXT column needs from this one is only a_(i,j+1) and the running diagonal a_ii - sum_k l_ik^2, so those two are
-// updated at once (multiplier by v_readlane) and the other 30 - j row updates of the column are deferred into the next
-// column's body, where they issue in the latency shadow of its pivot chain with multipliers read back from the
-// compact column buffer CB[j][k] (uniform-address LDS broadcasts; the write -> read round trip is off the critical
-// path by then).  Stamps (tools/diag_stamps.sh): 600 -> ~250 cycles per column against everything done in place.
+// The value the lanes of half `from` (0: lanes 0-31, 1: lanes 32-63) hold, in both halves: one v_permlane32_swap per word
+// (with the same register as both operands it leaves the low half's copy in one result and the high half's in the other).
+__device__ __forceinline__ double from_half(double v, int from) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)h2[from], (int)l2[from]);
+}
+
+// One wave: right-looking Cholesky of the 32x32 block at offset o.  Row i lives in lanes i and i + 32: the low lane holds
+// its even columns, the high lane its odd ones (round 5; rounds 2-4 kept the whole row in both and did every update
+// twice -- the sweep is bound as much by what the one wave has to ISSUE per column as by the pivot chain, and this halves
+// the row updates and their LDS reads).  Per column the dependent chain is: pivot (v_readlane of the running diagonal),
+// its reciprocal square root (v_rsq_f64 + two coupled Goldschmidt steps), the multipliers l_ij = a_ij r in the half that
+// holds column j, their copy to the other half (v_permlane32_swap).  What the NEXT column needs from this one is only
+// a_(i,j+1) and the running diagonal a_ii - sum_k l_ik^2 (kept in both halves), so those two are updated at once
+// (multiplier by v_readlane) and the other row updates of the column are deferred into the next column's body, where
+// they issue in the latency shadow of its pivot chain with multipliers read back from the compact column buffer
+// CB[j][k] (two-address LDS broadcasts; the write -> read round trip is off the critical path by then).  Every element
+// sees the same updates in the same order as in the one-row-per-lane form: the factor is bit for bit the same.
 // RI[j] = 1 / l_jj for the inverse.
 __device__ __forceinline__ void factor32(double* S, double* CBu, double* RI, int o, int lane, int32_t* info,
                                          int64_t gbase, int64_t m_real) {
   const int zz = vzero();          // also keeps the 32 lane-compare masks from being hoisted out of the caller's loop
   const int i = (lane & 31) + zz;
-  const double* CB = CBu + zz;
-  double a[32];
+  const int h = lane >> 5;         // this lane holds columns 2 m + h of row i in a[m]
+  const bool h1 = h != 0;
+  const double* CB = CBu + zz + h;
+  double a[16];
 #pragma unroll
-  for (int k = 0; k < 32; ++k) a[k] = S[(o + i) * DP + o + k];
+  for (int m = 0; m < 16; ++m) a[m] = S[(o + i) * DP + o + 2 * m + h];
   double diag = S[(o + i) * DP + o + i];
   double lprev = 0.0;
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
-    double d = bcast(diag, j);
-    if (!(d > 0.0)) {
-      if (lane == 0 && gbase + j < m_real) atomicCAS(info, 0, (int)(gbase + j + 1));
-      d = 1.0;
-    }
-    // deferred row updates of column j-1 (k = j was done on the spot there): independent of the pivot chain below
+    // (no test of the pivot here: compare, select and branch through scalar registers were 40 of the ~400 cycles a
+    // column takes -- tools/valu_chain_probe.hip.  A pivot that is not positive turns into NaN and spreads; the diagonal
+    // is looked at once, behind the sweep.)
+    const double d = bcast(diag, j);
+    // deferred row updates of column j-1 for the columns k >= j+1 (k = j was done on the spot there): independent of the
+    // pivot chain below.  k = 2 m + h >= j + 1 for m >= (j + 2) / 2 in both halves; for even j column j + 1 = 2 (j / 2) + 1
+    // of the high half is due as well, and the low half's register of that index is the pivot column: multiplier 0 there.
     if (j >= 1) {
+      if ((j & 1) == 0) {
+        const double cb = CB[(j - 1) * 32 + j];
+        a[j / 2] = fma(-lprev, h1 ? cb : 0.0, a[j / 2]);
+      }
 #pragma unroll
-      for (int k = j + 1; k < 32; ++k) a[k] = fma(-lprev, CB[(j - 1) * 32 + k], a[k]);
+      for (int m = (j + 2) / 2; m < 16; ++m) a[m] = fma(-lprev, CB[(j - 1) * 32 + 2 * m], a[m]);
     }
     double sq, r;
     sqrt_rsqrt(d, sq, r);
-    const double lj = (i == j) ? sq : a[j] * r;      // rows i < j carry garbage that is never read back
+    const double lmine = (i == j) ? sq : a[j >> 1] * r;      // the half (j & 1) holds column j; rows i < j carry garbage
+    const double lj = from_half(lmine, j & 1);               // ... that is never read back
     diag = fma(-lj, lj, diag);
-    if (j + 1 < 32) a[j + 1] = fma(-lj, bcast(lj, j + 1), a[j + 1]);   // what column j+1 needs, now
+    if (j + 1 < 32) {                                         // what column j+1 needs, now
+      const double bc = bcast(lj, j + 1);
+      // column j + 1 is register (j + 1) / 2 of the other half; in this half that register is column j (spent) when j is
+      // even and column j + 2 (live: multiplier 0) when j is odd
+      if ((j & 1) == 0) a[(j + 1) >> 1] = fma(-lj, bc, a[(j + 1) >> 1]);
+      else a[(j + 1) >> 1] = fma(-lj, h1 ? 0.0 : bc, a[(j + 1) >> 1]);
+    }
     CBu[j * 32 + i] = lj;                             // twin lanes store the same value to the same address
     if (i >= j) S[(o + i) * DP + o + j] = lj;
     // RI[j] doubles as the "column j is in LDS" flag for the wave that inverts this sub-block behind us (it was zeroed
@@ -117,10 +143,20 @@ __device__ __forceinline__ void factor32(double* S, double* CBu, double* RI, int
     __hip_atomic_store(&RI[j], r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WAVEFRONT);   // wave-uniform
     lprev = lj;
     // pin the updates to this column: LLVM otherwise sinks each one to the column that consumes it and keeps
-    // all 496 broadcast values alive until then (spills)
+    // all the broadcast values alive until then (spills)
 #pragma unroll
-    for (int k = j + 1; k < 32; ++k) asm volatile("" : "+v"(a[k]));
+    for (int m = (j + 1) >> 1; m < 16; ++m) asm volatile("" : "+v"(a[m]));
     __builtin_amdgcn_sched_barrier(0);
+  }
+  // LAPACK's info: the first column whose pivot was not positive.  sqrt / rsqrt of such a pivot is NaN (d < 0, d = NaN) or
+  // becomes one in the first Goldschmidt product (d = 0: 0 * inf), so l_jj > 0 fails for it -- and, the NaN spreading
+  // down and right, possibly for later columns, never for earlier ones.  (A wave's LDS operations execute in order: the
+  // read below sees the sweep's stores.)
+  const double lii = S[(o + i) * DP + o + i];
+  const unsigned long long bad = __ballot(!(lii > 0.0)) & 0xffffffffull;
+  if (bad != 0ull) {
+    const int jb = __builtin_ctzll(bad);
+    if (lane == 0 && gbase + jb < m_real) atomicCAS(info, 0, (int)(gbase + jb + 1));
   }
 }
 
@@ -224,6 +260,9 @@ __device__ __forceinline__ void prepare(double* S, int tid) {
 
 // Factor (factor != 0) the block in S and invert its four 32x32 diagonal sub-blocks; every thread of the workgroup
 // calls it (barriers inside).  info: first non-positive pivot of this matrix (real rows only), LAPACK style.
+// NW: waves that take part in the sub-panel and trailing products (4, or 8 when the workgroup has them: these phases
+// are chains of dependent LDS reads and MFMAs, and a second wave per SIMD runs in the first one's latency).
+template <int NW = 4>
 __device__ __forceinline__ void factor_block(double* S, int tid, int32_t* info, int64_t gbase, int64_t m_real, int factor) {
   double* CB = S + 128 * DP;
   double* RI = CB + 32 * 32;
@@ -258,9 +297,9 @@ __device__ __forceinline__ void factor_block(double* S, int tid, int32_t* info, 
       d4 acc[3];
 #pragma unroll
       for (int u = 0; u < 3; ++u) acc[u] = d4{0, 0, 0, 0};
-      // every wave owns ntiles / 4 = 3 - s tiles (t = w, w+4, w+8): advanced together k-step by k-step, as independent
-      // MFMA chains, in a body specialised on that count (MFMAs under a run-time condition make hipcc shuffle the
-      // accumulators through VGPR copies: measured 2x slower)
+      // every wave owns up to ceil(ntiles / NW) tiles (t = w, w + NW, ...): advanced together k-step by k-step, as
+      // independent MFMA chains, in a body specialised on that count (MFMAs under a run-time condition make hipcc shuffle
+      // the accumulators through VGPR copies: measured 2x slower)
       auto panel = [&](auto nu_c) __attribute__((always_inline)) {
         constexpr int NU = decltype(nu_c)::value;
 #pragma unroll
@@ -268,7 +307,7 @@ __device__ __forceinline__ void factor_block(double* S, int tid, int32_t* info, 
           const int k = 4 * kk + q;
 #pragma unroll
           for (int u = 0; u < NU; ++u) {
-            const int t = w + 4 * u;
+            const int t = w + NW * u;
             const int i0 = R0 + 16 * (t >> 1), j = 16 * (t & 1) + r;
             const double av = S[(i0 + r) * DP + o + k];
             const double bv = (j >= k) ? XT(S, o + k, o + j) : 0.0;   // inv(Lss)[j][k]
@@ -276,16 +315,15 @@ __device__ __forceinline__ void factor_block(double* S, int tid, int32_t* info, 
           }
         }
       };
-      if (w < 4) {
-        if (s == 0) panel(std::integral_constant<int, 3>{});
-        else if (s == 1) panel(std::integral_constant<int, 2>{});
-        else panel(std::integral_constant<int, 1>{});
-      }
+      const int mine = w < NW ? (ntiles - w + NW - 1) / NW : 0;     // tiles t = w, w + NW, ... < ntiles (wave-uniform)
+      if (mine == 3) panel(std::integral_constant<int, 3>{});
+      else if (mine == 2) panel(std::integral_constant<int, 2>{});
+      else if (mine == 1) panel(std::integral_constant<int, 1>{});
       __syncthreads();
-      if (w < 4) {
+      if (w < NW) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-          const int t = w + 4 * u;
+          const int t = w + NW * u;
           if (t < ntiles) {
             const int i0 = R0 + 16 * (t >> 1), j0 = 16 * (t & 1);
 #pragma unroll
@@ -297,10 +335,10 @@ __device__ __forceinline__ void factor_block(double* S, int tid, int32_t* info, 
     }
     GPZ_STAMP(4 + 4 * s);
     // ---- in-block trailing update: A[a][b] -= L[a][s] L[b][s]^T, 16x16 tiles with a >= b ----
-    if (w < 4) {
+    if (w < NW) {
       const int n16 = (128 - R0) / 16;
       const int nl = n16 * (n16 + 1) / 2;
-      // two tiles of a wave at a time (t and t + 4), advanced together as independent MFMA chains; the loop condition
+      // two tiles of a wave at a time (t and t + NW), advanced together as independent MFMA chains; the loop condition
       // makes both valid, so no MFMA sits under a branch; a possible last single tile follows
       auto tile_of = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
         int ta = 0, rem = t;
@@ -308,10 +346,10 @@ __device__ __forceinline__ void factor_block(double* S, int tid, int32_t* info, 
         i0 = R0 + 16 * ta; j0 = R0 + 16 * rem;
       };
       int t = w;
-      for (; t + 4 < nl; t += 8) {
+      for (; t + NW < nl; t += 2 * NW) {
         int ia, ja, ib, jb;
         tile_of(t, ia, ja);
-        tile_of(t + 4, ib, jb);
+        tile_of(t + NW, ib, jb);
         d4 acc0, acc1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) { acc0[g] = S[(ia + q + 4 * g) * DP + ja + r]; acc1[g] = S[(ib + q + 4 * g) * DP + jb + r]; }

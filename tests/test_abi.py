@@ -1,8 +1,11 @@
 """CPU: the C-ABI library loads and exports every symbol include/gpzoo_hip.h declares
 (no compute calls: there is no GPU here)."""
 import ctypes
+import ctypes as C
 import os
 import re
+
+import pytest
 
 from conftest import ROOT
 
@@ -103,7 +106,62 @@ def test_flag_constants_match_the_header():
     hdr = open(os.path.join(ROOT, "include", "gpzoo_hip.h")).read()
     vals = {n: int(v) for n, v in re.findall(r"#define\s+(GPZ_SVGP_[A-Z_]+)\s+(\d+)", hdr)}
     assert vals == {"GPZ_SVGP_MATERIALIZE_KZX": _lib.SVGP_MATERIALIZE_KZX, "GPZ_SVGP_NARROW_TILES": _lib.SVGP_NARROW_TILES,
-                    "GPZ_SVGP_GENERATE_KZX": _lib.SVGP_GENERATE_KZX, "GPZ_SVGP_PANEL_PRODUCTS": _lib.SVGP_PANEL_PRODUCTS}
-    assert len(set(vals.values())) == 4 and all(v & (v - 1) == 0 for v in vals.values())     # distinct single bits
+                    "GPZ_SVGP_GENERATE_KZX": _lib.SVGP_GENERATE_KZX, "GPZ_SVGP_PANEL_PRODUCTS": _lib.SVGP_PANEL_PRODUCTS,
+                    "GPZ_SVGP_BACKWARD_ALGEBRA": _lib.SVGP_BACKWARD_ALGEBRA, "GPZ_SVGP_BACKWARD_CLASSIC": _lib.SVGP_BACKWARD_CLASSIC}
+    assert len(set(vals.values())) == 6 and all(v & (v - 1) == 0 for v in vals.values())     # distinct single bits
     fields = dict(_lib.SvgpProblem._fields_)
     assert "flags" in fields and ctypes.sizeof(fields["flags"]) == 4
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("inverse", [1, 0])
+def test_factor_claim_order_is_a_linear_extension_of_the_tile_dag(inverse, fused):
+    """The one-launch factorisation (csrc/coop.hip) makes progress with ANY number of resident workgroups because its
+    claim list is a linear extension of the tile DAG: whatever a task waits for is produced by a task claimed earlier.
+    Checked here, on the host, for every order the library can be asked for up to 26 block columns (M = 3328)."""
+    from gpzoo_amd import _lib
+    lib = _lib.load()
+    lib.gpz_debug_coop_order.restype = C.c_int
+    lib.gpz_debug_coop_order.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int]
+    buf = (C.c_uint16 * 1536)()
+    for nblk in list(range(1, 27)):
+        for G in (1, 2, 6, 8, 32):
+            n = lib.gpz_debug_coop_order(nblk, G, inverse, fused, buf, 1536)
+            assert n > 0, (nblk, G)
+            have = set()                          # ("C", i, j), ("X", i, j), ("INV", j), ("PRE", j)
+            for k in range(n):
+                code = buf[k]
+                kind, i, j = code >> 12, (code >> 6) & 63, code & 63
+                need = []
+                if kind == 2:                      # C(j, j-1) then C(j, j)
+                    assert i == j and j >= 1 and fused
+                    need += [("C", j, k2) for k2 in range(j - 1)] + [("C", j - 1, k2) for k2 in range(j - 1)] + [("INV", j - 1)]
+                    need += [("PRE", j)] if j >= 2 else []
+                    made = [("C", j, j - 1), ("C", j, j), ("INV", j)]
+                elif kind == 3:                    # the sums of C(j, j) over k < j - 1
+                    assert i == j and j >= 2 and fused
+                    need += [("C", j, k2) for k2 in range(j - 1)]
+                    made = [("PRE", j)]
+                elif kind == 0 and i == j:
+                    assert not (fused and j >= 1)
+                    need += [("C", j, k2) for k2 in range(j)]
+                    made = [("C", j, j), ("INV", j)]
+                elif kind == 0:
+                    assert not (fused and i == j + 1)
+                    need += [("C", i, k2) for k2 in range(j)] + [("C", j, k2) for k2 in range(j)] + [("INV", j)]
+                    made = [("C", i, j)]
+                else:
+                    assert kind == 1 and inverse and i > j
+                    need += [("C", i, k2) for k2 in range(j, i)] + [("C", j, j)] + [("X", k2, j) for k2 in range(j + 1, i)] + [("INV", i)]
+                    made = [("X", i, j)]
+                missing = [t for t in need if t not in have]
+                assert not missing, (nblk, G, k, kind, i, j, missing[:3])
+                for t in made:
+                    assert t not in have, (nblk, G, t)
+                    have.add(t)
+            want = {("C", i, j) for j in range(nblk) for i in range(j, nblk)} | {("INV", j) for j in range(nblk)}
+            if fused:
+                want |= {("PRE", j) for j in range(2, nblk)}
+            if inverse:
+                want |= {("X", i, j) for j in range(nblk) for i in range(j + 1, nblk)}
+            assert have == want, (nblk, G)

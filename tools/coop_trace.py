@@ -24,6 +24,9 @@ B = torch.randn(L, M, M, generator=g, dtype=torch.float64)
 A = (B @ B.transpose(-1, -2) / M + torch.eye(M, dtype=torch.float64)).cuda()
 nblk = (M + 127) // 128
 ntasks = nblk * (nblk + 1) // 2 + (nblk * (nblk - 1) // 2 if INV else 0)
+if not os.environ.get("GPZ_COOP_UNFUSED"):
+    ntasks -= nblk - 1              # tiles (j, j-1) and (j, j) are one task (kind 2) ...
+    ntasks += max(nblk - 2, 0)      # ... and the early sums of tile (j, j), j >= 2, another (kind 3)
 trace = torch.zeros(L * ntasks * 8, dtype=torch.int64, device="cuda")
 if INV:
     assert M % 128 == 0
@@ -75,7 +78,7 @@ jj = code & 63
 dur = (t[:, :, 3] - t[:, :, 2]).double() / 100.0
 poll = t[:, :, 4].double() / 100.0
 net = dur - poll
-diag = (kind == 0) & (ii == jj)
+diag = ((kind == 0) | (kind == 2)) & (ii == jj)
 off = (kind == 0) & (ii != jj)
 print(f"  diag tiles: mean dur {float(dur[diag].mean()):.1f} us, polling {float(poll[diag].mean()):.1f}")
 print(f"  off tiles : mean dur {float(dur[off].mean()):.1f} us, polling {float(poll[off].mean()):.1f}")
@@ -92,10 +95,10 @@ sol = torch.linalg.lstsq(Amat, nd[:, None]).solution
 print(f"  diag tiles net = {float(sol[0]):.2f} us per k-block + {float(sol[1]):.2f} us")
 acc_t = t[:, :, 5].double() / 100.0
 segs = t[:, :, 6].double()
-kb_total = float(jj[kind == 0].double().sum() + (ii - jj)[kind != 0].double().sum())
+kb_total = float(jj[kind == 0].double().sum() + (ii - jj)[kind == 1].double().sum())
 print(f"  accumulation loops: {float(acc_t.sum()):.0f} us over {kb_total:.0f} k-blocks = {float(acc_t.sum()) / kb_total:.2f} us per k-block; {float(segs.sum()) / max(1.0, float((jj > 0).sum())):.2f} segments per tile with a sum")
 if INV:
-    xt = kind != 0
+    xt = kind == 1
     print(f"  inverse tiles: mean dur {float(dur[xt].mean()):.1f} us, polling {float(poll[xt].mean()):.1f}")
     jo = (ii - jj)[xt].double()
     Amat = torch.stack([jo, torch.ones_like(jo)], 1)
@@ -108,7 +111,7 @@ pl = t[:, :, 7].double() / 100.0
 tail = dur - acc_t - e1 - pl - poll
 print(f"  off tiles: park + wait {float(e1[off].mean()):.1f} us (incl. polling), multiply loop {float(pl[off].mean()):.1f} us, rest (claim, store, publish) {float((dur - acc_t - e1 - pl)[off].mean()):.1f} us")
 if INV:
-    print(f"  inverse tiles: park + wait {float(e1[kind != 0].mean()):.1f} us, multiply loop {float(pl[kind != 0].mean()):.1f} us, rest {float((dur - acc_t - e1 - pl)[kind != 0].mean()):.1f} us")
+    print(f"  inverse tiles: park + wait {float(e1[kind == 1].mean()):.1f} us, multiply loop {float(pl[kind == 1].mean()):.1f} us, rest {float((dur - acc_t - e1 - pl)[kind == 1].mean()):.1f} us")
 wg = t[:, :, 1]
 nw = len(torch.unique(wg))
 busy = float(net.sum())
@@ -118,5 +121,12 @@ m0 = t[0]
 for tk in range(ntasks):
     c = int(m0[tk, 0])
     i, j = (c >> 6) & 63, c & 63
-    if i == j and (c >> 12) == 0:
+    if i == j and (c >> 12) in (0, 2):
         print(f"    D({j:2d}) ticket {tk:3d} wg {int(m0[tk,1]):3d} claim {(int(m0[tk,2])-t0)/100:8.1f} end {(int(m0[tk,3])-t0)/100:8.1f} poll {int(m0[tk,4])/100:7.1f}")
+if os.environ.get("GPZ_TRACE_ALL"):
+    print("    every task of matrix 0 (us from the first claim): kind i j | wg | claim end | polling, accumulate, park+wait, multiply")
+    rows = sorted(range(ntasks), key=lambda k: int(m0[k, 2]))
+    for tk in rows:
+        c = int(m0[tk, 0])
+        k, i, j = c >> 12, (c >> 6) & 63, c & 63
+        print(f"    {'CXFP'[k]}({i:2d},{j:2d}) wg {int(m0[tk,1]):3d} claim {(int(m0[tk,2])-t0)/100:8.1f} end {(int(m0[tk,3])-t0)/100:8.1f} | poll {int(m0[tk,4])/100:6.1f} acc {int(m0[tk,5])/100:6.1f} park {int(m0[tk,6])/100:6.1f} mult {int(m0[tk,7])/100:6.1f}")
