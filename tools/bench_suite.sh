@@ -53,6 +53,11 @@ python3 tools/coop_trace.py 32 2048 2>/dev/null | grep -v "    D("
 python3 tools/coop_trace.py 32 2048 1 2>/dev/null | grep -v "    D("
 python3 tools/coop_trace.py 8 512 1 2>/dev/null | grep -v "    D("
 python3 tools/coop_trace.py 20 3072 1 2>/dev/null | grep -v "    D("
+python3 tools/coop_trace.py 4 2048 1 2>/dev/null | grep -v "    D("
+echo "== the same with tiles (j,j-1) and (j,j) as two tasks, as in round 4 (GPZ_COOP_UNFUSED=1): L=8 M=512, L=4 M=2048, L=32 M=2048"
+GPZ_COOP_UNFUSED=1 python3 tools/coop_trace.py 8 512 1 2>/dev/null | grep "host-timed\|span"
+GPZ_COOP_UNFUSED=1 python3 tools/coop_trace.py 4 2048 1 2>/dev/null | grep "host-timed\|span"
+GPZ_COOP_UNFUSED=1 python3 tools/coop_trace.py 32 2048 1 2>/dev/null | grep "host-timed\|span"
 echo "== config 3 with the launch-per-step factor path, for comparison"
 GPZ_FACTOR_PATH=launches python3 bench.py --no-cpu-baseline --no-extra-legs --steps 5 --warmup 2 > /tmp/b.log 2>/dev/null; one /tmp/b.log
 echo "== minibatch step with the launch-per-step factor path"
