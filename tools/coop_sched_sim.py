@@ -4,6 +4,9 @@ Workers (workgroups of one matrix's cluster) claim tiles from ONE ordered list (
 any number of resident workers makes progress); a claimed tile walks its k-blocks in order and blocks on the flags of
 tiles that are not finished yet.  This script evaluates candidate orders for (nblk, G) with rough per-phase times and
 prints the makespan, so the order builder in csrc/coop.hip (same rules, in C++) can be chosen on paper first.
+(Round 4's task set: since round 5 the library fuses tiles (j, j-1) and (j, j) into one task, gives the diagonal tile's
+early sums a task of their own and announces a diagonal block's inverse ahead of its other stores -- build_order in
+coop.hip models that; the order it produces is checked by tests/test_abi.py, not by this script.)
 
     python tools/coop_sched_sim.py 16 8
 """
