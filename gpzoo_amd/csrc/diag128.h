@@ -72,80 +72,70 @@ __device__ __forceinline__ void sqrt_rsqrt(double d, double& sq, double& rs) {
   rs = h + h;
 }
 
-// The value the lanes of half `from` (0: lanes 0-31, 1: lanes 32-63) hold, in both halves: one v_permlane32_swap per word
-// (with the same register as both operands it leaves the low half's copy in one result and the high half's in the other).
-__device__ __forceinline__ double from_half(double v, int from) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double((int)h2[from], (int)l2[from]);
-}
-
 // One wave: right-looking Cholesky of the 32x32 block at offset o.  Row i lives in lanes i and i + 32: the low lane holds
 // its even columns, the high lane its odd ones (round 5; rounds 2-4 kept the whole row in both and did every update
-// twice -- the sweep is bound as much by what the one wave has to ISSUE per column as by the pivot chain, and this halves
-// the row updates and their LDS reads).  Per column the dependent chain is: pivot (v_readlane of the running diagonal),
-// its reciprocal square root (v_rsq_f64 + two coupled Goldschmidt steps), the multipliers l_ij = a_ij r in the half that
-// holds column j, their copy to the other half (v_permlane32_swap).  What the NEXT column needs from this one is only
-// a_(i,j+1) and the running diagonal a_ii - sum_k l_ik^2 (kept in both halves), so those two are updated at once
-// (multiplier by v_readlane) and the other row updates of the column are deferred into the next column's body, where
-// they issue in the latency shadow of its pivot chain with multipliers read back from the compact column buffer
-// CB[j][k] (two-address LDS broadcasts; the write -> read round trip is off the critical path by then).  Every element
-// sees the same updates in the same order as in the one-row-per-lane form: the factor is bit for bit the same.
-// RI[j] = 1 / l_jj for the inverse.
+// twice).  tools/valu_chain_probe.hip: on this chip a wave pays ~5 cycles for every vector instruction it issues and 8.5
+// for a dependent one, and independent work does NOT hide in a dependent chain's shadow -- a column costs the SUM of what
+// the wave issues, so the sweep is written for few instructions, not for a short chain:
+//   * per column the chain is: pivot (v_readlane), reciprocal square root (v_rsq_f64 + two coupled Goldschmidt steps),
+//     the multipliers l_ij = a_ij r in the half that holds column j, their store to the column buffer CB[j][.];
+//   * ALL updates by column j -- of column j + 1 as of the others -- are made in the next column's body with this row's
+//     multiplier and the columns' multipliers read back from CB (one plain and a few broadcast LDS reads: the half that
+//     did not compute l_ij gets it that way too, nothing is exchanged between the halves in registers); they are needed
+//     only when that column's reciprocal square root is through, ~100 cycles after the reads were issued;
+//   * the one value the next pivot needs at once, a_(j+1,j+1) - l_(j+1,j)^2, is formed separately from two v_readlane.
+// Every element sees the updates of columns 0, 1, 2, ... in that order with the same operands as in the one-row-per-lane
+// form of rounds 2-4: the factor is bit for bit the same.  No test of the pivot on the way (compare, select and branch
+// through scalar registers were 40 cycles a column): a non-positive pivot turns into NaN and spreads, and the diagonal
+// is looked at once behind the sweep.  RI[j] = 1 / l_jj for the inverse.
 __device__ __forceinline__ void factor32(double* S, double* CBu, double* RI, int o, int lane, int32_t* info,
                                          int64_t gbase, int64_t m_real) {
   const int zz = vzero();          // also keeps the 32 lane-compare masks from being hoisted out of the caller's loop
   const int i = (lane & 31) + zz;
   const int h = lane >> 5;         // this lane holds columns 2 m + h of row i in a[m]
-  const bool h1 = h != 0;
   const double* CB = CBu + zz + h;
   double a[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) a[m] = S[(o + i) * DP + o + 2 * m + h];
-  double diag = S[(o + i) * DP + o + i];
-  double lprev = 0.0;
+  double d = bcast(a[0], 0);
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
-    // (no test of the pivot here: compare, select and branch through scalar registers were 40 of the ~400 cycles a
-    // column takes -- tools/valu_chain_probe.hip.  A pivot that is not positive turns into NaN and spreads; the diagonal
-    // is looked at once, behind the sweep.)
-    const double d = bcast(diag, j);
-    // deferred row updates of column j-1 for the columns k >= j+1 (k = j was done on the spot there): independent of the
-    // pivot chain below.  k = 2 m + h >= j + 1 for m >= (j + 2) / 2 in both halves; for even j column j + 1 = 2 (j / 2) + 1
-    // of the high half is due as well, and the low half's register of that index is the pivot column: multiplier 0 there.
+    // the updates by column j - 1 of the columns c = 2 m + h >= j: m >= j / 2 in both halves (for odd j the low half's
+    // register (j - 1) / 2 is column j - 1, spent: updating it is harmless)
+    // (the reads are issued first, the reciprocal square root runs while they travel, the updates follow it)
+    double lprev = 0.0, cb[16];
     if (j >= 1) {
-      if ((j & 1) == 0) {
-        const double cb = CB[(j - 1) * 32 + j];
-        a[j / 2] = fma(-lprev, h1 ? cb : 0.0, a[j / 2]);
-      }
+      lprev = CBu[(j - 1) * 32 + i];
 #pragma unroll
-      for (int m = (j + 2) / 2; m < 16; ++m) a[m] = fma(-lprev, CB[(j - 1) * 32 + 2 * m], a[m]);
+      for (int m = j >> 1; m < 16; ++m) cb[m] = CB[(j - 1) * 32 + 2 * m];
     }
     double sq, r;
     sqrt_rsqrt(d, sq, r);
-    const double lmine = (i == j) ? sq : a[j >> 1] * r;      // the half (j & 1) holds column j; rows i < j carry garbage
-    const double lj = from_half(lmine, j & 1);               // ... that is never read back
-    diag = fma(-lj, lj, diag);
-    if (j + 1 < 32) {                                         // what column j+1 needs, now
-      const double bc = bcast(lj, j + 1);
-      // column j + 1 is register (j + 1) / 2 of the other half; in this half that register is column j (spent) when j is
-      // even and column j + 2 (live: multiplier 0) when j is odd
-      if ((j & 1) == 0) a[(j + 1) >> 1] = fma(-lj, bc, a[(j + 1) >> 1]);
-      else a[(j + 1) >> 1] = fma(-lj, h1 ? 0.0 : bc, a[(j + 1) >> 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (j >= 1) {
+#pragma unroll
+      for (int m = j >> 1; m < 16; ++m) a[m] = fma(-lprev, cb[m], a[m]);
     }
-    CBu[j * 32 + i] = lj;                             // twin lanes store the same value to the same address
-    if (i >= j) S[(o + i) * DP + o + j] = lj;
+    const double lj = (i == j) ? sq : a[j >> 1] * r;       // meaningful in the half (j & 1); rows i < j carry garbage
+    if (h == (j & 1)) {                                      // ... that is never read back
+      CBu[j * 32 + i] = lj;
+      if (i >= j) S[(o + i) * DP + o + j] = lj;
+    }
     // RI[j] doubles as the "column j is in LDS" flag for the wave that inverts this sub-block behind us (it was zeroed
     // before the sweep; 1 / l_jj > 0).  Stored LAST, as a release at WAVEFRONT scope: that only keeps the compiler from
     // moving the stores above behind it -- the hardware executes a wave's LDS operations in order -- whereas a
     // workgroup-scope release would make this wave drain its LDS queue in every column of the pivot chain.
     __hip_atomic_store(&RI[j], r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WAVEFRONT);   // wave-uniform
-    lprev = lj;
+    if (j + 1 < 32) {
+      // the next pivot: a_(j+1,j+1) as it stands (updated through column j - 1) minus l_(j+1,j)^2
+      const double bc = bcast(lj, j + 1 + 32 * (j & 1));
+      const double t = fma(-bc, bc, a[(j + 1) >> 1]);
+      d = bcast(t, j + 1 + 32 * ((j + 1) & 1));
+    }
     // pin the updates to this column: LLVM otherwise sinks each one to the column that consumes it and keeps
     // all the broadcast values alive until then (spills)
 #pragma unroll
-    for (int m = (j + 1) >> 1; m < 16; ++m) asm volatile("" : "+v"(a[m]));
+    for (int m = j >> 1; m < 16; ++m) asm volatile("" : "+v"(a[m]));
     __builtin_amdgcn_sched_barrier(0);
   }
   // LAPACK's info: the first column whose pivot was not positive.  sqrt / rsqrt of such a pivot is NaN (d < 0, d = NaN) or
@@ -203,30 +193,53 @@ __device__ __forceinline__ void invert32(double* S, const double* CBu, const dou
   }
 }
 
+// The value the lanes of half `from` (0: lanes 0-31, 1: lanes 32-63) hold, in both halves: one v_permlane32_swap per word
+// (with the same register as both operands it leaves the low half's copy in one result and the high half's in the other).
+__device__ __forceinline__ double from_half(double v, int from) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)h2[from], (int)l2[from]);
+}
+
 // invert32 run by a SECOND wave while the first one is still factoring the sub-block: step ii needs column ii of L
-// and 1 / l_ii only, which factor32 publishes column by column (RI[ii] turns non-zero last).  The substitution (~220-390 cycles per step) is faster than the factorisation (~415 per column), so this
-// wave trails by one step and the inverse is complete a few hundred cycles after the factor instead of 7 000.
+// and 1 / l_ii only, which factor32 publishes column by column (RI[ii] turns non-zero last).  It has to keep up with a
+// sweep of ~350 cycles a column (round 5), so, like the sweep, it is written for few instructions: column c of the
+// inverse lives in lanes c and c + 32, its even rows in the low lane and its odd rows in the high one (half the
+// multiply-adds and half the LDS reads of a lane owning the whole column; x_ii goes from the half that formed it to the
+// other by v_permlane32_swap), and a step's flag and multipliers come in ONE LDS round trip -- the flag's read is issued
+// first and a wave's LDS reads execute in order, so multipliers read behind a flag that turns out set are the
+// published ones (waiting for the flag and reading then was two round trips a step).
 __device__ __forceinline__ void invert32_follow(double* S, const double* CBu, double* RIu, int o, int lane) {
   const int z = vzero();
   const int c = (lane & 31) + z;
-  const double* CB = CBu + z;
+  const int h = lane >> 5;                       // this lane holds rows 2 m + h of column c in acc[m]
+  const double* CB = CBu + z + h;
   double* RI = RIu + z;
-  double acc[32];
+  double acc[16];
 #pragma unroll
-  for (int m = 0; m < 32; ++m) acc[m] = (m == c) ? 1.0 : 0.0;
+  for (int m = 0; m < 16; ++m) acc[m] = (2 * m + h == c) ? 1.0 : 0.0;
 #pragma unroll
   for (int ii = 0; ii < 32; ++ii) {
-    double ri;
-    while ((ri = __hip_atomic_load(&RI[ii], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0.0) __builtin_amdgcn_s_sleep(2);
-    double cb[32];
+    // rows 2 m + h > ii: m >= (ii + 1) / 2 in both halves (for even ii the low half's register ii / 2 is row ii itself:
+    // spent once x is formed, updating it is harmless)
+    double ri, cb[16];
+    for (;;) {
+      asm volatile("" ::: "memory");
+      ri = RI[ii];
+      asm volatile("" ::: "memory");
 #pragma unroll
-    for (int m = ii + 1; m < 32; ++m) cb[m] = CB[ii * 32 + m];
-    const double x = acc[ii] * ri;
-    if (lane < 32 && ii >= c) XT(S, o + c, o + ii) = x;
+      for (int m = (ii + 1) >> 1; m < 16; ++m) cb[m] = CB[ii * 32 + 2 * m];
+      asm volatile("" ::: "memory");
+      if (ri != 0.0) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const double x = from_half(acc[ii >> 1] * ri, ii & 1);
+    if (h == (ii & 1) && ii >= c) XT(S, o + c, o + ii) = x;
 #pragma unroll
-    for (int m = ii + 1; m < 32; ++m) acc[m] = fma(-cb[m], x, acc[m]);
+    for (int m = (ii + 1) >> 1; m < 16; ++m) acc[m] = fma(-cb[m], x, acc[m]);
 #pragma unroll
-    for (int m = ii + 1; m < 32; ++m) asm volatile("" : "+v"(acc[m]));
+    for (int m = (ii + 1) >> 1; m < 16; ++m) asm volatile("" : "+v"(acc[m]));
     __builtin_amdgcn_sched_barrier(0);
   }
 }
