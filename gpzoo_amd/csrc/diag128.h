@@ -281,6 +281,55 @@ __device__ __forceinline__ void factor_block(double* S, int tid, int32_t* info, 
   double* RI = CB + 32 * 32;
   const int lane = tid & 63, w = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
+  // tiles t = first, first + stride, ... < last of the trailing update of the step whose sub-block starts at o (R0 = o + 32):
+  // two tiles of a wave at a time, advanced together as independent MFMA chains; the loop condition makes both valid, so
+  // no MFMA sits under a branch; a possible last single tile follows
+  auto trail_tiles = [&](int o, int R0, int first, int stride, int last) __attribute__((always_inline)) {
+    auto tile_of = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
+      int ta = 0, rem = t;
+      while (rem > ta) { rem -= ta + 1; ++ta; }
+      i0 = R0 + 16 * ta; j0 = R0 + 16 * rem;
+    };
+    int t = first;
+    for (; t + stride < last; t += 2 * stride) {
+      int ia, ja, ib, jb;
+      tile_of(t, ia, ja);
+      tile_of(t + stride, ib, jb);
+      d4 acc0, acc1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { acc0[g] = S[(ia + q + 4 * g) * DP + ja + r]; acc1[g] = S[(ib + q + 4 * g) * DP + jb + r]; }
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k = o + 4 * kk + q;
+        acc0 = mma(-S[(ia + r) * DP + k], S[(ja + r) * DP + k], acc0);
+        acc1 = mma(-S[(ib + r) * DP + k], S[(jb + r) * DP + k], acc1);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { S[(ia + q + 4 * g) * DP + ja + r] = acc0[g]; S[(ib + q + 4 * g) * DP + jb + r] = acc1[g]; }
+    }
+    if (t < last) {
+      int i0, j0;
+      tile_of(t, i0, j0);
+      d4 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = S[(i0 + q + 4 * g) * DP + j0 + r];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k = o + 4 * kk + q;
+        acc = mma(-S[(i0 + r) * DP + k], S[(j0 + r) * DP + k], acc);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) S[(i0 + q + 4 * g) * DP + j0 + r] = acc[g];
+    }
+  };
+  // the tiles t >= 3 of the step before sub-block s, by the waves 2, 3, 6, 7 of SIMDs 2 and 3 (eight-wave workgroups)
+  auto trail_rest = [&](int s) __attribute__((always_inline)) {
+    if (NW != 8 || s < 1 || s > 2 || (w & 3) < 2) return;
+    constexpr int NH = 4;
+    const int hi = (w & 1) + 2 * (w >> 2);
+    const int R0 = 32 * s, n16 = (128 - R0) / 16;
+    trail_tiles(R0 - 32, R0, 3 + hi, NH, n16 * (n16 + 1) / 2);
+  };
   for (int s = 0; s < 4; ++s) {
     const int o = 32 * s;
     if (factor) {
@@ -294,6 +343,8 @@ __device__ __forceinline__ void factor_block(double* S, int tid, int32_t* info, 
 #ifndef GPZ_DIAG_NOFOLLOW
         invert32_follow(S, CB, RI, o, lane);
 #endif
+      } else {
+        trail_rest(s);
       }
     } else if (w == 0) {
       stage32(S, CB, RI, o, lane);
@@ -348,47 +399,17 @@ __device__ __forceinline__ void factor_block(double* S, int tid, int32_t* info, 
     }
     GPZ_STAMP(4 + 4 * s);
     // ---- in-block trailing update: A[a][b] -= L[a][s] L[b][s]^T, 16x16 tiles with a >= b ----
-    if (w < NW) {
+    // Only the three tiles of the NEXT diagonal sub-block (t = 0, 1, 2) stand between this step and the next sweep; they
+    // are done here, the others by the waves of SIMDs 2 and 3 WHILE that sweep runs on SIMDs 0 and 1 (trail_rest at the
+    // top of the loop: the sweep touches nothing but its sub-block, the column buffer and the strictly upper triangle;
+    // the barrier that ends it is the one these tiles are needed behind).
+    // (With four waves there are two left for that, and the 18 other tiles of the first step take them longer than the
+    // sweep lasts: measured no gain -- all tiles stay here then.)
+    if (NW == 8) {
+      if (w >= 2 && w < 5) trail_tiles(o, R0, w - 2, 3, 3);
+    } else if (w < NW) {
       const int n16 = (128 - R0) / 16;
-      const int nl = n16 * (n16 + 1) / 2;
-      // two tiles of a wave at a time (t and t + NW), advanced together as independent MFMA chains; the loop condition
-      // makes both valid, so no MFMA sits under a branch; a possible last single tile follows
-      auto tile_of = [&](int t, int& i0, int& j0) __attribute__((always_inline)) {
-        int ta = 0, rem = t;
-        while (rem > ta) { rem -= ta + 1; ++ta; }
-        i0 = R0 + 16 * ta; j0 = R0 + 16 * rem;
-      };
-      int t = w;
-      for (; t + NW < nl; t += 2 * NW) {
-        int ia, ja, ib, jb;
-        tile_of(t, ia, ja);
-        tile_of(t + NW, ib, jb);
-        d4 acc0, acc1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { acc0[g] = S[(ia + q + 4 * g) * DP + ja + r]; acc1[g] = S[(ib + q + 4 * g) * DP + jb + r]; }
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const int k = o + 4 * kk + q;
-          acc0 = mma(-S[(ia + r) * DP + k], S[(ja + r) * DP + k], acc0);
-          acc1 = mma(-S[(ib + r) * DP + k], S[(jb + r) * DP + k], acc1);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { S[(ia + q + 4 * g) * DP + ja + r] = acc0[g]; S[(ib + q + 4 * g) * DP + jb + r] = acc1[g]; }
-      }
-      if (t < nl) {
-        int i0, j0;
-        tile_of(t, i0, j0);
-        d4 acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = S[(i0 + q + 4 * g) * DP + j0 + r];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const int k = o + 4 * kk + q;
-          acc = mma(-S[(i0 + r) * DP + k], S[(j0 + r) * DP + k], acc);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) S[(i0 + q + 4 * g) * DP + j0 + r] = acc[g];
-      }
+      trail_tiles(o, R0, w, NW, n16 * (n16 + 1) / 2);
     }
     __syncthreads();
     GPZ_STAMP(5 + 4 * s);
