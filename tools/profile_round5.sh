@@ -30,6 +30,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_poisson -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_poisson20 -- python3 tools/poisson_step.py 20 > $out/trace_poisson20.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_vnngp -- python3 tools/vnngp_step.py > $out/trace_vnngp.log 2>&1
 echo "traces done"
+# PMC passes over the default bench line WITH its training legs (forward + backward at config 3 and configs[1]): how busy the
+# matrix pipes are under the backward pass's kernels
+T="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq_train -- $T > $out/pmc_sq_train.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_l2_train -- $T > $out/pmc_l2_train.log 2>&1
+python3 tools/pmc_summary.py $out/pmc_sq_train $out/pmc_l2_train --json $pub/pmc_train.json > /dev/null
+echo "train pmc done"
 python3 tools/publish_profile5.py rest $out $pub
 python3 tools/nsf_benchmark_step.py 300 > $pub/nsf_benchmark_steps.txt 2>&1 || true
 python3 tools/small_step.py > $pub/small_step.txt 2>/dev/null || true

@@ -101,6 +101,16 @@ if b:
               f"(floor {v['mfma_floor_ms']:.2f} ms)")
 for name, calls, avg, tot in sorted(rows(st, lambda n: "gemmw" in n or "kgrad" in n or "kfill" in n or "panel" in n or "coop" in n), key=lambda r: -r[3])[:14]:
     P(f"  {name[:86]:86s} {calls:5d} calls  avg {avg:8.3f} ms  total {tot:9.1f} ms")
+if os.path.exists(dst + "/pmc_train.json"):
+    pt = json.load(open(dst + "/pmc_train.json"))
+    P("  matrix pipes and L2 under the same command (separate rocprofv3 --pmc passes, averaged over a kernel's dispatches -- launches")
+    P("  that leave at their gate included -- profiles/<round>/pmc_train.json): SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8)")
+    for k in sorted(pt, key=lambda k: -pt[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * pt[k].get("dispatches", 0)):
+        w = pt[k]
+        if w.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) <= 0 or not w.get("GRBM_GUI_ACTIVE"):
+            continue
+        hit = w.get("TCC_HIT_sum", 0.0) / max(1.0, w.get("TCC_HIT_sum", 0.0) + w.get("TCC_MISS_sum", 0.0))
+        P(f"    {k[:70]:70s} {int(w['dispatches']):4d} dispatches  MFMA pipes busy {w['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * w['GRBM_GUI_ACTIVE'] / 8):.3f}  L2 hit {hit:.3f}")
 
 # ---- configs[1] ----
 st = stats("_cfg2")
