@@ -2,7 +2,9 @@
 """Timeline of the one-launch factorisation (csrc/coop.hip): per-task claim / end stamps and polling time.
 
     python tools/coop_trace.py L M [inverse=1]
-Prints the launch's span, per-kind task counts and mean durations net of polling, and the utilisation of the clusters.
+Prints the launch's span, per-kind task counts and mean durations net of polling, and the utilisation of the clusters;
+GPZ_TRACE_ALL=1: every task of matrix 0 with its claim / end times (for a diagonal block: `park` = factor, `mult` = inverse
+levels); GPZ_COOP_UNFUSED=1: round 4's task list (tiles (j, j-1) and (j, j) as two tasks).
 """
 import ctypes as C
 import os
