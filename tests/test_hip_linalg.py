@@ -114,3 +114,62 @@ def test_one_launch_factorisation_gives_up_instead_of_hanging():
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["msg"] is not None and "timed out" in out["msg"] and "-7" in out["msg"]
     assert out["seconds"] < 5.0 and out["healthy"]
+
+
+_TASK_LIST_CHILD = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, {root!r})
+import torch
+from gpzoo_amd import _lib
+lib = _lib.load()
+lib.gpz_debug_factor_sync_words.restype = C.c_size_t
+lib.gpz_debug_factor_sync_words.argtypes = [C.c_int64, C.c_int64]
+lib.gpz_debug_factor_invert.restype = C.c_int
+lib.gpz_debug_factor_invert.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6
+out = {{}}
+for L, M in ((3, 256), (5, 640), (2, 1408)):
+    g = torch.Generator().manual_seed(M)
+    B = torch.randn(L, M, M, generator=g, dtype=torch.float64)
+    A = (B @ B.transpose(-1, -2) / M + torch.eye(M, dtype=torch.float64)).cuda()
+    nblk = M // 128
+    Dinv = torch.empty(L * nblk * 128 * 128, dtype=torch.float64, device="cuda")
+    Linv = torch.full((L, M, M), float("nan"), dtype=torch.float64, device="cuda")
+    T = torch.empty(L, M, M, dtype=torch.float64, device="cuda")
+    sync = torch.empty(lib.gpz_debug_factor_sync_words(M, L), dtype=torch.int32, device="cuda")
+    info = torch.empty(L, dtype=torch.int32, device="cuda")
+    W = A.clone()
+    rc = lib.gpz_debug_factor_invert(W.data_ptr(), M, L, Dinv.data_ptr(), Linv.data_ptr(), T.data_ptr(), sync.data_ptr(),
+                                     info.data_ptr(), None)
+    torch.cuda.synchronize()
+    Lc = torch.tril(W)
+    ref = torch.linalg.cholesky(A)
+    eye = torch.eye(M, dtype=torch.float64, device="cuda")
+    out[str(M)] = dict(rc=rc, info=int(info.abs().max()), factor=float((Lc - ref).abs().max() / ref.abs().max()),
+                      inverse=float((torch.tril(Linv) @ Lc - eye).abs().max()), above=float(torch.triu(Linv, 1).abs().max()))
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("unfused", [False, True])
+def test_both_task_lists_of_the_one_launch_factorisation(unfused):
+    """csrc/coop.hip claims tiles (j, j-1) and (j, j) as one task since round 5 (the tile below the diagonal stays in LDS for
+    the diagonal tile's last update); GPZ_COOP_UNFUSED selects round 4's list, read once per process -- hence a child
+    process per list.  Factor against LAPACK, inverse against the factor, nothing above the diagonal; 2, 5 and 11 block
+    columns (an even, an odd count and one where every fused task has parked sums)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("GPZ_FACTOR_PATH", None)
+    env.pop("GPZ_COOP_UNFUSED", None)
+    if unfused:
+        env["GPZ_COOP_UNFUSED"] = "1"
+    p = subprocess.run([sys.executable, "-c", _TASK_LIST_CHILD.format(root=root)], capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    for M, r in out.items():
+        assert r["rc"] == 0 and r["info"] == 0, (M, r)
+        assert r["factor"] < 1e-13 and r["inverse"] < 1e-12 and r["above"] == 0.0, (M, r)
