@@ -173,3 +173,27 @@ def test_both_task_lists_of_the_one_launch_factorisation(unfused):
     for M, r in out.items():
         assert r["rc"] == 0 and r["info"] == 0, (M, r)
         assert r["factor"] < 1e-13 and r["inverse"] < 1e-12 and r["above"] == 0.0, (M, r)
+
+
+@pytest.mark.parametrize("k", [1, 2, 32, 33, 64, 65, 96, 127, 128, 129, 160, 255, 256, 257, 300])
+def test_first_failing_minor_at_sub_block_and_block_boundaries(k):
+    """LAPACK's info = the order of the first leading minor that is not positive-definite.  Since round 5 the pivot sweep
+    (csrc/diag128.h factor32) does not test pivots on its way: a non-positive one becomes NaN, spreads, and the diagonal is
+    looked at once per 32 columns -- so the reported order is checked here at every kind of boundary (first / last column of
+    a 32-column sub-block, of a 128-column block, of the matrix), against torch's own message, for a negative pivot (and,
+    where it can be made exactly, a zero one: k = 1), with a second matrix in the batch that is fine."""
+    from gpzoo_amd import ops
+    M = 300
+    A = spd(2, M, 11)
+    for bad in ((-0.5, 0.0) if k == 1 else (-0.5,)):
+        B = A.clone()
+        Lref = torch.linalg.cholesky(A[0])
+        # make the k-th pivot exactly `bad`: a_kk <- (sum of squares of the row of the factor before it) + bad
+        B[0, k - 1, k - 1] = (Lref[k - 1, :k - 1] ** 2).sum() + bad
+        with pytest.raises(torch.linalg.LinAlgError) as mine:
+            ops.cholesky(B.cuda())
+        with pytest.raises(torch.linalg.LinAlgError) as theirs:
+            torch.linalg.cholesky(B)
+        if bad < 0:
+            assert str(mine.value) == str(theirs.value)
+        assert f"minor of order {k}" in str(mine.value) and "Batch element 0" in str(mine.value)
